@@ -1,0 +1,189 @@
+/*
+ * pmc.h -- C ABI of libpmc_hip.so: the MI355X (gfx950) implementation of the
+ * ParticlesMC pair-energy + Metropolis hot path.
+ *
+ * The reference (Julia) has no FFI; these are the entry points a `ccall` shim
+ * for this path binds (INTEGRATION.md shows the Julia side).  Each function
+ * cites the reference interface it replaces (paths relative to the reference
+ * tree).  Conventions:
+ *   - particle ids and species are 1-based at the ABI (reference convention);
+ *   - positions are AoS N*d doubles, never wrapped (src/moves.jl:46-48);
+ *   - the caller owns every host buffer; the library owns device memory behind
+ *     the handle and retains no host pointer past a call;
+ *   - every function returns 0 or a negative pmc_status; nothing throws or
+ *     exits; pmc_last_error() gives the text;
+ *   - one handle = one chain on one HIP device with one stream; a handle is not
+ *     thread-safe, distinct handles are (Arianna's chain-level parallelism).
+ */
+#ifndef PMC_H
+#define PMC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PMC_OK = 0,
+    PMC_ERR_BADARG = -1,
+    PMC_ERR_HIP = -2,
+    PMC_ERR_NONFINITE = -3,   /* "Initial configuration has infinite or NaN energy." src/atoms.jl:53-55 */
+    PMC_ERR_UNSUPPORTED = -4,
+    PMC_ERR_STATE = -5
+} pmc_status;
+
+/* src/models.jl: LennardJones 99-123, SoftSpheres 52-74, SmoothLennardJones 137-167 */
+typedef enum {
+    PMC_MODEL_LJ = 0,
+    PMC_MODEL_SOFT_INT = 1,    /* even n: (sigma2/r2)^(n/2) with an integer power */
+    PMC_MODEL_SOFT_FLOAT = 2,  /* odd n */
+    PMC_MODEL_SMOOTH_LJ = 3
+} pmc_model_kind;
+
+/* One entry of system.model_matrix (src/atoms.jl:25); all derived constants are
+ * computed by the HOST exactly as the reference constructors do. */
+typedef struct {
+    int32_t kind;
+    int32_t n;
+    double eps, eps4, sigma, sigma2, rcut, rcut2, shift;
+    int64_t ndiv2_i;
+    double ndiv2_f;
+    double C0, C2_s2, C4_s4;
+} pmc_pair_model;
+
+/* Atoms + LinkedList geometry (src/atoms.jl:18-30,45; src/neighbours.jl:236-238).
+ * box, cell and ncells are computed by the host so that cell membership is
+ * bit-exact with the reference. */
+typedef struct {
+    int64_t N;
+    int32_t d;                 /* 2 or 3 */
+    int32_t nspecies;
+    double box[3];
+    double cell[3];
+    int64_t ncells[3];
+    double temperature;
+    double density;
+    const pmc_pair_model *models;   /* nspecies*nspecies, row-major [s_i-1][s_j-1] */
+    int32_t device;
+    uint32_t chain;
+    uint64_t seed;
+} pmc_params;
+
+typedef enum { PMC_MOVE_DISPLACEMENT = 0, PMC_MOVE_SWAP = 1 } pmc_move_kind;
+
+/* Arianna Move(action, policy, parameters, probability): Displacement +
+ * SimpleGaussian (src/moves.jl:34-38,105-123), DiscreteSwap + DoubleUniform
+ * (src/moves.jl:137-149,226-241). */
+typedef struct {
+    int32_t kind;
+    int32_t species[2];
+    double probability;
+    double sigma;
+} pmc_move;
+
+#define PMC_MAX_MOVES 8
+
+typedef enum {
+    PMC_SEQUENTIAL = 0,    /* the reference's one-particle-per-step chain (src/moves.jl:57-81) */
+    PMC_CHECKERBOARD = 1   /* many independent proposals per sweep (DESIGN.md "schedule") */
+} pmc_mode;
+
+typedef struct {
+    int64_t attempted[PMC_MAX_MOVES];
+    int64_t accepted[PMC_MAX_MOVES];
+    double energy;        /* system.energy[1] after the call */
+    int64_t energy_fix;   /* same, in units of 2^-32 (checkerboard mode; exact) */
+    double kernel_ms;     /* HIP-event time of the sweep kernels on the handle's stream */
+    double sweep_kernel_ms; /* of which: the dE/Metropolis kernel alone */
+    int64_t sweep_kernel_launches;
+} pmc_stats;
+
+typedef struct pmc_system pmc_system;
+
+/* -- lifetime ------------------------------------------------------------- */
+int pmc_create(const pmc_params *p, pmc_system **out);          /* Atoms(...) src/atoms.jl:40-49 */
+int pmc_destroy(pmc_system *h);
+const char *pmc_last_error(const pmc_system *h);                /* h may be NULL */
+int pmc_device_count(int *n);
+
+/* -- host-side constructors (pure host arithmetic; usable without a GPU) ----
+ * A Julia caller already owns these numbers (it passes its own structs); hosts
+ * without the reference's constructors use these restatements. */
+int pmc_model_lennard_jones(double eps, double sigma, double rcut, int32_t shift_potential,
+                            pmc_pair_model *out);                 /* LennardJones(...) src/models.jl:110-119 */
+int pmc_model_soft_spheres(double eps, double sigma, int32_t n, double rcut,
+                           pmc_pair_model *out);                  /* SoftSpheres(...) src/models.jl:64-70 */
+int pmc_model_smooth_lennard_jones(double eps, double sigma, double rcut,
+                                   pmc_pair_model *out);          /* SmoothLennardJones(...) src/models.jl:150-160 */
+int pmc_potential(double r2, const pmc_pair_model *m, double *u); /* potential(r2, model) src/models.jl:72,121,162 */
+int pmc_box_from_density(int64_t N, double density, int32_t d, double *box);   /* src/atoms.jl:45 */
+int pmc_linked_list_geometry(int32_t d, const double *box, double rcut,
+                             double *cell, int64_t *ncells);      /* LinkedList(box, rcut, N) src/neighbours.jl:237-238 */
+
+/* -- state ---------------------------------------------------------------- */
+int pmc_upload(pmc_system *h, const double *pos, const int32_t *species);   /* system.position / .species */
+int pmc_download(pmc_system *h, double *pos, int32_t *species);
+int pmc_set_temperature(pmc_system *h, double T);               /* system.temperature */
+int pmc_get_temperature(pmc_system *h, double *T);
+int pmc_set_energy(pmc_system *h, double e);                    /* system.energy[1] */
+int pmc_get_energy(pmc_system *h, double *e);
+int pmc_set_counters(pmc_system *h, uint64_t step, uint64_t sweep);  /* RNG stream position */
+int pmc_get_counters(pmc_system *h, uint64_t *step, uint64_t *sweep);
+
+/* -- LinkedList (reference-order engine) ---------------------------------- */
+int pmc_build_cells(pmc_system *h);                             /* build_neighbour_list! src/neighbours.jl:251-270 */
+int pmc_get_cells(pmc_system *h, int64_t *cs);                  /* neighbour_list.cs, 1-based */
+int pmc_get_linked_list(pmc_system *h, int64_t *head, int64_t *list); /* .head (-1 = empty), .list */
+int pmc_get_neighbour_cells(pmc_system *h, int64_t c, int64_t *out, int32_t *n); /* .neighbour_cells[c] src/neighbours.jl:94-111 */
+int pmc_energy_particle(pmc_system *h, int64_t i, double *e);   /* compute_energy_particle src/atoms.jl:81-88 */
+int pmc_energy_particles(pmc_system *h, double *e);             /* [compute_energy_particle(i) for i] src/atoms.jl:51 */
+int pmc_init_energy(pmc_system *h, double *e);                  /* build list + sum(local)/2 + Inf/NaN guard, src/atoms.jl:50-56 */
+
+int pmc_species_count(pmc_system *h, int32_t sp, int64_t *n);    /* length(species_list.sp_ids[sp]) src/utils.jl:31-34 */
+int pmc_get_species_ids(pmc_system *h, int32_t sp, int64_t *ids);/* species_list.sp_ids[sp], current order */
+
+/* -- per-move verbs (batch of one; reference semantics incl. system.energy) */
+int pmc_displacement_perform(pmc_system *h, int64_t i, const double *delta,
+                             double *e1, double *e2, double *de);   /* src/moves.jl:11-20,57-67 */
+int pmc_displacement_revert(pmc_system *h, int64_t i, const double *minus_delta, double de); /* src/moves.jl:76-81 */
+int pmc_swap_perform(pmc_system *h, int64_t i, int64_t j,
+                     double *e1, double *e2, double *de);           /* src/moves.jl:11-20,187-194 */
+int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de);/* src/moves.jl:201-207 */
+
+/* -- throughput engine ----------------------------------------------------- */
+int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix);  /* sum(local)/2 src/atoms.jl:51-52, exact fixed-point */
+int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const double *delta,
+                double *e1, double *e2);                          /* independent batch of Displacement dE */
+int pmc_grid(pmc_system *h, int64_t *n_mc, double *w);            /* checkerboard grid geometry */
+
+/* mc_sweep!(system, pool, rng; mc_steps = nsweeps * N) -- the Arianna entry
+ * the reference reaches from run!(Simulation) (src/ParticlesMC.jl:246,294-297;
+ * benchmark/particles_benchmarks.jl:29). */
+int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
+              int64_t nsweeps, pmc_stats *out);
+
+/* -- parallel tempering (no reference counterpart: README.md:33 "soon") ----- */
+/* Deterministic swap decisions for one exchange round over n replicas:
+ * label[r] = index of the temperature replica r currently holds; pairs of
+ * adjacent temperatures (2k + parity, 2k + parity + 1); accept with
+ * min(1, exp((beta_a - beta_b) (E_a - E_b))).  Every rank calls this with the
+ * same all-gathered energies and gets the same answer. */
+int pmc_pt_decide(uint64_t seed, uint64_t round, int32_t n, const double *energy,
+                  const double *temperature_ladder, int32_t *label, int32_t *n_accepted);
+
+/* -- the schedule's random streams, host side (DESIGN.md "random streams") -- */
+int pmc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+int pmc_box_muller(uint32_t w1, uint32_t w2, double *z0, double *z1);
+int pmc_log_uniform(uint32_t hi, uint32_t lo, double *lnu);       /* log of the 53-bit uniform in (0,1) */
+/* words of sequential step `step`: R = block TAG_SEQ0, Q = block TAG_SEQ1 */
+int pmc_sequential_words(uint64_t seed, uint32_t chain, uint64_t step, uint32_t R[4], uint32_t Q[4]);
+
+/* -- debug / test hooks ----------------------------------------------------- */
+int pmc_debug_rng(pmc_system *h, int64_t n, const uint32_t *w1, const uint32_t *w2,
+                  double *z0, double *z1, double *lnu);           /* device Box-Muller / log, for bit-parity tests */
+const char *pmc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1201 @@
+// pmc_hip.hip -- C ABI (include/pmc.h) over the gfx950 kernels of pmc_kernels.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include "../../include/pmc.h"
+#include "pmc_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+struct pmc_system {
+    pmc_params p;
+    std::vector<pmc_pair_model> models;
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int N = 0, D = 0, S = 0;
+    int kind = 0;                // common model kind, 4 = mixed
+    double energy = 0.0;         // system.energy[1]
+    long long e_fix = 0;
+    bool e_fix_valid = false;
+    uint64_t step_ctr = 0, sweep_ctr = 0;
+    uint32_t key[2] = {0, 0};
+    // particle-id-ordered state
+    double *d_pos = nullptr;
+    int *d_species = nullptr;
+    DevModel *d_models = nullptr;
+    // reference LinkedList
+    int ncell_ref = 0, nn = 0;
+    int *d_cs = nullptr, *d_head = nullptr, *d_list = nullptr, *d_ccount = nullptr;
+    int *d_nbr = nullptr, *d_nbrcnt = nullptr;
+    std::vector<int> h_nbr, h_nbrcnt;
+    bool cells_built = false;
+    int *d_sp_off = nullptr, *d_sp_ids = nullptr, *d_sp_heads = nullptr;
+    bool species_list_built = false;
+    double *d_energy = nullptr;
+    // binning scratch
+    int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
+    int *d_start_ref = nullptr, *d_ids_ref = nullptr;
+    // throughput grid
+    bool mc_ok = false;
+    GridGeom grid{};
+    int ncell_mc = 0;
+    int *d_start = nullptr, *d_ids = nullptr;
+    double *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr;
+    unsigned char *d_ssp = nullptr;
+    bool mc_binned = false;      // CSR + SoA consistent with d_pos
+    unsigned long long *d_stats = nullptr;
+    double *d_result = nullptr;
+    int max_count = 0;
+};
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char buf_[512];                                                                     \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                     __FILE__, __LINE__);                                                       \
+            if (h) (h)->err = buf_;                                                             \
+            g_err = buf_;                                                                       \
+            return PMC_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+static int fail(pmc_system *h, int code, const char *msg)
+{
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+
+static int set_device(pmc_system *h) { HIPCHK(h, hipSetDevice(h->p.device)); return PMC_OK; }
+
+extern "C" const char *pmc_version(void) { return "particlesmc-hip 0.1 (gfx950)"; }
+
+extern "C" const char *pmc_last_error(const pmc_system *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+extern "C" int pmc_device_count(int *n)
+{
+    if (!n) return PMC_ERR_BADARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; g_err = hipGetErrorString(e); return PMC_ERR_HIP; }
+    *n = c;
+    return PMC_OK;
+}
+
+// ---- host-side restatements of the reference constructors -----------------------------
+
+static double h_lennard_jones(double r2, double eps4, double sigma2)   // src/models.jl:30-34
+{
+    double x = sigma2 * (1.0 / r2);
+    double x3 = x * x * x;
+    return eps4 * (x3 * x3 - x3);
+}
+
+static double h_pow_int(double x, long long n)   // Julia Base pow_body, as dev_pow_int
+{
+    double y = 1.0, xnlo = 0.0, ynlo = 0.0, err, hi;
+    if (n == 3) return x * x * x;
+    if (n < 0) {
+        double rx = 1.0 / x;
+        if (n == -2) return rx * rx;
+        if (std::isfinite(x)) xnlo = -std::fma(x, rx, -1.0) * rx;
+        x = rx;
+        n = -n;
+    }
+    while (n > 1) {
+        if (n & 1) {
+            err = std::fma(y, xnlo, x * ynlo);
+            hi = x * y;
+            ynlo = std::fma(x, y, -hi);
+            y = hi;
+            ynlo += err;
+        }
+        err = x * 2.0 * xnlo;
+        hi = x * x;
+        xnlo = std::fma(x, x, -hi);
+        x = hi;
+        xnlo += err;
+        n >>= 1;
+    }
+    err = std::fma(y, xnlo, x * ynlo);
+    if (std::isfinite(x) && std::isfinite(err)) return std::fma(x, y, err);
+    return x * y;
+}
+
+static double h_potential(double r2, const pmc_pair_model &m)
+{
+    switch (m.kind) {
+    case PMC_MODEL_LJ: return h_lennard_jones(r2, m.eps4, m.sigma2) - m.shift;
+    case PMC_MODEL_SOFT_INT: return m.eps * h_pow_int(m.sigma2 / r2, m.ndiv2_i) - m.shift;
+    case PMC_MODEL_SOFT_FLOAT: return m.eps * pow(m.sigma2 / r2, m.ndiv2_f) - m.shift;
+    default: {
+        double lj = h_lennard_jones(r2, m.eps4, m.sigma2);
+        double sh = m.eps4 * (m.C0 + r2 * std::fma(r2, m.C4_s4, m.C2_s2));
+        return lj + sh;
+    }
+    }
+}
+
+extern "C" int pmc_model_lennard_jones(double eps, double sigma, double rcut, int32_t shift_potential,
+                                       pmc_pair_model *out)
+{
+    if (!out) return PMC_ERR_BADARG;
+    memset(out, 0, sizeof *out);
+    out->kind = PMC_MODEL_LJ;
+    out->eps = eps; out->eps4 = 4.0 * eps; out->sigma = sigma; out->sigma2 = sigma * sigma;
+    out->rcut = rcut; out->rcut2 = rcut * rcut;
+    out->shift = shift_potential ? h_lennard_jones(out->rcut2, out->eps4, out->sigma2) : 0.0;
+    return PMC_OK;
+}
+
+extern "C" int pmc_model_soft_spheres(double eps, double sigma, int32_t n, double rcut, pmc_pair_model *out)
+{
+    if (!out) return PMC_ERR_BADARG;
+    memset(out, 0, sizeof *out);
+    out->n = n; out->eps = eps; out->sigma = sigma; out->sigma2 = sigma * sigma;
+    out->rcut = rcut; out->rcut2 = rcut * rcut;
+    if (n & 1) { out->kind = PMC_MODEL_SOFT_FLOAT; out->ndiv2_f = (double)n / 2.0; }
+    else { out->kind = PMC_MODEL_SOFT_INT; out->ndiv2_i = n / 2; }
+    out->shift = 0.0;
+    out->shift = h_potential(out->rcut2, *out);   // inverse_power(rcut2, ...) src/models.jl:68
+    return PMC_OK;
+}
+
+extern "C" int pmc_model_smooth_lennard_jones(double eps, double sigma, double rcut, pmc_pair_model *out)
+{
+    if (!out) return PMC_ERR_BADARG;
+    memset(out, 0, sizeof *out);
+    out->kind = PMC_MODEL_SMOOTH_LJ;
+    out->eps = eps; out->eps4 = 4.0 * eps; out->sigma = sigma; out->sigma2 = sigma * sigma;
+    out->C0 = 0.04049023795;
+    out->C2_s2 = -0.00970155098 / out->sigma2;
+    out->C4_s4 = 0.00062012616 / (out->sigma2 * out->sigma2);
+    out->rcut = rcut; out->rcut2 = rcut * rcut;
+    return PMC_OK;
+}
+
+extern "C" int pmc_potential(double r2, const pmc_pair_model *m, double *u)
+{
+    if (!m || !u) return PMC_ERR_BADARG;
+    *u = h_potential(r2, *m);
+    return PMC_OK;
+}
+
+extern "C" int pmc_box_from_density(int64_t N, double density, int32_t d, double *box)
+{
+    if (!box || d < 1 || d > 3 || !(density > 0.0) || N < 1) return PMC_ERR_BADARG;
+    double b = pow((double)N / density, 1.0 / (double)d);   // src/atoms.jl:45 (libm pow)
+    for (int a = 0; a < d; a++) box[a] = b;
+    return PMC_OK;
+}
+
+static double h_jl_fld(double x, double y)   // Julia Base fld for floats (base/div.jl)
+{
+    double r = fmod(x, y), m;
+    if (r == 0.0) m = copysign(r, y);
+    else if ((r > 0.0) != (y > 0.0)) m = r + y;
+    else m = r;
+    return rint((x - m) / y);
+}
+
+extern "C" int pmc_linked_list_geometry(int32_t d, const double *box, double rcut, double *cell, int64_t *ncells)
+{
+    if (!box || !cell || !ncells || d < 1 || d > 3 || !(rcut > 0.0)) return PMC_ERR_BADARG;
+    for (int a = 0; a < d; a++) {
+        cell[a] = box[a] / h_jl_fld(box[a], rcut);         // src/neighbours.jl:237
+        double q = box[a] / cell[a];                       // src/neighbours.jl:238: Int(box / cell)
+        if (!(q >= 1.0) || q != rint(q)) {
+            g_err = "LinkedList: box / cell is not a positive integer (rcut larger than the box?)";
+            return PMC_ERR_BADARG;
+        }
+        ncells[a] = (int64_t)q;
+    }
+    return PMC_OK;
+}
+
+static DevModel to_dev(const pmc_pair_model &m)
+{
+    DevModel d;
+    d.kind = m.kind; d.n = m.n; d.eps = m.eps; d.eps4 = m.eps4; d.sigma2 = m.sigma2;
+    d.rcut2 = m.rcut2; d.shift = m.shift; d.ndiv2_i = m.ndiv2_i; d.ndiv2_f = m.ndiv2_f;
+    d.C0 = m.C0; d.C2_s2 = m.C2_s2; d.C4_s4 = m.C4_s4;
+    return d;
+}
+
+static long long fld_i(long long a, long long b)
+{
+    long long q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) q -= 1;
+    return q;
+}
+
+// cell_index + build_neighbour_cells, src/neighbours.jl:79-111 (0-based output)
+static void host_neighbour_cells(pmc_system *h)
+{
+    const int D = h->D;
+    const int nn = (D == 3) ? 27 : 9;
+    h->nn = nn;
+    long long nc[3] = {h->p.ncells[0], h->p.ncells[1], D == 3 ? h->p.ncells[2] : 1};
+    auto cidx = [&](const long long *mc) {
+        long long c = 0, stride = 1;
+        for (int a = D - 1; a >= 0; a--) {
+            long long f = mc[a] - fld_i(mc[a], nc[a]) * nc[a];
+            c += f * stride;
+            stride *= nc[a];
+        }
+        return (int)c;
+    };
+    h->h_nbr.assign((size_t)h->ncell_ref * nn, -1);
+    h->h_nbrcnt.assign((size_t)h->ncell_ref, 0);
+    long long mc[3] = {1, 1, 1};
+    for (int it = 0; it < h->ncell_ref; it++) {
+        int c = cidx(mc);
+        int cnt = 0;
+        int *out = &h->h_nbr[(size_t)c * nn];
+        for (int o = 0; o < nn; o++) {
+            long long mc2[3] = {0, 0, 0};
+            int r = o;
+            for (int a = 0; a < D; a++) { mc2[a] = mc[a] + (r % 3) - 1; r /= 3; }
+            int c2 = cidx(mc2);
+            bool dup = false;
+            for (int k = 0; k < cnt; k++) if (out[k] == c2) { dup = true; break; }   // unique!
+            if (!dup) out[cnt++] = c2;
+        }
+        h->h_nbrcnt[c] = cnt;
+        for (int a = 0; a < D; a++) {
+            if (++mc[a] <= nc[a]) break;
+            mc[a] = 1;
+        }
+    }
+}
+
+extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
+{
+    if (!p || !out) return fail(nullptr, PMC_ERR_BADARG, "pmc_create: null argument");
+    *out = nullptr;
+    if (p->N < 1 || p->N > 2000000000LL) return fail(nullptr, PMC_ERR_BADARG, "pmc_create: N out of range");
+    if (p->d != 2 && p->d != 3) return fail(nullptr, PMC_ERR_BADARG, "pmc_create: d must be 2 or 3");
+    if (p->nspecies < 1 || p->nspecies > 8 || !p->models)
+        return fail(nullptr, PMC_ERR_BADARG, "pmc_create: nspecies must be 1..8 with a model matrix");
+    if (!(p->temperature > 0.0)) return fail(nullptr, PMC_ERR_BADARG, "pmc_create: temperature must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, PMC_ERR_HIP, "pmc_create: no HIP device available (the HIP path has no CPU fallback)");
+    if (p->device < 0 || p->device >= ndev) return fail(nullptr, PMC_ERR_BADARG, "pmc_create: bad device index");
+
+    pmc_system *h = new pmc_system();
+    h->p = *p;
+    h->N = (int)p->N;
+    h->D = p->d;
+    h->S = p->nspecies;
+    h->models.assign(p->models, p->models + (size_t)h->S * h->S);
+    h->p.models = nullptr;
+    h->key[0] = (uint32_t)p->seed;
+    h->key[1] = (uint32_t)(p->seed >> 32) + p->chain;
+    h->kind = h->models[0].kind;
+    double maxcut = 0.0;
+    for (auto &m : h->models) {
+        if (m.kind != h->kind) h->kind = 4;
+        if (m.kind < 0 || m.kind > 3) { delete h; return fail(nullptr, PMC_ERR_BADARG, "pmc_create: unknown model kind"); }
+        maxcut = std::max(maxcut, m.rcut);
+    }
+    // reference LinkedList geometry comes from the host (src/neighbours.jl:237-238)
+    long long nref = 1;
+    for (int a = 0; a < h->D; a++) {
+        if (p->ncells[a] < 1 || !(p->cell[a] > 0.0) || !(p->box[a] > 0.0)) {
+            delete h;
+            return fail(nullptr, PMC_ERR_BADARG, "pmc_create: degenerate LinkedList grid (rcut > box?)");
+        }
+        nref *= p->ncells[a];
+    }
+    if (nref > 400000000LL) { delete h; return fail(nullptr, PMC_ERR_BADARG, "pmc_create: too many cells"); }
+    h->ncell_ref = (int)nref;
+    // throughput grid: widest even grid with cells wider than rcut by a margin
+    // (DESIGN.md "schedule"; restated in oracle/pmc_oracle.c:orc_cb_create)
+    h->mc_ok = true;
+    long long nmc = 1;
+    const double need = maxcut * (1.0 + 1.0 / 1048576.0);
+    for (int a = 0; a < h->D; a++) {
+        long long n = (long long)floor(p->box[a] / need);
+        n -= (n & 1);
+        while (n >= 4 && p->box[a] / (double)n < need) n -= 2;
+        if (n < 4) { h->mc_ok = false; n = 0; }
+        h->grid.n[a] = (int)n;
+        h->grid.w[a] = n ? p->box[a] / (double)n : 0.0;
+        h->grid.shift[a] = 0.0;
+        nmc *= n;
+    }
+    if (h->D == 2) { h->grid.n[2] = 1; h->grid.w[2] = 1.0; h->grid.shift[2] = 0.0; }
+    h->ncell_mc = h->mc_ok ? (int)nmc : 0;
+
+    int rc = set_device(h);
+    if (rc) { std::string e = h->err; delete h; g_err = e; return rc; }
+#define CR(call)                                                                      \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            g_err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            pmc_destroy(h);                                                           \
+            return PMC_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+    const size_t N = (size_t)h->N;
+    CR(hipStreamCreate(&h->stream));
+    for (int k = 0; k < 4; k++) CR(hipEventCreate(&h->ev[k]));
+    CR(hipMalloc(&h->d_pos, N * h->D * sizeof(double)));
+    CR(hipMalloc(&h->d_species, N * sizeof(int)));
+    CR(hipMalloc(&h->d_models, (size_t)h->S * h->S * sizeof(DevModel)));
+    std::vector<DevModel> dm;
+    for (auto &m : h->models) dm.push_back(to_dev(m));
+    CR(hipMemcpy(h->d_models, dm.data(), dm.size() * sizeof(DevModel), hipMemcpyHostToDevice));
+    const size_t ncmax = (size_t)std::max(h->ncell_ref, h->ncell_mc) + 1;
+    CR(hipMalloc(&h->d_cs, N * sizeof(int)));
+    CR(hipMalloc(&h->d_head, (size_t)h->ncell_ref * sizeof(int)));
+    CR(hipMalloc(&h->d_list, N * sizeof(int)));
+    CR(hipMalloc(&h->d_ccount, (size_t)h->ncell_ref * sizeof(int)));
+    host_neighbour_cells(h);
+    CR(hipMalloc(&h->d_nbr, h->h_nbr.size() * sizeof(int)));
+    CR(hipMalloc(&h->d_nbrcnt, h->h_nbrcnt.size() * sizeof(int)));
+    CR(hipMemcpy(h->d_nbr, h->h_nbr.data(), h->h_nbr.size() * sizeof(int), hipMemcpyHostToDevice));
+    CR(hipMemcpy(h->d_nbrcnt, h->h_nbrcnt.data(), h->h_nbrcnt.size() * sizeof(int), hipMemcpyHostToDevice));
+    CR(hipMalloc(&h->d_sp_off, (size_t)(h->S + 1) * sizeof(int)));
+    CR(hipMalloc(&h->d_sp_ids, N * sizeof(int)));
+    CR(hipMalloc(&h->d_sp_heads, N * sizeof(int)));
+    CR(hipMalloc(&h->d_energy, sizeof(double)));
+    CR(hipMemset(h->d_energy, 0, sizeof(double)));
+    CR(hipMalloc(&h->d_cell_of, N * sizeof(int)));
+    CR(hipMalloc(&h->d_count, ncmax * sizeof(int)));
+    CR(hipMalloc(&h->d_fill, ncmax * sizeof(int)));
+    CR(hipMalloc(&h->d_tmp_ids, N * sizeof(int)));
+    CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
+    CR(hipMalloc(&h->d_ids_ref, N * sizeof(int)));
+    if (h->mc_ok) {
+        CR(hipMalloc(&h->d_start, ((size_t)h->ncell_mc + 1) * sizeof(int)));
+        CR(hipMalloc(&h->d_ids, N * sizeof(int)));
+        CR(hipMalloc(&h->d_sx, N * sizeof(double)));
+        CR(hipMalloc(&h->d_sy, N * sizeof(double)));
+        CR(hipMalloc(&h->d_sz, N * sizeof(double)));
+        CR(hipMalloc(&h->d_ssp, N));
+    }
+    CR(hipMalloc(&h->d_stats, 32 * sizeof(unsigned long long)));
+    CR(hipMemset(h->d_stats, 0, 32 * sizeof(unsigned long long)));
+    CR(hipMalloc(&h->d_result, 8 * sizeof(double)));
+#undef CR
+    *out = h;
+    return PMC_OK;
+}
+
+extern "C" int pmc_destroy(pmc_system *h)
+{
+    if (!h) return PMC_OK;
+    (void)hipSetDevice(h->p.device);
+    void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
+                    h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
+                    h->d_fill, h->d_tmp_ids, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
+                    h->d_sz, h->d_ssp, h->d_stats, h->d_result};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PMC_OK;
+}
+
+// ---- state -----------------------------------------------------------------------
+
+static int build_species_list(pmc_system *h, const std::vector<int> &sp0)
+{
+    // SpeciesList(species), src/utils.jl:36-49 (0-based on the device)
+    std::vector<int> off(h->S + 1, 0), ids(h->N), heads(h->N), fill(h->S, 0);
+    for (int i = 0; i < h->N; i++) off[sp0[i] + 1]++;
+    for (int s = 0; s < h->S; s++) off[s + 1] += off[s];
+    for (int i = 0; i < h->N; i++) {
+        int s = sp0[i];
+        heads[i] = fill[s];
+        ids[off[s] + fill[s]++] = i;
+    }
+    HIPCHK(h, hipMemcpy(h->d_sp_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_sp_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_sp_heads, heads.data(), heads.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->species_list_built = true;
+    return PMC_OK;
+}
+
+extern "C" int pmc_upload(pmc_system *h, const double *pos, const int32_t *species)
+{
+    if (!h || !pos) return fail(h, PMC_ERR_BADARG, "pmc_upload: null argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(h->d_pos, pos, (size_t)h->N * h->D * sizeof(double), hipMemcpyHostToDevice));
+    if (species) {
+        std::vector<int> sp0(h->N);
+        for (int i = 0; i < h->N; i++) {
+            if (species[i] < 1 || species[i] > h->S) return fail(h, PMC_ERR_BADARG, "pmc_upload: species must be 1..nspecies");
+            sp0[i] = species[i] - 1;
+        }
+        HIPCHK(h, hipMemcpy(h->d_species, sp0.data(), (size_t)h->N * sizeof(int), hipMemcpyHostToDevice));
+        rc = build_species_list(h, sp0);
+        if (rc) return rc;
+    } else if (!h->species_list_built) {
+        std::vector<int> sp0(h->N, 0);
+        HIPCHK(h, hipMemcpy(h->d_species, sp0.data(), (size_t)h->N * sizeof(int), hipMemcpyHostToDevice));
+        rc = build_species_list(h, sp0);
+        if (rc) return rc;
+    }
+    h->cells_built = false;
+    h->mc_binned = false;
+    h->e_fix_valid = false;
+    return PMC_OK;
+}
+
+extern "C" int pmc_download(pmc_system *h, double *pos, int32_t *species)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_download: null handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (pos) HIPCHK(h, hipMemcpy(pos, h->d_pos, (size_t)h->N * h->D * sizeof(double), hipMemcpyDeviceToHost));
+    if (species) {
+        std::vector<int> sp0(h->N);
+        HIPCHK(h, hipMemcpy(sp0.data(), h->d_species, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < h->N; i++) species[i] = sp0[i] + 1;
+    }
+    return PMC_OK;
+}
+
+extern "C" int pmc_set_temperature(pmc_system *h, double T)
+{
+    if (!h || !(T > 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_set_temperature: bad argument");
+    h->p.temperature = T;
+    return PMC_OK;
+}
+extern "C" int pmc_get_temperature(pmc_system *h, double *T)
+{
+    if (!h || !T) return fail(h, PMC_ERR_BADARG, "pmc_get_temperature: null argument");
+    *T = h->p.temperature;
+    return PMC_OK;
+}
+extern "C" int pmc_set_energy(pmc_system *h, double e)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_energy: null handle");
+    h->energy = e;
+    return PMC_OK;
+}
+extern "C" int pmc_get_energy(pmc_system *h, double *e)
+{
+    if (!h || !e) return fail(h, PMC_ERR_BADARG, "pmc_get_energy: null argument");
+    *e = h->energy;
+    return PMC_OK;
+}
+extern "C" int pmc_set_counters(pmc_system *h, uint64_t step, uint64_t sweep)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_counters: null handle");
+    h->step_ctr = step;
+    h->sweep_ctr = sweep;
+    return PMC_OK;
+}
+extern "C" int pmc_get_counters(pmc_system *h, uint64_t *step, uint64_t *sweep)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_get_counters: null handle");
+    if (step) *step = h->step_ctr;
+    if (sweep) *sweep = h->sweep_ctr;
+    return PMC_OK;
+}
+
+// ---- binning ------------------------------------------------------------------------
+
+static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+
+// cell_of (already filled) -> start / ids (ascending ids inside each cell)
+static int bin_by_cell(pmc_system *h, int ncell, int *d_start, int *d_ids)
+{
+    const int N = h->N;
+    HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)ncell + 1) * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_fill, 0, ((size_t)ncell + 1) * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_count, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, h->d_count);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, h->stream, h->d_count, ncell, d_start);
+    hipLaunchKernelGGL(k_scatter, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, d_start, h->d_fill,
+                       h->d_tmp_ids);
+    hipLaunchKernelGGL(k_rank, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, d_start, h->d_tmp_ids,
+                       d_ids);
+    HIPCHK(h, hipGetLastError());
+    return PMC_OK;
+}
+
+extern "C" int pmc_build_cells(pmc_system *h)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_build_cells: null handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const int N = h->N;
+    const pmc_params &p = h->p;
+    if (h->D == 3)
+        hipLaunchKernelGGL(k_ref_cell_index<3>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, N, p.cell[0],
+                           p.cell[1], p.cell[2], (int)p.ncells[0], (int)p.ncells[1], (int)p.ncells[2], h->d_cell_of);
+    else
+        hipLaunchKernelGGL(k_ref_cell_index<2>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, N, p.cell[0],
+                           p.cell[1], 1.0, (int)p.ncells[0], (int)p.ncells[1], 1, h->d_cell_of);
+    rc = bin_by_cell(h, h->ncell_ref, h->d_start_ref, h->d_ids_ref);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_cs, h->d_cell_of, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    int tot = std::max(N, h->ncell_ref);
+    hipLaunchKernelGGL(k_ref_links, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, h->d_start_ref,
+                       h->d_ids_ref, h->ncell_ref, h->d_head, h->d_list, h->d_ccount);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->cells_built = true;
+    return PMC_OK;
+}
+
+extern "C" int pmc_get_cells(pmc_system *h, int64_t *cs)
+{
+    if (!h || !cs) return fail(h, PMC_ERR_BADARG, "pmc_get_cells: null argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_get_cells: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<int> t(h->N);
+    HIPCHK(h, hipMemcpy(t.data(), h->d_cs, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->N; i++) cs[i] = (int64_t)t[i] + 1;
+    return PMC_OK;
+}
+
+extern "C" int pmc_get_linked_list(pmc_system *h, int64_t *head, int64_t *list)
+{
+    if (!h || !head || !list) return fail(h, PMC_ERR_BADARG, "pmc_get_linked_list: null argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_get_linked_list: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<int> t(std::max(h->N, h->ncell_ref));
+    HIPCHK(h, hipMemcpy(t.data(), h->d_head, (size_t)h->ncell_ref * sizeof(int), hipMemcpyDeviceToHost));
+    for (int c = 0; c < h->ncell_ref; c++) head[c] = t[c] < 0 ? -1 : (int64_t)t[c] + 1;
+    HIPCHK(h, hipMemcpy(t.data(), h->d_list, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->N; i++) list[i] = t[i] < 0 ? -1 : (int64_t)t[i] + 1;
+    return PMC_OK;
+}
+
+extern "C" int pmc_get_neighbour_cells(pmc_system *h, int64_t c, int64_t *out, int32_t *n)
+{
+    if (!h || !out || !n || c < 1 || c > h->ncell_ref) return fail(h, PMC_ERR_BADARG, "pmc_get_neighbour_cells: bad argument");
+    int cnt = h->h_nbrcnt[c - 1];
+    for (int k = 0; k < cnt; k++) out[k] = (int64_t)h->h_nbr[(size_t)(c - 1) * h->nn + k] + 1;
+    *n = cnt;
+    return PMC_OK;
+}
+
+static RefArgs ref_args(pmc_system *h)
+{
+    RefArgs a;
+    memset(&a, 0, sizeof a);
+    a.N = h->N; a.S = h->S;
+    for (int q = 0; q < 3; q++) {
+        a.box[q] = q < h->D ? h->p.box[q] : 1.0;
+        a.cell[q] = q < h->D ? h->p.cell[q] : 1.0;
+        a.nc[q] = q < h->D ? (int)h->p.ncells[q] : 1;
+    }
+    a.nnmax = h->nn;
+    a.pos = h->d_pos; a.species = h->d_species; a.models = h->d_models;
+    a.cs = h->d_cs; a.head = h->d_head; a.list = h->d_list; a.ccount = h->d_ccount;
+    a.nbr = h->d_nbr; a.nbrcnt = h->d_nbrcnt;
+    a.sp_off = h->d_sp_off; a.sp_ids = h->d_sp_ids; a.sp_heads = h->d_sp_heads;
+    a.energy = h->d_energy;
+    a.temperature = h->p.temperature;
+    return a;
+}
+
+static int ref_energy_launch(pmc_system *h, const int *d_which, int n, double *d_out)
+{
+    RefArgs a = ref_args(h);
+    int grid = std::min(n, 65536 * 4);
+    if (h->D == 3) hipLaunchKernelGGL(k_ref_energy<3>, dim3(grid), dim3(64), 0, h->stream, a, d_which, n, d_out);
+    else hipLaunchKernelGGL(k_ref_energy<2>, dim3(grid), dim3(64), 0, h->stream, a, d_which, n, d_out);
+    HIPCHK(h, hipGetLastError());
+    return PMC_OK;
+}
+
+extern "C" int pmc_energy_particles(pmc_system *h, double *e)
+{
+    if (!h || !e) return fail(h, PMC_ERR_BADARG, "pmc_energy_particles: null argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_energy_particles: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    double *d_out = nullptr;
+    HIPCHK(h, hipMalloc(&d_out, (size_t)h->N * sizeof(double)));
+    rc = ref_energy_launch(h, nullptr, h->N, d_out);
+    if (!rc) {
+        hipError_t er = hipMemcpy(e, d_out, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost);
+        if (er != hipSuccess) rc = fail(h, PMC_ERR_HIP, hipGetErrorString(er));
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
+// Base sum(::Vector{Float64}) is pairwise with 1024-element leaves (base/reduce.jl)
+static double pairwise_sum(const double *v, long long lo, long long hi)
+{
+    if (hi - lo < 1024) {
+        double a = v[lo];
+        for (long long k = lo + 1; k <= hi; k++) a += v[k];
+        return a;
+    }
+    long long mid = lo + ((hi - lo) >> 1);
+    return pairwise_sum(v, lo, mid) + pairwise_sum(v, mid + 1, hi);
+}
+
+extern "C" int pmc_init_energy(pmc_system *h, double *e)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_init_energy: null handle");
+    int rc = pmc_build_cells(h);                       // src/atoms.jl:50
+    if (rc) return rc;
+    std::vector<double> loc((size_t)h->N);
+    rc = pmc_energy_particles(h, loc.data());          // src/atoms.jl:51
+    if (rc) return rc;
+    double en = pairwise_sum(loc.data(), 0, h->N - 1) / 2.0;   // src/atoms.jl:52
+    if (std::isinf(en) || std::isnan(en))              // src/atoms.jl:53-55
+        return fail(h, PMC_ERR_NONFINITE, "Initial configuration has infinite or NaN energy.");
+    h->energy = en;
+    h->e_fix_valid = false;
+    if (e) *e = en;
+    return PMC_OK;
+}
+
+extern "C" int pmc_energy_particle(pmc_system *h, int64_t i, double *e)
+{
+    if (!h || !e || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_energy_particle: bad argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_energy_particle: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    int i0 = (int)i - 1;
+    int *d_which = reinterpret_cast<int *>(h->d_result + 4);
+    HIPCHK(h, hipMemcpy(d_which, &i0, sizeof(int), hipMemcpyHostToDevice));
+    rc = ref_energy_launch(h, d_which, 1, h->d_result);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(e, h->d_result, sizeof(double), hipMemcpyDeviceToHost));
+    return PMC_OK;
+}
+
+extern "C" int pmc_species_count(pmc_system *h, int32_t sp, int64_t *n)
+{
+    if (!h || !n || sp < 1 || sp > h->S) return fail(h, PMC_ERR_BADARG, "pmc_species_count: bad argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    int off[2];
+    HIPCHK(h, hipMemcpy(off, h->d_sp_off + (sp - 1), 2 * sizeof(int), hipMemcpyDeviceToHost));
+    *n = off[1] - off[0];
+    return PMC_OK;
+}
+
+extern "C" int pmc_get_species_ids(pmc_system *h, int32_t sp, int64_t *ids)
+{
+    if (!h || !ids || sp < 1 || sp > h->S) return fail(h, PMC_ERR_BADARG, "pmc_get_species_ids: bad argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    int off[2];
+    HIPCHK(h, hipMemcpy(off, h->d_sp_off + (sp - 1), 2 * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> t((size_t)(off[1] - off[0]));
+    if (!t.empty()) HIPCHK(h, hipMemcpy(t.data(), h->d_sp_ids + off[0], t.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < t.size(); k++) ids[k] = (int64_t)t[k] + 1;
+    return PMC_OK;
+}
+
+// ---- per-move verbs and the sequential chain ------------------------------------------
+
+static MovePool make_pool(const pmc_move *pool, int npool)
+{
+    MovePool mp;
+    memset(&mp, 0, sizeof mp);
+    mp.npool = npool;
+    for (int m = 0; m < npool; m++) {
+        mp.kind[m] = pool[m].kind;
+        mp.sp0[m] = pool[m].species[0] - 1;
+        mp.sp1[m] = pool[m].species[1] - 1;
+        mp.prob[m] = pool[m].probability;
+        mp.sigma[m] = pool[m].sigma;
+    }
+    return mp;
+}
+
+static int ref_op_launch(pmc_system *h, RefOp &o)
+{
+    RefArgs a = ref_args(h);
+    HIPCHK(h, hipMemcpyAsync(h->d_energy, &h->energy, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->D == 3) hipLaunchKernelGGL(k_ref_ops<3>, dim3(1), dim3(64), 0, h->stream, a, o);
+    else hipLaunchKernelGGL(k_ref_ops<2>, dim3(1), dim3(64), 0, h->stream, a, o);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(&h->energy, h->d_energy, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->mc_binned = false;
+    h->e_fix_valid = false;
+    return PMC_OK;
+}
+
+extern "C" int pmc_displacement_perform(pmc_system *h, int64_t i, const double *delta, double *e1, double *e2,
+                                        double *de)
+{
+    if (!h || !delta || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_displacement_perform: bad argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_displacement_perform: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    RefOp o;
+    memset(&o, 0, sizeof o);
+    o.op = OP_DISP_PERFORM;
+    o.i = (int)i - 1;
+    for (int q = 0; q < h->D; q++) o.delta[q] = delta[q];
+    o.result = h->d_result;
+    rc = ref_op_launch(h, o);
+    if (rc) return rc;
+    double r[3];
+    HIPCHK(h, hipMemcpy(r, h->d_result, sizeof r, hipMemcpyDeviceToHost));
+    if (e1) *e1 = r[0];
+    if (e2) *e2 = r[1];
+    if (de) *de = r[2];
+    return PMC_OK;
+}
+
+extern "C" int pmc_displacement_revert(pmc_system *h, int64_t i, const double *minus_delta, double de)
+{
+    if (!h || !minus_delta || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_displacement_revert: bad argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_displacement_revert: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    RefOp o;
+    memset(&o, 0, sizeof o);
+    o.op = OP_DISP_REVERT;
+    o.i = (int)i - 1;
+    for (int q = 0; q < h->D; q++) o.delta[q] = minus_delta[q];
+    o.de_in = de;
+    return ref_op_launch(h, o);
+}
+
+extern "C" int pmc_swap_perform(pmc_system *h, int64_t i, int64_t j, double *e1, double *e2, double *de)
+{
+    if (!h || i < 1 || i > h->N || j < 1 || j > h->N) return fail(h, PMC_ERR_BADARG, "pmc_swap_perform: bad argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_swap_perform: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    RefOp o;
+    memset(&o, 0, sizeof o);
+    o.op = OP_SWAP_PERFORM;
+    o.i = (int)i - 1;
+    o.j = (int)j - 1;
+    o.result = h->d_result;
+    rc = ref_op_launch(h, o);
+    if (rc) return rc;
+    double r[3];
+    HIPCHK(h, hipMemcpy(r, h->d_result, sizeof r, hipMemcpyDeviceToHost));
+    if (e1) *e1 = r[0];
+    if (e2) *e2 = r[1];
+    if (de) *de = r[2];
+    return PMC_OK;
+}
+
+extern "C" int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de)
+{
+    if (!h || i < 1 || i > h->N || j < 1 || j > h->N) return fail(h, PMC_ERR_BADARG, "pmc_swap_revert: bad argument");
+    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_swap_revert: call pmc_build_cells first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    RefOp o;
+    memset(&o, 0, sizeof o);
+    o.op = OP_SWAP_REVERT;
+    o.i = (int)i - 1;
+    o.j = (int)j - 1;
+    o.de_in = de;
+    return ref_op_launch(h, o);
+}
+
+// ---- throughput engine -----------------------------------------------------------------
+
+static int mc_bin(pmc_system *h, const double shift[3])
+{
+    const int N = h->N;
+    for (int q = 0; q < 3; q++) h->grid.shift[q] = q < h->D ? shift[q] : 0.0;
+    if (h->D == 3) {
+        hipLaunchKernelGGL(k_mc_cell_index<3>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of);
+    } else {
+        hipLaunchKernelGGL(k_mc_cell_index<2>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of);
+    }
+    int rc = bin_by_cell(h, h->ncell_mc, h->d_start, h->d_ids);
+    if (rc) return rc;
+    if (h->D == 3)
+        hipLaunchKernelGGL(k_mc_gather<3>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, h->d_species, N, h->d_ids,
+                           h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
+    else
+        hipLaunchKernelGGL(k_mc_gather<2>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, h->d_species, N, h->d_ids,
+                           h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
+    HIPCHK(h, hipGetLastError());
+    h->mc_binned = true;
+    return PMC_OK;
+}
+
+static CbArgs cb_args(pmc_system *h)
+{
+    CbArgs a;
+    memset(&a, 0, sizeof a);
+    for (int q = 0; q < 3; q++) {
+        a.n[q] = q < h->D ? h->grid.n[q] : 1;
+        a.half[q] = a.n[q] / 2;
+        a.w[q] = q < h->D ? h->grid.w[q] : 1.0;
+        a.shift[q] = h->grid.shift[q];
+        a.L[q] = q < h->D ? h->p.box[q] : 1.0;
+        a.invL[q] = 1.0 / a.L[q];
+    }
+    a.temperature = h->p.temperature;
+    a.start = h->d_start; a.ids = h->d_ids;
+    a.sx = h->d_sx; a.sy = h->d_sy; a.sz = h->d_sz; a.ssp = h->d_ssp;
+    a.pos = h->d_pos; a.species = h->d_species;
+    a.N = h->N; a.S = h->S;
+    a.key0 = h->key[0]; a.key1 = h->key[1];
+    a.m0 = to_dev(h->models[0]);
+    a.models = h->d_models;
+    a.stats = h->d_stats;
+    return a;
+}
+
+static size_t cb_lds_bytes(const pmc_system *h)
+{
+    size_t b = (PMC_LDS_WAVE_BYTES + 15) & ~(size_t)15;
+    if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
+    return b;
+}
+
+#define DISPATCH_ONE(KERNEL, DD, KK, h, grid, lds, args)                                                     \
+    if (!done_ && (h)->D == DD && (h)->kind == KK) {                                                            \
+        if ((h)->S > 1) hipLaunchKernelGGL((KERNEL<DD, KK, true>), dim3(grid), dim3(64), lds, (h)->stream, args);   \
+        else hipLaunchKernelGGL((KERNEL<DD, KK, false>), dim3(grid), dim3(64), lds, (h)->stream, args);         \
+        done_ = true;                                                                                           \
+    }
+
+// template instance for (dimension, common model kind, multi-species)
+#define DISPATCH_KERNEL(KERNEL, h, grid, lds, args)                                                             \
+    do {                                                                                                        \
+        bool done_ = false;                                                                                     \
+        DISPATCH_ONE(KERNEL, 3, 0, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 3, 1, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 3, 2, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 3, 3, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 3, 4, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 2, 0, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 2, 1, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 2, 2, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 2, 3, h, grid, lds, args)                                                          \
+        DISPATCH_ONE(KERNEL, 2, 4, h, grid, lds, args)                                                          \
+        (void)done_;                                                                                            \
+    } while (0)
+
+static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
+{
+    if (st[17] & 1ull)
+        return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity (PMC_CAP)");
+    return PMC_OK;
+}
+
+extern "C" int pmc_grid(pmc_system *h, int64_t *n_mc, double *w)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_grid: null handle");
+    if (!h->mc_ok) return fail(h, PMC_ERR_UNSUPPORTED, "checkerboard grid needs >= 4 cells of width >= rcut per side");
+    for (int q = 0; q < h->D; q++) {
+        if (n_mc) n_mc[q] = h->grid.n[q];
+        if (w) w[q] = h->grid.w[q];
+    }
+    return PMC_OK;
+}
+
+extern "C" int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_total_energy: null handle");
+    if (!h->mc_ok) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_total_energy: box too small for the cell grid (need >= 4 cells per side)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (!h->mc_binned) {
+        const double z[3] = {0, 0, 0};
+        rc = mc_bin(h, z);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    CbArgs a = cb_args(h);
+    a.all_cells = 1;
+    a.nactive = h->ncell_mc;
+    size_t lds = cb_lds_bytes(h);
+    DISPATCH_KERNEL(k_total_energy, h, a.nactive, lds, a);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long st[32];
+    HIPCHK(h, hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    rc = check_kernel_flags(h, st);
+    if (rc) return rc;
+    long long tot = (long long)st[16];
+    h->e_fix = tot / 2;
+    h->e_fix_valid = true;
+    h->energy = (double)h->e_fix / PMC_FIX;
+    if (E) *E = h->energy;
+    if (E_fix) *E_fix = h->e_fix;
+    return PMC_OK;
+}
+
+extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const double *delta, double *e1, double *e2)
+{
+    if (!h || n < 0 || (n > 0 && (!i || !delta || !e1 || !e2))) return fail(h, PMC_ERR_BADARG, "pmc_delta_e: bad argument");
+    if (!h->mc_ok) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_delta_e: box too small for the cell grid");
+    if (n == 0) return PMC_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (!h->mc_binned) {
+        const double z[3] = {0, 0, 0};
+        rc = mc_bin(h, z);
+        if (rc) return rc;
+    }
+    std::vector<int> w((size_t)n);
+    for (int64_t k = 0; k < n; k++) {
+        if (i[k] < 1 || i[k] > h->N) return fail(h, PMC_ERR_BADARG, "pmc_delta_e: particle id out of range");
+        w[(size_t)k] = (int)i[k] - 1;
+    }
+    int *d_w = nullptr;
+    double *d_d = nullptr, *d_e = nullptr;
+    HIPCHK(h, hipMalloc(&d_w, (size_t)n * sizeof(int)));
+    HIPCHK(h, hipMalloc(&d_d, (size_t)n * h->D * sizeof(double)));
+    HIPCHK(h, hipMalloc(&d_e, (size_t)n * 2 * sizeof(double)));
+    (void)hipMemcpyAsync(d_w, w.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    (void)hipMemcpyAsync(d_d, delta, (size_t)n * h->D * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    CbArgs a = cb_args(h);
+    int grid = (int)std::min<int64_t>(n, 262144);
+    if (h->D == 3) hipLaunchKernelGGL(k_delta_e<3>, dim3(grid), dim3(64), 0, h->stream, a, (int)n, d_w, d_d, d_e, d_e + n);
+    else hipLaunchKernelGGL(k_delta_e<2>, dim3(grid), dim3(64), 0, h->stream, a, (int)n, d_w, d_d, d_e, d_e + n);
+    hipError_t er = hipGetLastError();
+    if (er == hipSuccess) er = hipMemcpyAsync(e1, d_e, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(e2, d_e + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_w); (void)hipFree(d_d); (void)hipFree(d_e);
+    if (er != hipSuccess) return fail(h, PMC_ERR_HIP, hipGetErrorString(er));
+    return PMC_OK;
+}
+
+static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    if (!h->cells_built) {
+        int rc = pmc_build_cells(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    RefOp o;
+    memset(&o, 0, sizeof o);
+    o.op = OP_STEPS;
+    o.step0 = h->step_ctr;
+    o.nsteps = nsweeps * (int64_t)h->N;   // sweepstep = N, src/ParticlesMC.jl:246
+    o.key0 = h->key[0];
+    o.key1 = h->key[1];
+    o.pool = make_pool(pool, npool);
+    o.stats = h->d_stats;
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    int rc = ref_op_launch(h, o);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev[1]));
+    h->step_ctr += (uint64_t)o.nsteps;
+    h->sweep_ctr += (uint64_t)nsweeps;
+    if (out) {
+        unsigned long long st[32];
+        HIPCHK(h, hipMemcpy(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost));
+        for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)st[m]; out->accepted[m] = (int64_t)st[8 + m]; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+        out->kernel_ms = ms;
+        out->sweep_kernel_ms = ms;
+        out->sweep_kernel_launches = 1;
+        out->energy = h->energy;
+        out->energy_fix = 0;
+    }
+    return PMC_OK;
+}
+
+static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    if (!h->mc_ok)
+        return fail(h, PMC_ERR_UNSUPPORTED, "checkerboard mode needs >= 4 cells of width >= rcut per side; use PMC_SEQUENTIAL");
+    int rc;
+    if (!h->e_fix_valid) {
+        rc = pmc_total_energy(h, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    for (int m = 0; m < npool; m++)
+        if (pool[m].kind == PMC_MOVE_SWAP && h->S < 2)
+            return fail(h, PMC_ERR_BADARG, "DiscreteSwap needs at least two species");
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    const MovePool mp = make_pool(pool, npool);
+    const int ncol = 1 << h->D;
+    int nactive = 1;
+    for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
+    const size_t lds = cb_lds_bytes(h);
+    float pass_ms = 0.f;
+    int64_t launches = 0;
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    for (int64_t sw = 0; sw < nsweeps; sw++) {
+        const uint64_t g = h->sweep_ctr + (uint64_t)sw;
+        const uint32_t s_lo = (uint32_t)g, s_hi = (uint32_t)(g >> 32) & 0xffffffu;
+        uint32_t W[4];
+        philox4x32(0, 0, s_lo, s_hi | ((uint32_t)TAG_SHIFT << 24), h->key[0], h->key[1], W);
+        double shift[3] = {0, 0, 0};
+        for (int q = 0; q < h->D; q++) shift[q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
+        rc = mc_bin(h, shift);
+        if (rc) return rc;
+        CbArgs a = cb_args(h);
+        a.s_lo = s_lo; a.s_hi = s_hi;
+        a.pool = mp;
+        a.all_cells = 0;
+        a.nactive = nactive;
+        HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+        for (int col = 0; col < ncol; col++) {
+            a.colour = col;
+            DISPATCH_KERNEL(k_cb_pass, h, nactive, lds, a);
+            launches++;
+        }
+        HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+        HIPCHK(h, hipGetLastError());
+        // the per-sweep event pair is only read when a caller asks for the split
+        if (out) {
+            HIPCHK(h, hipEventSynchronize(h->ev[3]));
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, h->ev[2], h->ev[3]);
+            pass_ms += ms;
+        }
+    }
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    unsigned long long st[32];
+    HIPCHK(h, hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->sweep_ctr += (uint64_t)nsweeps;
+    h->cells_built = false;
+    rc = check_kernel_flags(h, st);
+    if (rc) return rc;
+    h->e_fix += (long long)st[16];
+    h->energy = (double)h->e_fix / PMC_FIX;
+    if (out) {
+        for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)st[m]; out->accepted[m] = (int64_t)st[8 + m]; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+        out->kernel_ms = ms;
+        out->sweep_kernel_ms = pass_ms;
+        out->sweep_kernel_launches = launches;
+        out->energy = h->energy;
+        out->energy_fix = h->e_fix;
+    }
+    return PMC_OK;
+}
+
+extern "C" int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool, int64_t nsweeps,
+                         pmc_stats *out)
+{
+    if (!h || !pool || npool < 1 || npool > PMC_MAX_MOVES || nsweeps < 0)
+        return fail(h, PMC_ERR_BADARG, "pmc_sweep: bad argument");
+    for (int m = 0; m < npool; m++) {
+        if (pool[m].kind == PMC_MOVE_DISPLACEMENT) {
+            if (!(pool[m].sigma > 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_sweep: Displacement needs sigma > 0");
+        } else if (pool[m].kind == PMC_MOVE_SWAP) {
+            if (pool[m].species[0] < 1 || pool[m].species[0] > h->S || pool[m].species[1] < 1 || pool[m].species[1] > h->S)
+                return fail(h, PMC_ERR_BADARG, "pmc_sweep: DiscreteSwap species out of range");
+        } else {
+            return fail(h, PMC_ERR_BADARG, "pmc_sweep: unsupported action");
+        }
+        if (!(pool[m].probability >= 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_sweep: negative probability");
+    }
+    if (out) memset(out, 0, sizeof *out);
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (mode == PMC_SEQUENTIAL) return sweep_sequential(h, pool, npool, nsweeps, out);
+    if (mode == PMC_CHECKERBOARD) return sweep_checkerboard(h, pool, npool, nsweeps, out);
+    return fail(h, PMC_ERR_BADARG, "pmc_sweep: unknown mode");
+}
+
+// ---- parallel tempering ---------------------------------------------------------------
+
+extern "C" int pmc_pt_decide(uint64_t seed, uint64_t round, int32_t n, const double *energy,
+                             const double *ladder, int32_t *label, int32_t *n_accepted)
+{
+    if (n < 1 || !energy || !ladder || !label) { g_err = "pmc_pt_decide: bad argument"; return PMC_ERR_BADARG; }
+    std::vector<int> holder(n, -1);   // holder[t] = replica currently at temperature index t
+    for (int r = 0; r < n; r++) {
+        if (label[r] < 0 || label[r] >= n || holder[label[r]] != -1) { g_err = "pmc_pt_decide: label is not a permutation"; return PMC_ERR_BADARG; }
+        holder[label[r]] = r;
+    }
+    int acc = 0;
+    const int parity = (int)(round & 1);
+    for (int t = parity; t + 1 < n; t += 2) {
+        int ra = holder[t], rb = holder[t + 1];
+        double ba = 1.0 / ladder[t], bb = 1.0 / ladder[t + 1];
+        double arg = (ba - bb) * (energy[ra] - energy[rb]);
+        uint32_t W[4];
+        philox4x32((uint32_t)t, 0, (uint32_t)round, ((uint32_t)(round >> 32) & 0xffffffu) | ((uint32_t)TAG_PT << 24),
+                   (uint32_t)seed, (uint32_t)(seed >> 32), W);
+        double lnu = det_log(uniform53(W[0], W[1]));
+        if (lnu < arg) {
+            label[ra] = t + 1;
+            label[rb] = t;
+            acc++;
+        }
+    }
+    if (n_accepted) *n_accepted = acc;
+    return PMC_OK;
+}
+
+// ---- host access to the random streams ---------------------------------------------------
+
+extern "C" int pmc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    if (!ctr || !key || !out) return PMC_ERR_BADARG;
+    philox4x32(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+    return PMC_OK;
+}
+
+extern "C" int pmc_box_muller(uint32_t w1, uint32_t w2, double *z0, double *z1)
+{
+    if (!z0 || !z1) return PMC_ERR_BADARG;
+    box_muller(w1, w2, z0, z1);
+    return PMC_OK;
+}
+
+extern "C" int pmc_log_uniform(uint32_t hi, uint32_t lo, double *lnu)
+{
+    if (!lnu) return PMC_ERR_BADARG;
+    *lnu = det_log(uniform53(hi, lo));
+    return PMC_OK;
+}
+
+extern "C" int pmc_sequential_words(uint64_t seed, uint32_t chain, uint64_t step, uint32_t R[4], uint32_t Q[4])
+{
+    if (!R || !Q) return PMC_ERR_BADARG;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) + chain;
+    philox4x32((uint32_t)step, (uint32_t)(step >> 32), 0, TAG_SEQ0, k0, k1, R);
+    philox4x32((uint32_t)step, (uint32_t)(step >> 32), 0, TAG_SEQ1, k0, k1, Q);
+    return PMC_OK;
+}
+
+// ---- debug ----------------------------------------------------------------------------
+
+extern "C" int pmc_debug_rng(pmc_system *h, int64_t n, const uint32_t *w1, const uint32_t *w2, double *z0, double *z1,
+                             double *lnu)
+{
+    if (!h || n < 1 || !w1 || !w2 || !z0 || !z1 || !lnu) return fail(h, PMC_ERR_BADARG, "pmc_debug_rng: bad argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    uint32_t *d_w = nullptr;
+    double *d_o = nullptr;
+    HIPCHK(h, hipMalloc(&d_w, (size_t)n * 2 * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&d_o, (size_t)n * 3 * sizeof(double)));
+    (void)hipMemcpy(d_w, w1, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_w + n, w2, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_debug_rng, dim3(nblk((int)n, 256)), dim3(256), 0, h->stream, (int)n, d_w, d_w + n, d_o, d_o + n,
+                       d_o + 2 * n);
+    hipError_t er = hipStreamSynchronize(h->stream);
+    if (er == hipSuccess) er = hipMemcpy(z0, d_o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(z1, d_o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(lnu, d_o + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_w); (void)hipFree(d_o);
+    if (er != hipSuccess) return fail(h, PMC_ERR_HIP, hipGetErrorString(er));
+    return PMC_OK;
+}

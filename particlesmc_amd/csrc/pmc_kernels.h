@@ -1,0 +1,974 @@
+// pmc_kernels.h -- HIP kernels of the ParticlesMC hot path for gfx950 (MI355X).
+//
+// Two engines share the pair arithmetic of pmc_device.h:
+//  * reference-order engine: device-resident head/list linked cells exactly as
+//    src/neighbours.jl:224-302, per-particle energies summed in the LinkedIterator
+//    order (src/neighbours.jl:332-377) -> bit-identical to the sequential Julia path;
+//  * throughput engine: cell-sorted SoA + CSR over an even grid, one wavefront per
+//    active cell, 3^d neighbour cells staged in LDS, exact (order-free) sums,
+//    checkerboard colour passes.
+#pragma once
+#include "pmc_device.h"
+
+#define PMC_CAP 640          // neighbourhood candidates staged in LDS per wavefront
+#define PMC_REF_MAXC 64      // chain length handled by the fast ordered path
+#define PMC_MAXNN 27
+
+// ------------------------------------------------------------------------------
+// binning: cell index -> CSR (cell_start, ids ascending inside each cell)
+// ------------------------------------------------------------------------------
+
+// get_cell + cell_index, src/neighbours.jl:178-180, 79-88 (0-based result)
+template <int D>
+__global__ void k_ref_cell_index(const double *__restrict__ pos, int N, double c0, double c1, double c2,
+                                 int n0, int n1, int n2, int *__restrict__ cell_of)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double cell[3] = {c0, c1, c2};
+    const int nc[3] = {n0, n1, n2};
+    long long c = 0, stride = 1;
+#pragma unroll
+    for (int a = D - 1; a >= 0; a--) {
+        long long mc = (long long)dev_jl_fld(pos[(size_t)i * D + a], cell[a]);
+        long long f = mc - dev_fld_i(mc, nc[a]) * nc[a];
+        c += f * stride;
+        stride *= nc[a];
+    }
+    cell_of[i] = (int)c;
+}
+
+struct GridGeom {
+    int n[3];
+    double w[3];
+    double shift[3];
+};
+
+template <int D>
+__device__ __forceinline__ double mc_coord(double x, double shift, double w)
+{
+    return floor((x - shift) / w);
+}
+
+template <int D>
+__global__ void k_mc_cell_index(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    long long lin = 0;
+#pragma unroll
+    for (int a = 0; a < D; a++) {
+        long long q = (long long)mc_coord<D>(pos[(size_t)i * D + a], g.shift[a], g.w[a]);
+        long long r = q % g.n[a];
+        if (r < 0) r += g.n[a];
+        lin = lin * g.n[a] + r;
+    }
+    cell_of[i] = (int)lin;
+}
+
+__global__ void k_count(const int *__restrict__ cell_of, int N, int *__restrict__ count)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) atomicAdd(&count[cell_of[i]], 1);
+}
+
+// exclusive scan of count[0..n) into start[0..n], single block of 1024 threads
+__global__ void k_scan(const int *__restrict__ count, int n, int *__restrict__ start)
+{
+    __shared__ int part[1024];
+    int t = threadIdx.x;
+    int per = (n + 1023) / 1024;
+    int lo = t * per, hi = min(lo + per, n);
+    int s = 0;
+    for (int k = lo; k < hi; k++) s += count[k];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int base = (t == 0) ? 0 : part[t - 1];
+    for (int k = lo; k < hi; k++) {
+        start[k] = base;
+        base += count[k];
+    }
+    if (t == 1023) start[n] = part[1023];
+}
+
+__global__ void k_scatter(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+                          int *__restrict__ fill, int *__restrict__ tmp_ids)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int c = cell_of[i];
+    int slot = start[c] + atomicAdd(&fill[c], 1);
+    tmp_ids[slot] = i;
+}
+
+// rank of each particle inside its cell by id -> deterministic order whatever
+// order the atomics of k_scatter ran in
+__global__ void k_rank(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+                       const int *__restrict__ tmp_ids, int *__restrict__ ids)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int c = cell_of[i];
+    int lo = start[c], hi = start[c + 1];
+    int r = 0;
+    for (int k = lo; k < hi; k++) r += (tmp_ids[k] < i);
+    ids[lo + r] = i;
+}
+
+// head/list exactly as build_neighbour_list! leaves them (src/neighbours.jl:259-267):
+// every chain runs through the cell's particles in DESCENDING id.
+__global__ void k_ref_links(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+                            const int *__restrict__ ids, int ncell, int *__restrict__ head,
+                            int *__restrict__ list, int *__restrict__ ccount)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N) {
+        int c = cell_of[t];
+        // position of t in its (ascending) cell segment
+        int lo = start[c], hi = start[c + 1];
+        int k = lo;
+        while (k < hi && ids[k] != t) k++;
+        list[t] = (k > lo) ? ids[k - 1] : -1;
+    }
+    if (t < ncell) {
+        int lo = start[t], hi = start[t + 1];
+        head[t] = (hi > lo) ? ids[hi - 1] : -1;
+        ccount[t] = hi - lo;
+    }
+}
+
+template <int D>
+__global__ void k_mc_gather(const double *__restrict__ pos, const int *__restrict__ species, int N,
+                            const int *__restrict__ ids, double *__restrict__ sx, double *__restrict__ sy,
+                            double *__restrict__ sz, unsigned char *__restrict__ ssp)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    int i = ids[k];
+    sx[k] = pos[(size_t)i * D + 0];
+    sy[k] = pos[(size_t)i * D + 1];
+    if (D == 3) sz[k] = pos[(size_t)i * D + 2];
+    ssp[k] = (unsigned char)species[i];
+}
+
+// ------------------------------------------------------------------------------
+// reference-order engine
+// ------------------------------------------------------------------------------
+
+struct RefArgs {
+    int N, S;
+    double box[3], cell[3];
+    int nc[3];
+    int nnmax;                 // 3^d
+    double *pos;               // AoS
+    int *species;              // 0-based
+    const DevModel *models;
+    int *cs, *head, *list, *ccount;
+    const int *nbr, *nbrcnt;   // neighbour-cell table, reference order
+    int *sp_off, *sp_ids, *sp_heads; // SpeciesList (utils.jl:31-49), 0-based
+    double *energy;            // system.energy[1]
+    double temperature;
+};
+
+template <int D>
+__device__ __forceinline__ int ref_cell_of(const RefArgs &a, const double *x)
+{
+    long long c = 0, stride = 1;
+#pragma unroll
+    for (int q = D - 1; q >= 0; q--) {
+        long long mc = (long long)dev_jl_fld(x[q], a.cell[q]);
+        long long f = mc - dev_fld_i(mc, a.nc[q]) * a.nc[q];
+        c += f * stride;
+        stride *= a.nc[q];
+    }
+    return (int)c;
+}
+
+// compute_energy_ij, src/atoms.jl:66-75 (literal, division-form minimum image)
+template <int D>
+__device__ __forceinline__ double ref_energy_ij(const RefArgs &a, int i, int j, const double *xi, int spi)
+{
+    if (i == j) return 0.0;
+    const DevModel &m = a.models[spi * a.S + a.species[j]];
+    double v = dev_vector_1d(xi[0], a.pos[(size_t)j * D + 0], a.box[0]);
+    double r2 = v * v;
+#pragma unroll
+    for (int q = 1; q < D; q++) {
+        v = dev_vector_1d(xi[q], a.pos[(size_t)j * D + q], a.box[q]);
+        r2 = r2 + v * v;
+    }
+    if (r2 > m.rcut2) return 0.0;
+    return dev_potential_dyn(r2, m);
+}
+
+__device__ __forceinline__ double readlane_double(double v, int l)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// compute_energy_particle with the LinkedIterator order (src/atoms.jl:81-88,
+// src/neighbours.jl:332-377).  One wavefront: lanes walk the <= 27 chains in
+// parallel, pair terms are evaluated in parallel per cell, and the sum is taken
+// strictly in iterator order.  lds_ids: PMC_MAXNN * PMC_REF_MAXC ints.
+template <int D>
+__device__ double wave_ordered_energy(const RefArgs &a, int i, const double *xi, int spi, int *lds_ids)
+{
+    const int lane = wave_lane();
+    int c = ref_cell_of<D>(a, xi);
+    int cnt = a.nbrcnt[c];
+    int len = 0;
+    if (lane < cnt) {
+        int c2 = a.nbr[(size_t)c * a.nnmax + lane];
+        int j = a.head[c2];
+        while (j != -1) {
+            if (len < PMC_REF_MAXC) lds_ids[lane * PMC_REF_MAXC + len] = j;
+            len++;
+            j = a.list[j];
+        }
+    }
+    bool ovf = __any(len > PMC_REF_MAXC);
+    __syncthreads();
+    double acc = 0.0;
+    if (!ovf) {
+        for (int l = 0; l < cnt; l++) {
+            int n = __builtin_amdgcn_readlane(len, l);
+            double u = 0.0;
+            if (lane < n) {
+                int j = lds_ids[l * PMC_REF_MAXC + lane];
+                u = ref_energy_ij<D>(a, i, j, xi, spi);
+            }
+            for (int k = 0; k < n; k++) acc += readlane_double(u, k);
+        }
+    } else {
+        for (int l = 0; l < cnt; l++) {
+            int j = a.head[a.nbr[(size_t)c * a.nnmax + l]];
+            while (j != -1) {
+                acc += ref_energy_ij<D>(a, i, j, xi, spi);
+                j = a.list[j];
+            }
+        }
+    }
+    __syncthreads();
+    return acc;
+}
+
+// [compute_energy_particle(system, i) for i in ids] -- one wavefront per particle
+template <int D>
+__global__ __launch_bounds__(64) void k_ref_energy(RefArgs a, const int *__restrict__ which, int n,
+                                                    double *__restrict__ out)
+{
+    __shared__ int lds_ids[PMC_MAXNN * PMC_REF_MAXC];
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        int i = which ? which[b] : b;
+        double xi[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < D; q++) xi[q] = a.pos[(size_t)i * D + q];
+        double e = wave_ordered_energy<D>(a, i, xi, a.species[i], lds_ids);
+        if (wave_lane() == 0) out[b] = e;
+    }
+}
+
+// update_neighbour_list!, src/neighbours.jl:276-302 (executed by lane 0)
+template <int D>
+__device__ void ref_relink(const RefArgs &a, int i, const double *x)
+{
+    int c = a.cs[i];
+    int c2 = ref_cell_of<D>(a, x);
+    if (c == c2) return;
+    if (a.head[c] == i) {
+        a.head[c] = a.list[i];
+    } else {
+        int j = a.head[c];
+        while (a.list[j] != i) j = a.list[j];
+        a.list[j] = a.list[i];
+    }
+    a.list[i] = a.head[c2];
+    a.head[c2] = i;
+    a.cs[i] = c2;
+    a.ccount[c]--;
+    a.ccount[c2]++;
+}
+
+enum { OP_DISP_PERFORM = 0, OP_DISP_REVERT = 1, OP_SWAP_PERFORM = 2, OP_SWAP_REVERT = 3, OP_STEPS = 4 };
+
+struct MovePool {
+    int npool;
+    int kind[8];
+    int sp0[8], sp1[8];       // 0-based species
+    double prob[8];
+    double sigma[8];
+};
+
+__device__ __host__ __forceinline__ int select_move(const MovePool &p, uint32_t w)
+{
+    if (p.npool == 1) return 0;
+    double tot = 0.0;
+    for (int m = 0; m < p.npool; m++) tot += p.prob[m];
+    double u = (double)w * (1.0 / 4294967296.0) * tot;
+    double acc = 0.0;
+    for (int m = 0; m < p.npool; m++) {
+        acc += p.prob[m];
+        if (u < acc) return m;
+    }
+    return p.npool - 1;
+}
+
+struct RefOp {
+    int op;
+    int i, j;                  // 0-based
+    double delta[3];
+    double de_in;
+    unsigned long long step0;
+    long long nsteps;
+    uint32_t key0, key1;
+    MovePool pool;
+    double *result;            // e1, e2, de
+    unsigned long long *stats; // attempted[8], accepted[8]
+};
+
+template <int D>
+__device__ void ref_disp_perform(const RefArgs &a, int i, const double *delta, int *lds_ids,
+                                 double *e1, double *e2, double *de)
+{
+    const int lane = wave_lane();
+    double x[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < D; q++) x[q] = a.pos[(size_t)i * D + q];
+    int sp = a.species[i];
+    double ea = wave_ordered_energy<D>(a, i, x, sp, lds_ids);
+#pragma unroll
+    for (int q = 0; q < D; q++) x[q] = x[q] + delta[q];   // update_position! src/moves.jl:46-48
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = x[q];
+        ref_relink<D>(a, i, x);
+    }
+    __threadfence();
+    __syncthreads();
+    double eb = wave_ordered_energy<D>(a, i, x, sp, lds_ids);
+    double d = 0.0;
+    if (!(isinf(ea) || isinf(eb))) {                      // src/moves.jl:13-18
+        d = eb - ea;
+        if (lane == 0) *a.energy += d;
+    }
+    *e1 = ea; *e2 = eb; *de = d;
+}
+
+template <int D>
+__device__ void ref_disp_revert(const RefArgs &a, int i, const double *mdelta, double de)
+{
+    if (wave_lane() == 0) {
+        double x[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            x[q] = a.pos[(size_t)i * D + q] + mdelta[q];
+            a.pos[(size_t)i * D + q] = x[q];
+        }
+        *a.energy -= de;                                  // src/moves.jl:79
+        ref_relink<D>(a, i, x);
+    }
+    __threadfence();
+    __syncthreads();
+}
+
+// update_species_list!, src/moves.jl:175-179 (0-based)
+__device__ __forceinline__ void ref_update_species_list(const RefArgs &a, int s1, int s2, int i, int j)
+{
+    a.sp_ids[a.sp_off[s1] + a.sp_heads[i]] = j;
+    a.sp_ids[a.sp_off[s2] + a.sp_heads[j]] = i;
+    int t = a.sp_heads[i];
+    a.sp_heads[i] = a.sp_heads[j];
+    a.sp_heads[j] = t;
+}
+
+template <int D>
+__device__ void ref_swap_perform(const RefArgs &a, int i, int j, int s1, int s2, int *lds_ids,
+                                 double *e1, double *e2, double *de)
+{
+    const int lane = wave_lane();
+    double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < D; q++) { xi[q] = a.pos[(size_t)i * D + q]; xj[q] = a.pos[(size_t)j * D + q]; }
+    int spi = a.species[i], spj = a.species[j];
+    double e1i = wave_ordered_energy<D>(a, i, xi, spi, lds_ids);
+    double e1j = wave_ordered_energy<D>(a, j, xj, spj, lds_ids);
+    if (lane == 0) { a.species[i] = spj; a.species[j] = spi; }
+    __threadfence();
+    __syncthreads();
+    double e2i = wave_ordered_energy<D>(a, i, xi, spj, lds_ids);
+    double e2j = wave_ordered_energy<D>(a, j, xj, spi, lds_ids);
+    double ea = e1i + e1j, eb = e2i + e2j;
+    double d = 0.0;
+    if (lane == 0) ref_update_species_list(a, s1, s2, i, j);
+    if (!(isinf(ea) || isinf(eb))) {
+        d = eb - ea;
+        if (lane == 0) *a.energy += d;
+    }
+    __threadfence();
+    __syncthreads();
+    *e1 = ea; *e2 = eb; *de = d;
+}
+
+__device__ void ref_swap_revert(const RefArgs &a, int i, int j, int s1, int s2, double de)
+{
+    if (wave_lane() == 0) {
+        int spi = a.species[i], spj = a.species[j];
+        a.species[j] = spi;                               // src/moves.jl:204 (as written)
+        a.species[i] = spj;
+        ref_update_species_list(a, s1, s2, i, j);
+        *a.energy -= de;
+    }
+    __threadfence();
+    __syncthreads();
+}
+
+// One wavefront runs the reference's strictly sequential chain: per-move verbs
+// (batch of one) or `nsteps` Metropolis steps following the Arianna mc_step!
+// contract with the Philox stream of DESIGN.md.
+template <int D>
+__global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
+{
+    __shared__ int lds_ids[PMC_MAXNN * PMC_REF_MAXC];
+    const int lane = wave_lane();
+    double e1 = 0, e2 = 0, de = 0;
+    if (o.op == OP_DISP_PERFORM) {
+        ref_disp_perform<D>(a, o.i, o.delta, lds_ids, &e1, &e2, &de);
+    } else if (o.op == OP_DISP_REVERT) {
+        ref_disp_revert<D>(a, o.i, o.delta, o.de_in);
+    } else if (o.op == OP_SWAP_PERFORM) {
+        ref_swap_perform<D>(a, o.i, o.j, a.species[o.i], a.species[o.j], lds_ids, &e1, &e2, &de);
+    } else if (o.op == OP_SWAP_REVERT) {
+        // called with the inverted action (src/moves.jl:212-214): o.i currently holds action.species[1]
+        ref_swap_revert(a, o.i, o.j, a.species[o.i], a.species[o.j], o.de_in);
+    } else {
+        unsigned long long att[8] = {0}, acc[8] = {0};
+        for (long long t = 0; t < o.nsteps; t++) {
+            unsigned long long g = o.step0 + (unsigned long long)t;
+            uint32_t R[4], Q[4];
+            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, o.key0, o.key1, R);
+            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ1, o.key0, o.key1, Q);
+            int m = select_move(o.pool, R[0]);
+            double lnu = det_log(uniform53(R[2], R[3]));
+            bool ok = false;
+            if (o.pool.kind[m] == 0) {
+                int i = (int)mulhi32(R[1], (uint32_t)a.N);
+                double z[4], delta[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+                box_muller(Q[0], Q[1], &z[0], &z[1]);
+                box_muller(Q[2], Q[3], &z[2], &z[3]);
+#pragma unroll
+                for (int q = 0; q < D; q++) { delta[q] = o.pool.sigma[m] * z[q]; md[q] = -delta[q]; }
+                ref_disp_perform<D>(a, i, delta, lds_ids, &e1, &e2, &de);
+                ok = lnu < -(e2 - e1) / a.temperature;
+                if (!ok) ref_disp_revert<D>(a, i, md, de);
+            } else {
+                int sa = o.pool.sp0[m], sb = o.pool.sp1[m];
+                int na = a.sp_off[sa + 1] - a.sp_off[sa], nb = a.sp_off[sb + 1] - a.sp_off[sb];
+                if (na > 0 && nb > 0) {
+                    int i = a.sp_ids[a.sp_off[sa] + mulhi32(R[1], (uint32_t)na)];
+                    int j = a.sp_ids[a.sp_off[sb] + mulhi32(Q[0], (uint32_t)nb)];
+                    ref_swap_perform<D>(a, i, j, sa, sb, lds_ids, &e1, &e2, &de);
+                    ok = lnu < -(e2 - e1) / a.temperature;
+                    if (!ok) ref_swap_revert(a, j, i, sa, sb, de);
+                }
+            }
+            // runtime-indexed counters stay in registers via a select chain
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                att[q] += (q == m);
+                acc[q] += (q == m && ok);
+            }
+        }
+        if (lane == 0)
+            for (int q = 0; q < 8; q++) { o.stats[q] += att[q]; o.stats[8 + q] += acc[q]; }
+    }
+    if (lane == 0 && o.result) { o.result[0] = e1; o.result[1] = e2; o.result[2] = de; }
+}
+
+// ------------------------------------------------------------------------------
+// throughput engine
+// ------------------------------------------------------------------------------
+
+struct CbArgs {
+    int n[3];
+    int half[3];
+    double w[3], shift[3], L[3], invL[3];
+    double temperature;
+    const int *start;
+    const int *ids;
+    double *sx, *sy, *sz;
+    unsigned char *ssp;
+    double *pos;               // AoS, particle-id order (kept current)
+    int *species;
+    int N, S;
+    uint32_t key0, key1, s_lo, s_hi;
+    int colour;
+    int nactive;               // cells handled by this launch
+    int all_cells;             // 1: every cell (total energy), 0: one colour
+    MovePool pool;
+    DevModel m0;
+    const DevModel *models;
+    unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
+    double *e_particle;        // optional per-particle energies (id order)
+};
+
+// bijective remap so that blocks sharing an XCD (b % 8) work on one contiguous
+// slab of cells: their neighbour cells then hit that XCD's L2
+__device__ __forceinline__ int xcd_remap(int b, int nb)
+{
+    int q = nb >> 3, r = nb & 7;
+    int xcd = b & 7, loc = b >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+struct WaveNbh {
+    double *cx, *cy, *cz;
+    unsigned char *csp;
+    int *segoff;   // PMC_MAXNN + 1
+    int *segsrc;   // PMC_MAXNN
+    int ncand;
+    int nc;        // centre-cell population (candidates [0, nc))
+    int k0;        // CSR offset of the centre cell
+    int lin;
+};
+
+__device__ __forceinline__ int nbh_find(const WaveNbh &h, int NN, int k)
+{
+    int lo = 0, hi = NN;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (h.segoff[mid] <= k) lo = mid; else hi = mid;
+    }
+    return h.segsrc[lo] + (k - h.segoff[lo]);
+}
+
+// Stage the 3^D neighbour cells of cell `cell` (centre first) into LDS.
+template <int D, bool MULTI>
+__device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h)
+{
+    constexpr int NN = (D == 3) ? 27 : 9;
+    const int lane = wave_lane();
+    int seg_start = 0, seg_cnt = 0;
+    if (lane < NN) {
+        // lane 0 <-> centre (offset index (NN-1)/2), that lane takes offset 0
+        int o = (lane == 0) ? (NN - 1) / 2 : ((lane == (NN - 1) / 2) ? 0 : lane);
+        int lin2 = 0, r = o;
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            int cq = cell[q] + (r % 3) - 1;
+            r /= 3;
+            if (cq < 0) cq += a.n[q];
+            if (cq >= a.n[q]) cq -= a.n[q];
+            lin2 = lin2 * a.n[q] + cq;
+        }
+        seg_start = a.start[lin2];
+        seg_cnt = a.start[lin2 + 1] - seg_start;
+    }
+    int incl = seg_cnt;
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) {
+        int v = __shfl_up(incl, s, PMC_WAVE);
+        if (lane >= s) incl += v;
+    }
+    if (lane < NN) {
+        h.segoff[lane] = incl - seg_cnt;
+        h.segsrc[lane] = seg_start;
+    }
+    h.ncand = __shfl(incl, NN - 1, PMC_WAVE);
+    if (lane == 0) h.segoff[NN] = h.ncand;
+    h.nc = __shfl(seg_cnt, 0, PMC_WAVE);
+    h.k0 = __shfl(seg_start, 0, PMC_WAVE);
+    __syncthreads();
+    int lim = min(h.ncand, PMC_CAP);
+    for (int k = lane; k < lim; k += PMC_WAVE) {
+        int src = nbh_find(h, NN, k);
+        h.cx[k] = a.sx[src];
+        h.cy[k] = a.sy[src];
+        if (D == 3) h.cz[k] = a.sz[src];
+        if (MULTI) h.csp[k] = a.ssp[src];
+    }
+    __syncthreads();
+}
+
+template <int D, bool MULTI>
+__device__ __forceinline__ void nbh_load(const CbArgs &a, const WaveNbh &h, int k, double &xj, double &yj,
+                                         double &zj, int &sj)
+{
+    constexpr int NN = (D == 3) ? 27 : 9;
+    if (k < PMC_CAP) {
+        xj = h.cx[k];
+        yj = h.cy[k];
+        zj = (D == 3) ? h.cz[k] : 0.0;
+        sj = MULTI ? (int)h.csp[k] : 0;
+    } else {
+        int src = nbh_find(h, NN, k);
+        xj = a.sx[src];
+        yj = a.sy[src];
+        zj = (D == 3) ? a.sz[src] : 0.0;
+        sj = MULTI ? (int)a.ssp[src] : 0;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ double dist2_fast(const CbArgs &a, double xi, double yi, double zi, double xj,
+                                             double yj, double zj)
+{
+    double vx = dev_vector_1d_fast(xi, xj, a.L[0], a.invL[0]);
+    double vy = dev_vector_1d_fast(yi, yj, a.L[1], a.invL[1]);
+    double r2 = vx * vx;
+    r2 = r2 + vy * vy;
+    if (D == 3) {
+        double vz = dev_vector_1d_fast(zi, zj, a.L[2], a.invL[2]);
+        r2 = r2 + vz * vz;
+    }
+    return r2;
+}
+
+template <int KIND>
+__device__ __forceinline__ double pot_kind(double r2, const DevModel &m)
+{
+    if (KIND == 4) return dev_potential_dyn(r2, m);
+    return dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m);
+}
+
+// exact per-particle energy of a particle at (xi,yi,zi) with species si against
+// the staged neighbourhood, skipping candidates ex1 / ex2; result in every lane
+template <int D, int KIND, bool MULTI>
+__device__ __forceinline__ double nbh_energy(const CbArgs &a, const WaveNbh &h, const DevModel *tab,
+                                             double xi, double yi, double zi, int si, int ex1, int ex2)
+{
+    double e = 0.0;
+    for (int k = wave_lane(); k < h.ncand; k += PMC_WAVE) {
+        double xj, yj, zj;
+        int sj;
+        nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
+        const DevModel &m = MULTI ? tab[si * a.S + sj] : a.m0;
+        double r2 = dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
+        if (k != ex1 && k != ex2 && !(r2 > m.rcut2)) e += dev_quant(pot_kind<KIND>(r2, m));
+    }
+    return wave_sum(e);
+}
+
+#define PMC_LDS_WAVE_BYTES (3 * PMC_CAP * 8 + PMC_CAP + 2 * 32 * 4)
+
+template <int D, bool MULTI>
+__device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned char *smem, WaveNbh &h)
+{
+    h.cx = reinterpret_cast<double *>(smem);
+    h.cy = h.cx + PMC_CAP;
+    h.cz = h.cy + PMC_CAP;
+    h.segoff = reinterpret_cast<int *>(h.cz + PMC_CAP);
+    h.segsrc = h.segoff + 32;
+    h.csp = reinterpret_cast<unsigned char *>(h.segsrc + 32);
+    DevModel *tab = reinterpret_cast<DevModel *>(smem + ((PMC_LDS_WAVE_BYTES + 15) & ~15));
+    if (MULTI) {
+        for (int k = threadIdx.x; k < a.S * a.S; k += blockDim.x) tab[k] = a.models[k];
+        __syncthreads();
+    }
+    return tab;
+}
+
+template <int D>
+__device__ __forceinline__ bool decode_cell(const CbArgs &a, int aidx, int cell[3], int &lin)
+{
+    int r = aidx;
+    if (a.all_cells) {
+#pragma unroll
+        for (int q = D - 1; q >= 0; q--) { cell[q] = r % a.n[q]; r /= a.n[q]; }
+    } else {
+#pragma unroll
+        for (int q = D - 1; q >= 0; q--) {
+            cell[q] = 2 * (r % a.half[q]) + ((a.colour >> q) & 1);
+            r /= a.half[q];
+        }
+    }
+    lin = 0;
+#pragma unroll
+    for (int q = 0; q < D; q++) lin = lin * a.n[q] + cell[q];
+    return true;
+}
+
+// sum(local_energy) (src/atoms.jl:51-52) over the cells of this launch, exact:
+// stats[16] += sum_i e_i * 2^32; optional per-particle energies.
+template <int D, int KIND, bool MULTI>
+__global__ __launch_bounds__(64) void k_total_energy(CbArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    WaveNbh h;
+    const DevModel *tab = setup_lds<D, MULTI>(a, smem, h);
+    int aidx = xcd_remap(blockIdx.x, gridDim.x);
+    if (aidx >= a.nactive) return;
+    int cell[3] = {0, 0, 0}, lin;
+    decode_cell<D>(a, aidx, cell, lin);
+    h.lin = lin;
+    stage_neighbourhood<D, MULTI>(a, cell, h);
+    if (h.nc == 0) return;
+    if (h.nc > PMC_CAP) { if (wave_lane() == 0) atomicOr(&a.stats[17], 1ull); return; }
+    long long tot = 0;
+    for (int p = 0; p < h.nc; p++) {
+        double xi = h.cx[p], yi = h.cy[p], zi = (D == 3) ? h.cz[p] : 0.0;
+        int si = MULTI ? (int)h.csp[p] : 0;
+        double e = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, si, p, -1);
+        tot += (long long)(e * PMC_FIX);
+        if (a.e_particle && wave_lane() == 0) a.e_particle[a.ids[h.k0 + p]] = e;
+    }
+    if (wave_lane() == 0) atomicAdd(&a.stats[16], (unsigned long long)tot);
+}
+
+// k-th (0-based) centre-cell particle of species sp, in cell order; uniform
+__device__ __forceinline__ int kth_of_species(const WaveNbh &h, int sp, int k)
+{
+    for (int c0 = 0; c0 < h.nc; c0 += PMC_WAVE) {
+        int idx = c0 + wave_lane();
+        bool is = idx < h.nc && (int)h.csp[idx] == sp;
+        unsigned long long b = __ballot(is);
+        int cnt = __popcll(b);
+        if (k < cnt) {
+            for (int q = 0; q < k; q++) b &= b - 1;
+            return c0 + (__ffsll((long long)b) - 1);
+        }
+        k -= cnt;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
+{
+    int n = 0;
+    for (int c0 = 0; c0 < h.nc; c0 += PMC_WAVE) {
+        int idx = c0 + wave_lane();
+        n += __popcll(__ballot(idx < h.nc && (int)h.csp[idx] == sp));
+    }
+    return n;
+}
+
+// One colour pass of the checkerboard sweep: one wavefront per active cell.
+// The cell's n_c proposal slots run in order against the LDS-resident
+// neighbourhood; Displacement slots that would leave the cell are rejected.
+template <int D, int KIND, bool MULTI>
+__global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    WaveNbh h;
+    const DevModel *tab = setup_lds<D, MULTI>(a, smem, h);
+    const int lane = wave_lane();
+    int aidx = xcd_remap(blockIdx.x, gridDim.x);
+    if (aidx >= a.nactive) return;
+    int cell[3] = {0, 0, 0}, lin;
+    decode_cell<D>(a, aidx, cell, lin);
+    h.lin = lin;
+    stage_neighbourhood<D, MULTI>(a, cell, h);
+    const int nc = h.nc;
+    if (nc == 0) return;
+    if (nc > PMC_CAP) { if (lane == 0) atomicOr(&a.stats[17], 1ull); return; }
+
+    unsigned long long att[8] = {0}, acc[8] = {0};
+    long long efix = 0;
+    bool dirty = false;
+
+    for (int chunk = 0; chunk < nc; chunk += PMC_WAVE) {
+        // lanes generate the slots of this chunk in parallel
+        int t = chunk + lane;
+        int g_m = 0;
+        uint32_t g_w1 = 0, g_w2 = 0;
+        double g_dx = 0, g_dy = 0, g_dz = 0, g_lnu = 0;
+        if (t < nc) {
+            uint32_t R[4], Q[4];
+            philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT0 << 24), a.key0, a.key1, R);
+            philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT1 << 24), a.key0, a.key1, Q);
+            g_m = select_move(a.pool, R[0]);
+            g_lnu = det_log(uniform53(R[2], R[3]));
+            g_w1 = R[1];
+            g_w2 = Q[0];
+            double z[4];
+            box_muller(Q[0], Q[1], &z[0], &z[1]);
+            box_muller(Q[2], Q[3], &z[2], &z[3]);
+            double sg = a.pool.sigma[g_m];
+            g_dx = sg * z[0];
+            g_dy = sg * z[1];
+            g_dz = sg * z[2];
+        }
+        int nslots = min(PMC_WAVE, nc - chunk);
+        for (int s = 0; s < nslots; s++) {
+            const int m = __builtin_amdgcn_readlane(g_m, s);
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, s);
+            const double lnu = readlane_double(g_lnu, s);
+            bool ok = false;
+            if (a.pool.kind[m] == 0) {
+                const int p = (int)mulhi32(w1, (uint32_t)nc);
+                const double xo = h.cx[p], yo = h.cy[p], zo = (D == 3) ? h.cz[p] : 0.0;
+                const double xn = xo + readlane_double(g_dx, s);
+                const double yn = yo + readlane_double(g_dy, s);
+                const double zn = (D == 3) ? zo + readlane_double(g_dz, s) : 0.0;
+                bool inside = mc_coord<D>(xn, a.shift[0], a.w[0]) == mc_coord<D>(xo, a.shift[0], a.w[0]) &&
+                              mc_coord<D>(yn, a.shift[1], a.w[1]) == mc_coord<D>(yo, a.shift[1], a.w[1]);
+                if (D == 3)
+                    inside = inside && mc_coord<D>(zn, a.shift[2], a.w[2]) == mc_coord<D>(zo, a.shift[2], a.w[2]);
+                if (inside) {
+                    const int si = MULTI ? (int)h.csp[p] : 0;
+                    double e1 = 0.0, e2 = 0.0;
+                    for (int k = lane; k < h.ncand; k += PMC_WAVE) {
+                        double xj, yj, zj;
+                        int sj;
+                        nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
+                        const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
+                        double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
+                        double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
+                        if (k != p) {
+                            if (!(r2o > mm.rcut2)) e1 += dev_quant(pot_kind<KIND>(r2o, mm));
+                            if (!(r2n > mm.rcut2)) e2 += dev_quant(pot_kind<KIND>(r2n, mm));
+                        }
+                    }
+                    e1 = wave_sum(e1);
+                    e2 = wave_sum(e2);
+                    const double de = e2 - e1;
+                    ok = lnu < -de / a.temperature;
+                    if (ok) {
+                        __syncthreads();
+                        if (lane == 0) {
+                            h.cx[p] = xn;
+                            h.cy[p] = yn;
+                            if (D == 3) h.cz[p] = zn;
+                        }
+                        __syncthreads();
+                        efix += (long long)(de * PMC_FIX);
+                        dirty = true;
+                    }
+                }
+            } else if (MULTI) {
+                const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)g_w2, s);
+                const int sa = a.pool.sp0[m], sb = a.pool.sp1[m];
+                const int na = count_species(h, sa), nb = count_species(h, sb);
+                if (na > 0 && nb > 0 && sa != sb) {
+                    const int pi = kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
+                    const int pj = kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
+                    const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
+                    const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
+                    double e1 = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, sa, pi, pj) +
+                                nbh_energy<D, KIND, MULTI>(a, h, tab, xj, yj, zj, sb, pi, pj);
+                    double e2 = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, sb, pi, pj) +
+                                nbh_energy<D, KIND, MULTI>(a, h, tab, xj, yj, zj, sa, pi, pj);
+                    const double de = e2 - e1;
+                    ok = lnu < -de / a.temperature;
+                    if (ok) {
+                        __syncthreads();
+                        if (lane == 0) {
+                            h.csp[pi] = (unsigned char)sb;
+                            h.csp[pj] = (unsigned char)sa;
+                        }
+                        __syncthreads();
+                        efix += (long long)(de * PMC_FIX);
+                        dirty = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                att[q] += (q == m);
+                acc[q] += (q == m && ok);
+            }
+        }
+    }
+    if (dirty) {
+        for (int k = lane; k < nc; k += PMC_WAVE) {
+            int id = a.ids[h.k0 + k];
+            a.sx[h.k0 + k] = h.cx[k];
+            a.sy[h.k0 + k] = h.cy[k];
+            a.pos[(size_t)id * D + 0] = h.cx[k];
+            a.pos[(size_t)id * D + 1] = h.cy[k];
+            if (D == 3) {
+                a.sz[h.k0 + k] = h.cz[k];
+                a.pos[(size_t)id * D + 2] = h.cz[k];
+            }
+            if (MULTI) {
+                a.ssp[h.k0 + k] = h.csp[k];
+                a.species[id] = (int)h.csp[k];
+            }
+        }
+    }
+    if (lane == 0) {
+        for (int q = 0; q < a.pool.npool; q++) {
+            if (att[q]) atomicAdd(&a.stats[q], att[q]);
+            if (acc[q]) atomicAdd(&a.stats[8 + q], acc[q]);
+        }
+        if (efix) atomicAdd(&a.stats[16], (unsigned long long)efix);
+    }
+}
+
+// independent batch of Displacement dE (exact sums): one wavefront per proposal,
+// candidates streamed straight from the CSR arrays of the cell of the old and of
+// the new position.
+template <int D>
+__device__ double stream_energy(const CbArgs &a, double xi, double yi, double zi, int si, int self_id)
+{
+    constexpr int NN = (D == 3) ? 27 : 9;
+    const double x[3] = {xi, yi, zi};
+    int cell[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < D; q++) {
+        long long c = (long long)mc_coord<D>(x[q], a.shift[q], a.w[q]);
+        int r = (int)(c % a.n[q]);
+        if (r < 0) r += a.n[q];
+        cell[q] = r;
+    }
+    double e = 0.0;
+    for (int o = 0; o < NN; o++) {
+        int lin2 = 0, r = o;
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            int cq = cell[q] + (r % 3) - 1;
+            r /= 3;
+            if (cq < 0) cq += a.n[q];
+            if (cq >= a.n[q]) cq -= a.n[q];
+            lin2 = lin2 * a.n[q] + cq;
+        }
+        int lo = a.start[lin2], hi = a.start[lin2 + 1];
+        for (int k = lo + wave_lane(); k < hi; k += PMC_WAVE) {
+            if (a.ids[k] == self_id) continue;
+            const DevModel &m = a.models[si * a.S + (int)a.ssp[k]];
+            double r2 = dist2_fast<D>(a, xi, yi, zi, a.sx[k], a.sy[k], (D == 3) ? a.sz[k] : 0.0);
+            if (!(r2 > m.rcut2)) e += dev_quant(dev_potential_dyn(r2, m));
+        }
+    }
+    return wave_sum(e);
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_delta_e(CbArgs a, int n, const int *__restrict__ which,
+                                                const double *__restrict__ delta, double *__restrict__ e1,
+                                                double *__restrict__ e2)
+{
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        int i = which[b];
+        double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            x[q] = a.pos[(size_t)i * D + q];
+            xn[q] = x[q] + delta[(size_t)b * D + q];
+        }
+        int si = a.species[i];
+        double ea = stream_energy<D>(a, x[0], x[1], x[2], si, i);
+        double eb = stream_energy<D>(a, xn[0], xn[1], xn[2], si, i);
+        if (wave_lane() == 0) { e1[b] = ea; e2[b] = eb; }
+    }
+}
+
+__global__ void k_debug_rng(int n, const uint32_t *__restrict__ w1, const uint32_t *__restrict__ w2,
+                            double *__restrict__ z0, double *__restrict__ z1, double *__restrict__ lnu)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, b;
+    box_muller(w1[i], w2[i], &a, &b);
+    z0[i] = a;
+    z1[i] = b;
+    lnu[i] = det_log(uniform53(w1[i], w2[i]));
+}
