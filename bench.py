@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- attempted Monte-Carlo moves per second of the HIP hot path on MI355X.
+
+Workload (BASELINE.json metric): N = 10^6 3-D Lennard-Jones
+particles, rho = 1.0, T = 1.0, rcut = 2.5 (shifted), Displacement moves with
+sigma = 0.05, from a 100^3 simple-cubic lattice jittered by U(-0.05, 0.05).
+One "step" = one sweep = N attempted moves.  With --gpus N every rank runs its own
+independent chain (seed 42 + rank) on its own GPU: weak scaling, no data-path
+collective.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 100] [--no-cpu]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SIGMA_MOVE = 0.05
+TEMPERATURE = 1.0
+
+
+def algorithmic_bytes_per_move(N, d, ncells_ref, multi_species=False):
+    """B_alg = 27 n_c (8 d + s) + 2 * 8 d with n_c the mean population of the reference's
+    LinkedList cells: 10 972 B at N = 10^6."""
+    nbar = N / float(np.prod(ncells_ref))
+    return (3 ** d) * nbar * (8 * d + (4 if multi_species else 0)) + 2 * 8 * d
+
+
+def cpu_baseline(pos, sp, rho, budget_moves):
+    """The oracle's sequential LinkedList path (one thread) on the same input, bounded sample."""
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    ref = O.System(pos, sp, rho, TEMPERATURE, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    t_build = time.perf_counter() - t0
+    pool = O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}])
+    # calibrate on a short burst, then run the bounded sample
+    t0 = time.perf_counter()
+    ref.mc_steps(pool, 42, 0, 0, 20000)
+    rate = 20000 / (time.perf_counter() - t0)
+    n = int(min(budget_moves, max(20000, rate * 12.0)))
+    t0 = time.perf_counter()
+    att, acc = ref.mc_steps(pool, 42, 0, 20000, n)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "attempted moves/s", "cores": 1, "kind": "port",
+        "sample": f"{n} sequential Displacement steps (reference LinkedList path, oracle/pmc_oracle.c) on the same "
+                  f"N={len(pos)} input after a {t_build:.1f} s build; acceptance {acc[0] / max(1, att[0]):.3f}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=100, help="lattice sites per side (N = n^3)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ngpus = world
+
+    import particlesmc_amd as pmc
+    from inputs import lj_lattice
+
+    if pmc.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device; the HIP path has no CPU fallback")
+    pos, sp, rho = lj_lattice(args.n, jitter=0.05, seed=42)
+    N = len(pos)
+    system = pmc.System(pos, sp, rho, TEMPERATURE, pmc.LennardJones(1.0, 1.0), seed=42 + rank, chain=rank,
+                        device=local_rank)
+    pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": SIGMA_MOVE}, 1.0)]
+    e0, _ = system.total_energy()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        pmc.mc_sweep(system, pool, nsweeps=args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    st = pmc.mc_sweep(system, pool, nsweeps=args.steps)       # synchronises its stream before returning
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # exactness property at full size: the running energy equals a recomputation bit for bit
+    run_fix = st.energy_fix
+    e1, efix = system.total_energy()
+    energy_ok = bool(efix == run_fix)
+
+    if rank == 0:
+        moves = float(N) * args.steps * ngpus
+        value = moves / elapsed
+        ncell_ref = system.neighbour_list.ncells
+        b_alg = algorithmic_bytes_per_move(N, 3, ncell_ref)
+        launches = max(1, int(st.sweep_kernel_launches))
+        avg_launch_s = st.sweep_kernel_ms * 1e-3 / launches
+        moves_per_launch = N * min(args.steps, 4096) / launches
+        achieved = b_alg * moves_per_launch / avg_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_cb_pass_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "attempted MC moves/sec, N=10^6 3D LJ rho=1.0 (one sweep = N attempted moves)",
+            "value": value, "unit": "attempted moves/s", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N={N} 3D LJ rho=1.0 T=1.0 rcut=2.5 shifted, Displacement sigma=0.05, "
+                                   f"jittered {args.n}^3 lattice, one independent chain per GPU",
+                       "schedule": "checkerboard", "grid": [int(v) for v in system.grid()[0]],
+                       "reference_cells": [int(v) for v in ncell_ref]},
+            "sweeps_per_s": args.steps * ngpus / elapsed,
+            "acceptance": float(st.accepted[0]) / float(max(1, st.attempted[0])),
+            "energy_per_particle": e1 / N, "energy_per_particle_initial": e0 / N,
+            "running_energy_equals_recomputed": energy_ok,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_cb_pass<3,LJ,single-species>", "algorithmic_bytes_per_move": b_alg,
+                         "moves_per_launch": moves_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
+                         "reference_traversal_bytes_per_move": 2 * 27 * (N / float(np.prod(ncell_ref))) * 40.0},
+        }
+        if ngpus == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(pos, sp, rho, 3_000_000)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

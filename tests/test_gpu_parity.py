@@ -71,7 +71,7 @@ def test_golden_jbb_energy_on_device(gpu):
     assert abs(e - ref.energy) <= REL_TOL * abs(ref.energy)
 
 
-@pytest.mark.parametrize("n,jit", [(12, 0.05), (16, 0.3)])
+@pytest.mark.parametrize("n,jit", [(12, 0.05), (16, 0.1)])
 def test_cells_lists_energies_bitexact_3d(gpu, n, jit):
     from oracle import oracle as O
     pmc = gpu
@@ -96,7 +96,7 @@ def test_cells_lists_energies_bitexact_3d(gpu, n, jit):
 def test_total_energy_exact_and_close(gpu):
     from oracle import oracle as O
     pmc = gpu
-    pos, sp, rho = lj_lattice(16, jitter=0.2, seed=5)
+    pos, sp, rho = lj_lattice(16, jitter=0.1, seed=5)
     g, o = _pair(pmc, O, pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), O.single(O.lennard_jones(1.0, 1.0)))
     cb = O.Checkerboard(pos, sp, o.box, 1.0, o.models, seed=11)
     e, efix = g.total_energy()
