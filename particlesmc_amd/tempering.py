@@ -1,0 +1,82 @@
+"""Parallel tempering across GPUs: one replica per rank, RCCL only for the exchange step.
+
+The reference has no replica exchange ("parallel tempering (soon)", README.md:33), so this
+defines it: every `exchange_every` sweeps each rank all-gathers ONE double (its
+total energy) -- `torch.distributed.all_gather`, i.e. RCCL over xGMI with the nccl backend,
+gloo on CPU -- then every rank evaluates the same Philox-keyed Metropolis decisions for the
+active (even/odd) pairs of adjacent temperatures with `pmc_pt_decide` and adopts its new
+temperature label.  Configurations never move between GPUs; the bulk traffic is zero.
+Acceptance: min(1, exp((beta_a - beta_b) (E_a - E_b))).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def pt_decide(seed, rnd, energies, ladder, label):
+    """Deterministic exchange decisions (same answer on every rank). Returns (label, n_accepted)."""
+    e = np.ascontiguousarray(energies, dtype=np.float64)
+    lad = np.ascontiguousarray(ladder, dtype=np.float64)
+    lab = np.ascontiguousarray(label, dtype=np.int32).copy()
+    nacc = C.c_int32()
+    _lib.check(_lib.lib().pmc_pt_decide(int(seed), int(rnd), len(e), e.ctypes.data_as(C.POINTER(C.c_double)),
+                                        lad.ctypes.data_as(C.POINTER(C.c_double)),
+                                        lab.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nacc)))
+    return lab, nacc.value
+
+
+class ReplicaExchange:
+    """State of one rank in a temperature ladder of `world` replicas."""
+
+    def __init__(self, ladder, seed, rank=0, world=1, group=None, device="cpu"):
+        self.ladder = np.ascontiguousarray(ladder, dtype=np.float64)
+        if len(self.ladder) != world:
+            raise ValueError("one temperature per rank")
+        self.seed, self.rank, self.world, self.group, self.device = int(seed), rank, world, group, device
+        self.label = np.arange(world, dtype=np.int32)     # replica r starts at ladder[r]
+        self.round = 0
+        self.accepted = 0
+        self.attempted = 0
+
+    @property
+    def temperature(self):
+        return float(self.ladder[self.label[self.rank]])
+
+    def gather(self, energy):
+        if self.world == 1:
+            return np.array([energy], dtype=np.float64)
+        import torch
+        import torch.distributed as dist
+        mine = torch.tensor([energy], dtype=torch.float64, device=self.device)
+        out = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(out, mine, group=self.group)
+        return np.array([float(t.item()) for t in out], dtype=np.float64)
+
+    def exchange(self, energy):
+        """One exchange round; returns this rank's new temperature."""
+        energies = self.gather(float(energy))
+        self.label, nacc = pt_decide(self.seed, self.round, energies, self.ladder, self.label)
+        parity = self.round & 1
+        self.attempted += max(0, (self.world - parity) // 2)
+        self.accepted += nacc
+        self.round += 1
+        return self.temperature
+
+
+def run_tempering(system, pool, ladder, nsweeps, exchange_every, seed, rank=0, world=1, group=None, device="cpu",
+                  mode="checkerboard"):
+    """Sweeps on this rank's replica with an exchange round every `exchange_every` sweeps."""
+    from .simulation import mc_sweep
+    rex = ReplicaExchange(ladder, seed, rank, world, group, device)
+    system.temperature = rex.temperature
+    done = 0
+    trace = []
+    while done < nsweeps:
+        k = min(exchange_every, nsweeps - done)
+        st = mc_sweep(system, pool, nsweeps=k, mode=mode)
+        done += k
+        system.temperature = rex.exchange(st.energy)
+        trace.append((done, int(rex.label[rank]), st.energy))
+    return rex, trace

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output under gpurun_out/prof/ into the tracked summaries in profiles/.
+
+Usage (after the gpurun call in profiles/README.md):  python profiles/summarize.py r01
+Writes profiles/<round>_kernel_stats.csv, profiles/<round>_pmc.json and profiles/traffic.json.
+HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are reported in KiB,
+collected in separate --pmc passes, and on gfx950 FETCH_SIZE counts 64 B per 128-B request,
+so the read side is doubled.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def counters(sub):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+summary = {}
+for sub in ("fetch", "write", "sq"):
+    for k, v in counters(sub).items():
+        for c, vals in v.items():
+            summary.setdefault(k, {})[c] = {"launches": len(vals), "mean": sum(vals) / len(vals)}
+json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+for k, v in summary.items():
+    if k.startswith("void k_cb_pass<3, 0, false>") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        fetch_kib, write_kib = v["FETCH_SIZE"]["mean"], v["WRITE_SIZE"]["mean"]
+        traffic = {
+            "kernel": k, "round": tag,
+            "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
+            "k_cb_pass_hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
+            "note": "read side doubled (gfx950 FETCH_SIZE correction); 8-B-per-lane gathers are not a calibrated "
+                    "access width, so treat the absolute as +-2x; it is ~35x below the algorithmic bytes",
+        }
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        print(traffic)
+print("wrote", tag)

@@ -1,0 +1,279 @@
+"""CPU: the oracle against the reference's own goldens and known answers.
+
+These pin the oracle before it is trusted as the checker of the HIP path."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from inputs import lj_lattice
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def O(built):
+    from oracle import oracle
+    oracle.lib()
+    return oracle
+
+
+def _load(name):
+    """Minimal reader, independent of particlesmc_amd.io: returns (pos, species, box)."""
+    lines = open(os.path.join(GOLD, name)).read().split("\n")
+    if name.endswith(".lmp"):
+        start = next(k for k, l in enumerate(lines) if l.startswith("ITEM: ATOMS")) + 1
+        n = int(lines[3])
+        lo, hi = [float(v) for v in lines[5].split()]
+        box = np.array([hi - lo, hi - lo])
+    else:
+        n = int(lines[0])
+        start = 2
+        box = np.array([32.8962, 32.8962])
+    rows = np.array([[float(v) for v in l.split()] for l in lines[start:start + n]])
+    return rows[:, 1:3].copy(), rows[:, 0].astype(np.int32), box
+
+
+def _fold(O, pos, box):
+    L = O.lib()
+    out = pos.copy()
+    for i in range(pos.shape[0]):
+        for a in range(pos.shape[1]):
+            out[i, a] = pos[i, a] - L.orc_jl_fld(pos[i, a], box[a]) * box[a]     # utils.jl:12
+    return out
+
+
+@pytest.mark.parametrize("fname", ["config_0.xyz", "config_0.exyz", "config_0.lmp"])
+@pytest.mark.parametrize("lt", [0, 1])
+def test_jbb_known_answer(O, fname, lt):
+    """test/runtests.jl:36-38: energy/N == -2.676832 (atol 1e-6) for EmptyList and LinkedList."""
+    pos, sp, box = _load(fname)
+    assert len(pos) == 1290 and sorted(np.bincount(sp)[1:]) == [330, 360, 600]
+    rho = len(pos) / np.prod(box)
+    if fname != "config_0.lmp":
+        assert rho == 1.192060351952634            # test/params.toml density
+    s = O.System(_fold(O, pos, box), sp, rho, 0.231, O.jbb(), lt)
+    assert abs(s.energy / s.N - (-2.676832)) < 1e-6
+
+
+def test_lists_agree_on_initial_state(O):
+    pos, sp, box = _load("config_0.xyz")
+    rho = len(pos) / np.prod(box)
+    p = _fold(O, pos, box)
+    el = O.System(p, sp, rho, 0.231, O.jbb(), O.EMPTYLIST)
+    ll = O.System(p, sp, rho, 0.231, O.jbb(), O.LINKEDLIST)
+    assert abs(el.energy - ll.energy) < 1e-9
+    e1, e2 = el.energy_particles(), ll.energy_particles()
+    assert np.allclose(e1, e2, rtol=0, atol=1e-11)
+
+
+def _trace(O, lt, pool, sweeps, seed=10):
+    pos, sp, box = _load("config_0.xyz")
+    rho = len(pos) / np.prod(box)
+    s = O.System(_fold(O, pos, box), sp, rho, 0.231, O.jbb(), lt)
+    out = [s.energy / s.N]
+    att = acc = 0
+    for t in range(sweeps):
+        a, c = s.mc_steps(pool, seed, 0, t * s.N, s.N)
+        att, acc = att + a, acc + c
+        out.append(s.energy / s.N)
+    return np.array(out), att, acc, s
+
+
+def test_same_seed_traces_equal_across_list_types_displacement(O):
+    """test/runtests.jl:83-91 (differential): same seed, Displacement sigma = 0.05."""
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.05}])
+    el, att_e, acc_e, _ = _trace(O, O.EMPTYLIST, pool, 8)
+    ll, att_l, acc_l, _ = _trace(O, O.LINKEDLIST, pool, 8)
+    assert np.allclose(el, ll, rtol=0, atol=1e-6)
+    assert np.array_equal(acc_e, acc_l) and acc_e[0] > 0
+
+
+def test_same_seed_traces_equal_across_list_types_swaps(O):
+    """test/runtests.jl:93-129: 20 % Displacement + 40 % swap(1,3) + 40 % swap(2,3)."""
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.2},
+                        {"kind": "DiscreteSwap", "species": (1, 3), "probability": 0.4},
+                        {"kind": "DiscreteSwap", "species": (2, 3), "probability": 0.4}])
+    el, _, acc_e, se = _trace(O, O.EMPTYLIST, pool, 4)
+    ll, _, acc_l, sl = _trace(O, O.LINKEDLIST, pool, 4)
+    assert np.allclose(el, ll, rtol=0, atol=1e-6)
+    assert np.array_equal(acc_e, acc_l) and acc_e[1] > 0
+    assert np.array_equal(se.species(), sl.species())
+    assert sorted(np.bincount(sl.species())[1:]) == [330, 360, 600]
+
+
+def test_running_energy_tracks_recomputation(O):
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.05}])
+    _, _, _, s = _trace(O, O.LINKEDLIST, pool, 3)
+    assert abs(s.energy - s.total_energy()) < 1e-8 * abs(s.energy)
+
+
+def test_analytic_known_answers(O):
+    m = O.lennard_jones(1.0, 1.0)
+    assert m.shift == -0.016316891136000003               # 4 (2.5^-12 - 2.5^-6), SURVEY 7.1
+    n = 8
+    g = np.array([[i, j, k] for i in range(n) for j in range(n) for k in range(n)], dtype=float)
+    s = O.System(g, np.ones(len(g), dtype=np.int32), 1.0, 1.0, O.single(m), O.LINKEDLIST)
+    # shells r^2 = 1..6 with multiplicities 6, 12, 8, 6, 24, 24 (r^2 = 6.25 is the cutoff)
+    ref = 0.0
+    for r2, mult in zip((1, 2, 3, 4, 5, 6), (6, 12, 8, 6, 24, 24)):
+        x3 = (1.0 / r2) ** 3
+        ref += mult * (4.0 * (x3 * x3 - x3) - m.shift)
+    assert abs(s.energy / len(g) - ref / 2) < 1e-12
+    assert abs(s.energy / len(g) - (-3.329660801490727)) < 1e-12
+
+
+def test_philox_known_answers(O):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2)[:2] == [0x408f276d, 0x41c83b0e]
+
+
+def test_deterministic_math_accuracy(O):
+    rng = np.random.default_rng(1)
+    L = O.lib()
+    for w in rng.integers(0, 2 ** 32, 5000):
+        s, c = O.det_sincos2pi(int(w))
+        th = 2 * math.pi * int(w) / 2 ** 32
+        assert abs(s - math.sin(th)) < 2e-15 and abs(c - math.cos(th)) < 2e-15
+    for x in rng.random(5000):
+        assert abs(L.orc_det_log(x) - math.log(x)) <= 4e-16 * abs(math.log(x)) + 1e-300
+    # antisymmetry under theta -> theta + pi keeps the Gaussian proposal exactly symmetric
+    for w in (1, 12345, 0x7fffffff, 0x12345678):
+        s1, c1 = O.det_sincos2pi(w)
+        s2, c2 = O.det_sincos2pi((w + 0x80000000) & 0xffffffff)
+        assert s1 == -s2 and c1 == -c2
+    z = np.array([O.box_muller(int(a), int(b)) for a, b in rng.integers(0, 2 ** 32, (20000, 2))]).ravel()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+
+
+def test_julia_fld_semantics(O):
+    L = O.lib()
+    assert L.orc_jl_fld(-0.3, 2.5) == -1.0 and L.orc_jl_fld(2.5, 2.5) == 1.0 and L.orc_jl_fld(0.0, 2.5) == 0.0
+    assert L.orc_jl_fld(7.4999999999999991, 2.5) == 2.0
+    assert L.orc_jl_fld(-2.5, 2.5) == -1.0 and L.orc_jl_fld(-2.5000000000000004, 2.5) == -2.0
+    assert L.orc_jl_fld_i(-1, 13) == -1 and L.orc_jl_fld_i(13, 13) == 1 and L.orc_jl_fld_i(-13, 13) == -1
+    # N = 10^6 -> 39 cells per side, N = 32768 -> 12
+    for N, nc in ((10 ** 6, 39), (32768, 12)):
+        box = (N / 1.0) ** (1.0 / 3.0)
+        cell = box / L.orc_jl_fld(box, 2.5)
+        assert int(box / cell) == nc
+
+
+def test_pow_int_matches_exact_power(O):
+    from fractions import Fraction
+    L = O.lib()
+    rng = np.random.default_rng(2)
+    for x in rng.uniform(0.05, 3.0, 300):
+        for n in (6, 7, 9):
+            exact = float(Fraction(float(x)) ** n)
+            got = L.orc_pow_int(float(x), n)
+            assert abs(got - exact) <= abs(exact) * 2.3e-16
+
+
+def test_neighbour_cells_unique_when_few_cells(O):
+    """build_neighbour_cells (neighbours.jl:94-111): unique! when < 3 cells per dimension."""
+    pos, sp, rho = lj_lattice(6, jitter=0.0)             # box 6 -> 2 cells per side
+    s = O.System(pos, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    _, nc = s.cell_geometry()
+    assert tuple(nc) == (2, 2, 2)
+    for c in range(1, 9):
+        nb = s.neighbour_cells(c)
+        assert len(nb) == 8 and sorted(nb) == list(range(1, 9))
+    # first-dimension-fastest offsets (Iterators.product), last-dimension-fastest scalar index
+    pos, sp, rho = lj_lattice(11, jitter=0.0)            # box 11 -> 4 cells per side
+    s = O.System(pos, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    nb = s.neighbour_cells(1 + (1 * 16 + 1 * 4 + 1))      # cell (1,1,1)
+    assert list(nb[:4]) == [1, 17, 33, 5]                 # (0,0,0),(1,0,0),(2,0,0),(0,1,0)
+
+
+def test_linked_list_invariants_after_moves(O):
+    pos, sp, rho = lj_lattice(8, jitter=0.1, seed=4)
+    s = O.System(pos, sp, rho, 2.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    s.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.4}]), 5, 0, 0, 4 * s.N)
+    head, lst = s.linked_list()
+    cs = s.cells()
+    seen = np.zeros(s.N, dtype=int)
+    for c, h in enumerate(head, start=1):
+        j = h
+        while j != -1:
+            seen[j - 1] += 1
+            assert cs[j - 1] == c
+            j = lst[j - 1]
+    assert np.all(seen == 1)
+    # a rebuilt list holds the same membership
+    s2 = O.System(s.positions(), sp, rho, 2.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    assert np.array_equal(s2.cells(), cs)
+
+
+def test_nonfinite_initial_energy_is_an_error(O):
+    pos, sp, rho = lj_lattice(6)
+    pos[1] = pos[0]
+    with pytest.raises(ValueError, match="infinite or NaN"):
+        O.System(pos, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+
+
+def test_checkerboard_exact_energy_bookkeeping(O):
+    pos, sp, rho = lj_lattice(11, jitter=0.1, seed=6)
+    ref = O.System(pos, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    cb = O.Checkerboard(pos, sp, ref.box, 1.0, ref.models, seed=77)
+    e0 = cb.energy_fix
+    assert abs(e0 / 2.0 ** 32 - ref.energy) <= 1e-9 * abs(ref.energy)
+    att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 0, 5)
+    assert att[0] == 5 * len(pos) and 0 < acc[0] < att[0]
+    assert cb.energy_fix == cb.total_energy_fix()          # exact, not approximate
+    ref2 = O.System(cb.positions(), sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    assert abs(cb.energy_fix / 2.0 ** 32 - ref2.energy) <= 1e-9 * abs(ref2.energy)
+
+
+def test_min_image_reciprocal_form_gives_identical_energies(O):
+    """DESIGN.md "min-image": dx - rint(dx * (1/L)) * L changes no pair energy when L >= 4 rcut."""
+    pos, sp, rho = lj_lattice(12, jitter=0.3, seed=8)
+    L = (len(pos) / rho) ** (1 / 3)
+    pos = pos + np.random.default_rng(0).integers(-3, 4, size=pos.shape) * L
+    rc2, inv = 6.25, 1.0 / L
+    rng = np.random.default_rng(1)
+    i = rng.integers(0, len(pos), 200000)
+    j = rng.integers(0, len(pos), 200000)
+    dx = pos[i] - pos[j]
+    a = dx - np.rint(dx / L) * L
+    b = dx - np.rint(dx * inv) * L
+    r2a, r2b = (a * a).sum(1), (b * b).sum(1)
+    inr = (r2a <= rc2) | (r2b <= rc2)
+    assert inr.sum() > 500 and np.array_equal(r2a[inr], r2b[inr])
+
+
+@pytest.mark.timeout(600)
+def test_checkerboard_statistics_match_sequential_chain(O):
+    """The parallel schedule samples the same ensemble as the reference's sequential chain:
+    <e> and the Displacement acceptance (after removing the cell-leaving rejections) agree."""
+    pos, sp, rho = lj_lattice(12, jitter=0.05, seed=1)
+    T = 1.5
+    model = O.single(O.lennard_jones(1.0, 1.0))
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.08}])
+    seq = O.System(pos, sp, rho, T, model, O.LINKEDLIST)
+    cb = O.Checkerboard(pos, sp, seq.box, T, model, seed=3)
+    N = len(pos)
+    burn, prod = 60, 140
+    seq.mc_steps(pool, 3, 0, 0, burn * N)
+    cb.sweeps(pool, 0, burn)
+    es, ec = [], []
+    acc_s = acc_c = 0
+    for t in range(prod):
+        _, a = seq.mc_steps(pool, 3, 0, (burn + t) * N, N)
+        acc_s += a[0]
+        es.append(seq.energy / N)
+        _, a = cb.sweeps(pool, burn + t, 1)
+        acc_c += a[0]
+        ec.append(cb.energy_fix / 2.0 ** 32 / N)
+    es, ec = np.array(es), np.array(ec)
+    # block errors ~ 0.01; means must agree within 4 sigma of the combined error
+    def err(x):
+        b = x[: len(x) // 10 * 10].reshape(10, -1).mean(1)
+        return b.std(ddof=1) / np.sqrt(10)
+    assert abs(es.mean() - ec.mean()) < 4 * np.hypot(err(es), err(ec)) + 5e-3
+    a_s, a_c = acc_s / (prod * N), acc_c / (prod * N)
+    assert abs(a_s - a_c) < 0.06 and a_c < a_s + 0.01
