@@ -1,0 +1,163 @@
+"""-m gpu: BASELINE.json's full sizes, checked through size-independent properties
+(the oracle cannot finish these in seconds), plus the CLI/TOML surface end to end."""
+import os
+
+import numpy as np
+import pytest
+
+from inputs import binary_lattice, lj_lattice
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pool(pmc, sigma=0.05):
+    return [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": sigma}, 1.0)]
+
+
+def test_fullsize_lj_million_properties(gpu):
+    """Config 4: N = 10^6 3-D LJ.  (1) cell membership equals an independent numpy evaluation of the
+    reference's cell function; (2) linked lists are a partition with descending chains; (3) the exact
+    total energy agrees with the reference-order sum to 1e-6 relative (expected ~1e-11);
+    (4) after sweeps the running energy equals a recomputation EXACTLY and is reproducible:
+    a second chain with the same seed ends in bit-identical positions; (5) every particle stays
+    within its displacement budget and acceptance is physical."""
+    pmc = gpu
+    pos, sp, rho = lj_lattice(100, jitter=0.05, seed=42)
+    N = len(pos)
+    a = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+    assert a.neighbour_list.ncells == (39, 39, 39) and float(a.box[0]) == 99.99999999999997
+    cell = a.neighbour_list.box
+    mc = np.floor_divide(pos, cell).astype(np.int64) % 39          # fld + fold_back on in-box positions
+    cs_np = 1 + (mc[:, 0] * 39 + mc[:, 1]) * 39 + mc[:, 2]
+    cs = a.get_cells()
+    assert np.array_equal(cs, cs_np)
+    head, lst = a.get_linked_list()
+    assert np.count_nonzero(lst == -1) == np.count_nonzero(head != -1)
+    nxt = lst[lst != -1]
+    assert len(np.unique(nxt)) == len(nxt)                           # nobody has two predecessors
+    has_next = np.nonzero(lst != -1)[0]
+    assert np.all(lst[has_next] < has_next + 1)                      # chains run in descending id
+    assert np.array_equal(cs[lst[has_next] - 1], cs[has_next])       # and stay inside one cell
+    e_ref = a.energy[0]                                              # reference-order sum (atoms.jl:51-52)
+    e_fix, fix = a.total_energy()
+    assert abs(e_fix - e_ref) <= 1e-6 * abs(e_ref)
+    assert abs(e_fix - e_ref) <= 1e-9 * abs(e_ref)
+    st = pmc.mc_sweep(a, _pool(pmc), nsweeps=5)
+    assert st.attempted[0] == 5 * N and 0.2 < st.accepted[0] / st.attempted[0] < 0.5
+    _, fix2 = a.total_energy()
+    assert fix2 == st.energy_fix
+    b = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+    b.total_energy()
+    st_b = pmc.mc_sweep(b, _pool(pmc), nsweeps=5)
+    pa, pb = a.position, b.position
+    assert np.array_equal(pa, pb) and st_b.energy_fix == st.energy_fix and st_b.accepted[0] == st.accepted[0]
+    assert np.abs(pa - pos).max() < 5 * 7 * 0.05
+    c = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=43)
+    c.total_energy()
+    pmc.mc_sweep(c, _pool(pmc), nsweeps=1)
+    assert not np.array_equal(c.position, pos)
+
+
+def test_c2_lj_32768_against_oracle_one_sweep(gpu):
+    """Config 2 (N = 32768) is small enough for one oracle sweep: bit-exact."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(32, jitter=0.05, seed=42)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+    assert g.neighbour_list.ncells == (12, 12, 12) and float(g.box[0]) == 31.999999999999993
+    o = O.System(pos, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    assert np.array_equal(g.get_cells(), o.cells()) and g.energy[0] == o.energy
+    cb = O.Checkerboard(pos, sp, o.box, 1.0, o.models, seed=42)
+    st = pmc.mc_sweep(g, _pool(pmc), nsweeps=1)
+    att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 0, 1)
+    assert st.accepted[0] == acc[0] and np.array_equal(g.position, cb.positions()) and st.energy_fix == cb.energy_fix
+
+
+def test_c3_kob_andersen_100k_properties(gpu):
+    """Config 3: N = 10^5 KA 80:20 at rho = 1.2 with 90 % Displacement + 10 % DiscreteSwap."""
+    pmc = gpu
+    pos, sp, rho = binary_lattice(100000, frac_b=0.2, rho=1.2, jitter=0.05, seed=42)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.KobAndersen(), seed=42)
+    assert g.neighbour_list.ncells == (17, 17, 17) and float(g.box[0]) == 43.679023236814935
+    pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.05}, 0.9),
+            pmc.Move(pmc.DiscreteSwap([1, 2], g), pmc.DoubleUniform(), [], 0.1)]
+    e_ref = g.energy[0]
+    e_fix, _ = g.total_energy()
+    assert abs(e_fix - e_ref) <= 1e-6 * abs(e_ref)
+    st = pmc.mc_sweep(g, pool, nsweeps=10)
+    assert st.attempted.sum() == 10 * 100000
+    assert abs(st.attempted[1] / st.attempted.sum() - 0.1) < 0.005
+    assert st.accepted[1] > 0 and 0.2 < st.accepted[0] / st.attempted[0] < 0.6
+    _, fix = g.total_energy()
+    assert fix == st.energy_fix
+    spn = g.species
+    assert np.count_nonzero(spn == 2) == 20000 and not np.array_equal(spn, sp)
+    g.build_neighbour_list()
+    assert abs(g.total_energy()[0] - pmc.compute_energy_particles(g).sum() / 2) <= 1e-9 * abs(e_ref)
+
+
+def test_cli_toml_surface_end_to_end(gpu, tmp_path):
+    """`particlesmc params.toml` with the keys of test/params.toml (config_0.xyz, JBB, LinkedList,
+    T = 0.231, seed 10, Displacement sigma = 0.05); success + outputs in the reference's layout."""
+    import shutil
+    from particlesmc_amd import cli
+    shutil.copy(os.path.join(GOLD, "config_0.xyz"), tmp_path / "config_0.xyz")
+    (tmp_path / "params.toml").write_text('''
+[system]
+config = "config_0.xyz"
+temperature = 0.231
+density = 1.192060351952634
+model = "JBB"
+list_type = "LinkedList"
+
+[simulation]
+type = "Metropolis"
+steps = 20
+seed = 10
+parallel = false
+output_path = "data/out"
+
+[[simulation.move]]
+action = "Displacement"
+probability = 1.0
+policy = "SimpleGaussian"
+parameters = {sigma = 0.05}
+
+[[simulation.output]]
+algorithm = "StoreCallbacks"
+callbacks = ["energy"]
+scheduler_params = {linear_interval = 5}
+
+[[simulation.output]]
+algorithm = "StoreAcceptance"
+dependencies = ["Metropolis"]
+scheduler_params = {linear_interval = 10}
+
+[[simulation.output]]
+algorithm = "StoreTrajectories"
+scheduler_params = {linear_interval = 10}
+fmt = "XYZ"
+
+[[simulation.output]]
+algorithm = "StoreLastFrames"
+scheduler_params = {linear_interval = 20}
+fmt = "XYZ"
+''')
+    sim = cli.particlesmc(str(tmp_path / "params.toml"))
+    out = tmp_path / "data" / "out"
+    en = np.loadtxt(out / "chains" / "1" / "energy.dat")
+    assert en.shape == (5, 2) and list(en[:, 0]) == [0, 5, 10, 15, 20]
+    assert abs(en[0, 1] - (-2.676832)) < 1e-6                       # t = 0 is the golden energy
+    assert np.all(np.abs(en[:, 1] + 2.67) < 0.05)
+    acc = np.loadtxt(out / "moves" / "1" / "acceptance.dat")
+    assert acc.shape == (3, 2) and 0.1 < acc[-1, 1] < 0.9
+    last = pmc_load(out / "chains" / "1" / "lastframe.xyz")
+    assert last["N"] == 1290 and np.allclose(last["position"], sim.chains[0].position, atol=5e-7)
+    traj = open(out / "chains" / "1" / "trajectory.xyz").read().split("\n")
+    assert traj[0] == "1290" and traj[1].startswith("step:0 columns:species,position")
+
+
+def pmc_load(path):
+    import particlesmc_amd as pmc
+    return pmc.load_configuration(str(path))
