@@ -140,7 +140,7 @@ def run(sim):
                 if alg == "StoreCallbacks":
                     for cb in a["callbacks"]:
                         f = fh(os.path.join(cdir, f"{cb.__name__}.dat"))
-                        f.write(f"{t} {cb(system)!r}\n")
+                        f.write(f"{t} {float(cb(system))!r}\n")
                 elif alg == "StoreTrajectories":
                     fmt = a["fmt"]
                     f = fh(os.path.join(cdir, "trajectory" + fmt.extension))
@@ -155,7 +155,7 @@ def run(sim):
                 for m in range(npool):
                     f = fh(os.path.join(sim.path, "moves", str(m + 1), "acceptance.dat"))
                     tot_att, tot_acc = att[:, m].sum(), acc[:, m].sum()
-                    f.write(f"{t} {tot_acc / tot_att if tot_att else 0.0!r}\n")
+                    f.write(f"{t} {float(tot_acc) / float(tot_att) if tot_att else 0.0!r}\n")
             elif alg == "PrintTimeSteps" and sim.verbose:
                 print(f"t = {t}", file=sys.stderr)
     for f in files.values():
