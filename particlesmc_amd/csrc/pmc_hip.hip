@@ -836,6 +836,8 @@ static int mc_bin(pmc_system *h, const double shift[3])
     return PMC_OK;
 }
 
+static int cb_cap(const pmc_system *h);
+
 static CbArgs cb_args(pmc_system *h)
 {
     CbArgs a;
@@ -857,12 +859,22 @@ static CbArgs cb_args(pmc_system *h)
     a.m0 = to_dev(h->models[0]);
     a.models = h->d_models;
     a.stats = h->d_stats;
+    a.cap = h->mc_ok ? cb_cap(h) : 128;
     return a;
+}
+
+// LDS staging capacity: the expected 3^d-cell population plus 4 %, rounded up to a multiple
+// of 64 (candidates beyond it are read from HBM/L2 by the kernels' overflow loops)
+static int cb_cap(const pmc_system *h)
+{
+    double mean = (double)h->N / (double)h->ncell_mc * (h->D == 3 ? 27.0 : 9.0);
+    int cap = (int)((mean * 1.04 + 63.0) / 64.0) * 64;
+    return std::min(std::max(cap, 128), PMC_CAP_MAX);
 }
 
 static size_t cb_lds_bytes(const pmc_system *h)
 {
-    size_t b = (PMC_LDS_WAVE_BYTES + 15) & ~(size_t)15;
+    size_t b = (pmc_lds_wave_bytes(cb_cap(h)) + 15) & ~(size_t)15;
     if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
     return b;
 }
@@ -894,7 +906,7 @@ static size_t cb_lds_bytes(const pmc_system *h)
 static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
 {
     if (st[17] & 1ull)
-        return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity (PMC_CAP)");
+        return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity");
     return PMC_OK;
 }
 

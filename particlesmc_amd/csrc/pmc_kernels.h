@@ -10,7 +10,8 @@
 #pragma once
 #include "pmc_device.h"
 
-#define PMC_CAP 640          // neighbourhood candidates staged in LDS per wavefront
+#define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
+#define PMC_CFL 64           // centre-cell particles whose cell coordinates are cached
 #define PMC_REF_MAXC 64      // chain length handled by the fast ordered path
 #define PMC_MAXNN 27
 
@@ -515,6 +516,7 @@ struct CbArgs {
     MovePool pool;
     DevModel m0;
     const DevModel *models;
+    int cap;                   // candidates staged in LDS per wavefront (multiple of 64)
     unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
     double *e_particle;        // optional per-particle energies (id order)
 };
@@ -531,6 +533,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 
 struct WaveNbh {
     double *cx, *cy, *cz;
+    double *cfl;   // [D][PMC_CFL]: floor((x - shift) / w) of the first centre-cell particles
+    int cap;
     unsigned char *csp;
     int *segoff;   // PMC_MAXNN + 1
     int *segsrc;   // PMC_MAXNN
@@ -587,13 +591,19 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
     h.nc = __shfl(seg_cnt, 0, PMC_WAVE);
     h.k0 = __shfl(seg_start, 0, PMC_WAVE);
     __syncthreads();
-    int lim = min(h.ncand, PMC_CAP);
+    int lim = min(h.ncand, h.cap);
     for (int k = lane; k < lim; k += PMC_WAVE) {
         int src = nbh_find(h, NN, k);
         h.cx[k] = a.sx[src];
         h.cy[k] = a.sy[src];
         if (D == 3) h.cz[k] = a.sz[src];
         if (MULTI) h.csp[k] = a.ssp[src];
+    }
+    __syncthreads();
+    if (lane < min(h.nc, PMC_CFL)) {
+        h.cfl[0 * PMC_CFL + lane] = mc_coord<D>(h.cx[lane], a.shift[0], a.w[0]);
+        h.cfl[1 * PMC_CFL + lane] = mc_coord<D>(h.cy[lane], a.shift[1], a.w[1]);
+        if (D == 3) h.cfl[2 * PMC_CFL + lane] = mc_coord<D>(h.cz[lane], a.shift[2], a.w[2]);
     }
     __syncthreads();
 }
@@ -603,7 +613,7 @@ __device__ __forceinline__ void nbh_load(const CbArgs &a, const WaveNbh &h, int 
                                          double &zj, int &sj)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
-    if (k < PMC_CAP) {
+    if (k < h.cap) {
         xj = h.cx[k];
         yj = h.cy[k];
         zj = (D == 3) ? h.cz[k] : 0.0;
@@ -632,6 +642,29 @@ __device__ __forceinline__ double dist2_fast(const CbArgs &a, double xi, double 
     return r2;
 }
 
+// v + (v moved by a DPP lane pattern); 64-bit values move as two 32-bit halves
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+
+// Sum over the 64 lanes of values that add EXACTLY (multiples of 2^-32, see dev_quant), so
+// the association below is free to differ from any other and still give the same bits.
+__device__ __forceinline__ double wave_sum_exact(double v)
+{
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
+    double r0 = readlane_double(v, 0), r1 = readlane_double(v, 16);
+    double r2 = readlane_double(v, 32), r3 = readlane_double(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
 template <int KIND>
 __device__ __forceinline__ double pot_kind(double r2, const DevModel &m)
 {
@@ -646,29 +679,40 @@ __device__ __forceinline__ double nbh_energy(const CbArgs &a, const WaveNbh &h, 
                                              double xi, double yi, double zi, int si, int ex1, int ex2)
 {
     double e = 0.0;
-    for (int k = wave_lane(); k < h.ncand; k += PMC_WAVE) {
+    const int lim = min(h.ncand, h.cap);
+    for (int k = wave_lane(); k < lim; k += PMC_WAVE) {          // staged candidates: LDS
+        const DevModel &m = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
+        double r2 = dist2_fast<D>(a, xi, yi, zi, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0);
+        if (k != ex1 && k != ex2 && !(r2 > m.rcut2)) e += dev_quant(pot_kind<KIND>(r2, m));
+    }
+    for (int k = lim + wave_lane(); k < h.ncand; k += PMC_WAVE) { // overflow beyond the LDS capacity: HBM/L2
         double xj, yj, zj;
         int sj;
         nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
         const DevModel &m = MULTI ? tab[si * a.S + sj] : a.m0;
         double r2 = dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
-        if (k != ex1 && k != ex2 && !(r2 > m.rcut2)) e += dev_quant(pot_kind<KIND>(r2, m));
+        if (!(r2 > m.rcut2)) e += dev_quant(pot_kind<KIND>(r2, m));
     }
-    return wave_sum(e);
+    return wave_sum_exact(e);
 }
 
-#define PMC_LDS_WAVE_BYTES (3 * PMC_CAP * 8 + PMC_CAP + 2 * 32 * 4)
+__host__ __device__ inline size_t pmc_lds_wave_bytes(int cap)
+{
+    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 2 * 32 * 4 + cap;
+}
 
 template <int D, bool MULTI>
 __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned char *smem, WaveNbh &h)
 {
+    h.cap = a.cap;
     h.cx = reinterpret_cast<double *>(smem);
-    h.cy = h.cx + PMC_CAP;
-    h.cz = h.cy + PMC_CAP;
-    h.segoff = reinterpret_cast<int *>(h.cz + PMC_CAP);
+    h.cy = h.cx + h.cap;
+    h.cz = h.cy + h.cap;
+    h.cfl = h.cz + h.cap;
+    h.segoff = reinterpret_cast<int *>(h.cfl + 3 * PMC_CFL);
     h.segsrc = h.segoff + 32;
     h.csp = reinterpret_cast<unsigned char *>(h.segsrc + 32);
-    DevModel *tab = reinterpret_cast<DevModel *>(smem + ((PMC_LDS_WAVE_BYTES + 15) & ~15));
+    DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap) + 15) & ~(size_t)15));
     if (MULTI) {
         for (int k = threadIdx.x; k < a.S * a.S; k += blockDim.x) tab[k] = a.models[k];
         __syncthreads();
@@ -711,7 +755,7 @@ __global__ __launch_bounds__(64) void k_total_energy(CbArgs a)
     h.lin = lin;
     stage_neighbourhood<D, MULTI>(a, cell, h);
     if (h.nc == 0) return;
-    if (h.nc > PMC_CAP) { if (wave_lane() == 0) atomicOr(&a.stats[17], 1ull); return; }
+    if (h.nc > h.cap) { if (wave_lane() == 0) atomicOr(&a.stats[17], 1ull); return; }
     long long tot = 0;
     for (int p = 0; p < h.nc; p++) {
         double xi = h.cx[p], yi = h.cy[p], zi = (D == 3) ? h.cz[p] : 0.0;
@@ -768,11 +812,13 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
     stage_neighbourhood<D, MULTI>(a, cell, h);
     const int nc = h.nc;
     if (nc == 0) return;
-    if (nc > PMC_CAP) { if (lane == 0) atomicOr(&a.stats[17], 1ull); return; }
+    if (nc > h.cap) { if (lane == 0) atomicOr(&a.stats[17], 1ull); return; }
 
     unsigned long long att[8] = {0}, acc[8] = {0};
     long long efix = 0;
     bool dirty = false;
+    const double my_shift = (lane == 0) ? a.shift[0] : ((lane == 1) ? a.shift[1] : a.shift[2]);
+    const double my_w = (lane == 0) ? a.w[0] : ((lane == 1) ? a.w[1] : a.w[2]);
 
     for (int chunk = 0; chunk < nc; chunk += PMC_WAVE) {
         // lanes generate the slots of this chunk in parallel
@@ -808,28 +854,40 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
                 const double xn = xo + readlane_double(g_dx, s);
                 const double yn = yo + readlane_double(g_dy, s);
                 const double zn = (D == 3) ? zo + readlane_double(g_dz, s) : 0.0;
-                bool inside = mc_coord<D>(xn, a.shift[0], a.w[0]) == mc_coord<D>(xo, a.shift[0], a.w[0]) &&
-                              mc_coord<D>(yn, a.shift[1], a.w[1]) == mc_coord<D>(yo, a.shift[1], a.w[1]);
-                if (D == 3)
-                    inside = inside && mc_coord<D>(zn, a.shift[2], a.w[2]) == mc_coord<D>(zo, a.shift[2], a.w[2]);
-                if (inside) {
+                // "stays in its cell": lane a evaluates dimension a; the old coordinate is cached
+                // (an accepted move never changes it)
+                bool bad = false;
+                if (lane < D) {
+                    const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
+                    const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
+                    const double fo = (p < PMC_CFL) ? h.cfl[lane * PMC_CFL + p] : mc_coord<D>(xs_o, my_shift, my_w);
+                    bad = mc_coord<D>(xs_n, my_shift, my_w) != fo;
+                }
+                if (__ballot(bad) == 0ull) {
                     const int si = MULTI ? (int)h.csp[p] : 0;
-                    double e1 = 0.0, e2 = 0.0;
-                    for (int k = lane; k < h.ncand; k += PMC_WAVE) {
+                    double dsum = 0.0;             // sum_j q(u_new) - q(u_old): every term and the sum are exact
+                    const int lim = min(h.ncand, h.cap);
+                    for (int k = lane; k < lim; k += PMC_WAVE) {
+                        const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
+                        const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
+                        const double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
+                        const double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
+                        if (k != p) {
+                            if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
+                            if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                        }
+                    }
+                    for (int k = lim + lane; k < h.ncand; k += PMC_WAVE) {
                         double xj, yj, zj;
                         int sj;
                         nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
                         const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
-                        double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
-                        double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
-                        if (k != p) {
-                            if (!(r2o > mm.rcut2)) e1 += dev_quant(pot_kind<KIND>(r2o, mm));
-                            if (!(r2n > mm.rcut2)) e2 += dev_quant(pot_kind<KIND>(r2n, mm));
-                        }
+                        const double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
+                        const double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
+                        if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
+                        if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
                     }
-                    e1 = wave_sum(e1);
-                    e2 = wave_sum(e2);
-                    const double de = e2 - e1;
+                    const double de = wave_sum_exact(dsum);
                     ok = lnu < -de / a.temperature;
                     if (ok) {
                         __syncthreads();
@@ -938,7 +996,7 @@ __device__ double stream_energy(const CbArgs &a, double xi, double yi, double zi
             if (!(r2 > m.rcut2)) e += dev_quant(dev_potential_dyn(r2, m));
         }
     }
-    return wave_sum(e);
+    return wave_sum_exact(e);
 }
 
 template <int D>
