@@ -41,6 +41,8 @@ struct pmc_system {
     double *d_energy = nullptr;
     // binning scratch
     int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
+    int *d_arrival = nullptr, *d_tile_sum = nullptr, *d_order = nullptr, *d_hist = nullptr;
+    bool use_order = true;
     int *d_start_ref = nullptr, *d_ids_ref = nullptr;
     // throughput grid
     bool mc_ok = false;
@@ -376,6 +378,11 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     CR(hipMalloc(&h->d_count, ncmax * sizeof(int)));
     CR(hipMalloc(&h->d_fill, ncmax * sizeof(int)));
     CR(hipMalloc(&h->d_tmp_ids, N * sizeof(int)));
+    CR(hipMalloc(&h->d_arrival, N * sizeof(int)));
+    CR(hipMalloc(&h->d_tile_sum, (ncmax / PMC_SCAN_TILE + 2) * sizeof(int)));
+    CR(hipMalloc(&h->d_order, ncmax * sizeof(int)));
+    CR(hipMalloc(&h->d_hist, (8 * 256 + 1) * sizeof(int)));
+    if (const char *e = getenv("PMC_NO_ORDER")) h->use_order = !(e[0] == '1');
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
     CR(hipMalloc(&h->d_ids_ref, N * sizeof(int)));
     if (h->mc_ok) {
@@ -400,7 +407,7 @@ extern "C" int pmc_destroy(pmc_system *h)
     (void)hipSetDevice(h->p.device);
     void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
-                    h->d_fill, h->d_tmp_ids, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
+                    h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
                     h->d_sz, h->d_ssp, h->d_stats, h->d_result};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
@@ -515,6 +522,18 @@ extern "C" int pmc_get_counters(pmc_system *h, uint64_t *step, uint64_t *sweep)
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
+static int scan_counts(pmc_system *h, int ncell, int *d_start)
+{
+    const int ntiles = nblk(ncell, PMC_SCAN_TILE);
+    int *d_total = h->d_hist + 8 * 256;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, h->stream, h->d_count, ncell, h->d_tile_sum);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, h->stream, h->d_tile_sum, ntiles, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(1024), 0, h->stream, h->d_count, ncell, h->d_tile_sum, d_total,
+                       d_start);
+    HIPCHK(h, hipGetLastError());
+    return PMC_OK;
+}
+
 // cell_of (already filled) -> start / ids (ascending ids inside each cell)
 static int bin_by_cell(pmc_system *h, int ncell, int *d_start, int *d_ids)
 {
@@ -522,7 +541,7 @@ static int bin_by_cell(pmc_system *h, int ncell, int *d_start, int *d_ids)
     HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)ncell + 1) * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_fill, 0, ((size_t)ncell + 1) * sizeof(int), h->stream));
     hipLaunchKernelGGL(k_count, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, h->d_count);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, h->stream, h->d_count, ncell, d_start);
+    if (int rc = scan_counts(h, ncell, d_start)) return rc;
     hipLaunchKernelGGL(k_scatter, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, d_start, h->d_fill,
                        h->d_tmp_ids);
     hipLaunchKernelGGL(k_rank, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, d_start, h->d_tmp_ids,
@@ -817,22 +836,36 @@ extern "C" int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de)
 static int mc_bin(pmc_system *h, const double shift[3])
 {
     const int N = h->N;
+    const int nb = nblk(N, 256);
     for (int q = 0; q < 3; q++) h->grid.shift[q] = q < h->D ? shift[q] : 0.0;
-    if (h->D == 3) {
-        hipLaunchKernelGGL(k_mc_cell_index<3>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of);
-    } else {
-        hipLaunchKernelGGL(k_mc_cell_index<2>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of);
-    }
-    int rc = bin_by_cell(h, h->ncell_mc, h->d_start, h->d_ids);
-    if (rc) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)h->ncell_mc + 1) * sizeof(int), h->stream));
+    if (h->D == 3) hipLaunchKernelGGL(k_mc_bin_a<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival);
+    else hipLaunchKernelGGL(k_mc_bin_a<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival);
+    if (int rc = scan_counts(h, h->ncell_mc, h->d_start)) return rc;
+    hipLaunchKernelGGL(k_mc_bin_b, dim3(nb), dim3(256), 0, h->stream, h->d_cell_of, h->d_arrival, N, h->d_start, h->d_tmp_ids);
     if (h->D == 3)
-        hipLaunchKernelGGL(k_mc_gather<3>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, h->d_species, N, h->d_ids,
-                           h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
+        hipLaunchKernelGGL(k_mc_bin_c<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->d_species, h->d_cell_of, N, h->d_start,
+                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
     else
-        hipLaunchKernelGGL(k_mc_gather<2>, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_pos, h->d_species, N, h->d_ids,
-                           h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
+        hipLaunchKernelGGL(k_mc_bin_c<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->d_species, h->d_cell_of, N, h->d_start,
+                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
     HIPCHK(h, hipGetLastError());
     h->mc_binned = true;
+    return PMC_OK;
+}
+
+// per colour: cells in descending population (longest processing time first)
+static int mc_order(pmc_system *h, int nactive)
+{
+    const int ncol = 1 << h->D;
+    const int nb = nblk(h->ncell_mc, 256);
+    HIPCHK(h, hipMemsetAsync(h->d_hist, 0, 8 * 256 * sizeof(int), h->stream));
+    if (h->D == 3) hipLaunchKernelGGL(k_order_hist<3>, dim3(nb), dim3(256), 0, h->stream, h->d_start, h->ncell_mc, h->grid, h->d_hist);
+    else hipLaunchKernelGGL(k_order_hist<2>, dim3(nb), dim3(256), 0, h->stream, h->d_start, h->ncell_mc, h->grid, h->d_hist);
+    hipLaunchKernelGGL(k_order_scan, dim3(ncol), dim3(64), 0, h->stream, h->d_hist, ncol);
+    if (h->D == 3) hipLaunchKernelGGL(k_order_fill<3>, dim3(nb), dim3(256), 0, h->stream, h->d_start, h->ncell_mc, h->grid, h->d_hist, nactive, h->d_order);
+    else hipLaunchKernelGGL(k_order_fill<2>, dim3(nb), dim3(256), 0, h->stream, h->d_start, h->ncell_mc, h->grid, h->d_hist, nactive, h->d_order);
+    HIPCHK(h, hipGetLastError());
     return PMC_OK;
 }
 
@@ -1058,7 +1091,12 @@ static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, in
         for (int q = 0; q < h->D; q++) shift[q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
         rc = mc_bin(h, shift);
         if (rc) return rc;
+        if (h->use_order) {
+            rc = mc_order(h, nactive);
+            if (rc) return rc;
+        }
         CbArgs a = cb_args(h);
+        a.order = h->use_order ? h->d_order : nullptr;
         a.s_lo = s_lo; a.s_hi = s_hi;
         a.pool = mp;
         a.all_cells = 0;

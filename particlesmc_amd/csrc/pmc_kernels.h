@@ -67,6 +67,174 @@ __global__ void k_mc_cell_index(const double *__restrict__ pos, int N, GridGeom 
     cell_of[i] = (int)lin;
 }
 
+// throughput-grid binning, pass A: cell index + arrival ticket inside the cell
+template <int D>
+__global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of,
+                           int *__restrict__ count, int *__restrict__ arrival)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    long long lin = 0;
+#pragma unroll
+    for (int a = 0; a < D; a++) {
+        long long q = (long long)mc_coord<D>(pos[(size_t)i * D + a], g.shift[a], g.w[a]);
+        long long r = q % g.n[a];
+        if (r < 0) r += g.n[a];
+        lin = lin * g.n[a] + r;
+    }
+    cell_of[i] = (int)lin;
+    arrival[i] = atomicAdd(&count[(int)lin], 1);
+}
+
+// pass B: place ids by ticket (order inside a cell still depends on atomic arrival)
+__global__ void k_mc_bin_b(const int *__restrict__ cell_of, const int *__restrict__ arrival, int N,
+                           const int *__restrict__ start, int *__restrict__ tmp_ids)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) tmp_ids[start[cell_of[i]] + arrival[i]] = i;
+}
+
+// pass C: rank by id inside the cell (deterministic order) and gather the cell-sorted SoA copy
+template <int D>
+__global__ void k_mc_bin_c(const double *__restrict__ pos, const int *__restrict__ species,
+                           const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+                           const int *__restrict__ tmp_ids, int *__restrict__ ids, double *__restrict__ sx,
+                           double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int c = cell_of[i];
+    int lo = start[c], hi = start[c + 1];
+    int r = 0;
+    for (int k = lo; k < hi; k++) r += (tmp_ids[k] < i);
+    int dst = lo + r;
+    ids[dst] = i;
+    sx[dst] = pos[(size_t)i * D + 0];
+    sy[dst] = pos[(size_t)i * D + 1];
+    if (D == 3) sz[dst] = pos[(size_t)i * D + 2];
+    ssp[dst] = (unsigned char)species[i];
+}
+
+// three-launch exclusive scan: tile sums, scan of the tile sums, tile scan + base
+#define PMC_SCAN_TILE 1024
+__device__ __forceinline__ int block_inclusive_scan_1024(int v, int *wsum)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        int y = __shfl_up(x, s, 64);
+        if (lane >= s) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        int w = (lane < 16) ? wsum[lane] : 0;
+#pragma unroll
+        for (int s = 1; s < 16; s <<= 1) {
+            int y = __shfl_up(w, s, 64);
+            if (lane >= s) w += y;
+        }
+        if (lane < 16) wsum[lane] = w;
+    }
+    __syncthreads();
+    int base = (wave == 0) ? 0 : wsum[wave - 1];
+    __syncthreads();
+    return x + base;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int *__restrict__ count, int n, int *__restrict__ tile_sum)
+{
+    __shared__ int wsum[16];
+    int i = blockIdx.x * PMC_SCAN_TILE + threadIdx.x;
+    int v = (i < n) ? count[i] : 0;
+    int incl = block_inclusive_scan_1024(v, wsum);
+    if (threadIdx.x == 1023) tile_sum[blockIdx.x] = incl;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tops(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total)
+{
+    __shared__ int wsum[16];
+    int carry = 0;
+    for (int base = 0; base < ntiles; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = (i < ntiles) ? tile_sum[i] : 0;
+        int incl = block_inclusive_scan_1024(v, wsum);
+        if (i < ntiles) tile_sum[i] = carry + incl - v;   // exclusive
+        __shared__ int last;
+        if (threadIdx.x == 1023) last = incl;
+        __syncthreads();
+        carry += last;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_apply(const int *__restrict__ count, int n, const int *__restrict__ tile_sum,
+                                                     const int *__restrict__ total, int *__restrict__ start)
+{
+    __shared__ int wsum[16];
+    int i = blockIdx.x * PMC_SCAN_TILE + threadIdx.x;
+    int v = (i < n) ? count[i] : 0;
+    int incl = block_inclusive_scan_1024(v, wsum);
+    if (i < n) start[i] = tile_sum[blockIdx.x] + incl - v;
+    if (i == n - 1) start[n] = *total;
+}
+
+// longest-first ordering of the cells of each colour (counting sort by population, descending):
+// the tail of a colour pass then consists of its cheapest cells.
+template <int D>
+__device__ __forceinline__ int cell_colour(int lin, const int n[3])
+{
+    int r = lin, col = 0;
+#pragma unroll
+    for (int q = D - 1; q >= 0; q--) {
+        col |= ((r % n[q]) & 1) << q;
+        r /= n[q];
+    }
+    return col;
+}
+
+template <int D>
+__global__ void k_order_hist(const int *__restrict__ start, int ncell, GridGeom g, int *__restrict__ hist)
+{
+    int lin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= ncell) return;
+    int cnt = min(start[lin + 1] - start[lin], 255);
+    atomicAdd(&hist[cell_colour<D>(lin, g.n) * 256 + (255 - cnt)], 1);
+}
+
+__global__ void k_order_scan(int *__restrict__ hist, int ncol)   // one wave per colour, 256 buckets
+{
+    int col = blockIdx.x;
+    if (col >= ncol) return;
+    int lane = threadIdx.x;
+    int carry = 0;
+    for (int b0 = 0; b0 < 256; b0 += 64) {
+        int v = hist[col * 256 + b0 + lane];
+        int x = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            int y = __shfl_up(x, s, 64);
+            if (lane >= s) x += y;
+        }
+        hist[col * 256 + b0 + lane] = carry + x - v;
+        carry += __shfl(x, 63, 64);
+    }
+}
+
+template <int D>
+__global__ void k_order_fill(const int *__restrict__ start, int ncell, GridGeom g, int *__restrict__ hist,
+                             int nactive, int *__restrict__ order)
+{
+    int lin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= ncell) return;
+    int cnt = min(start[lin + 1] - start[lin], 255);
+    int col = cell_colour<D>(lin, g.n);
+    int slot = atomicAdd(&hist[col * 256 + (255 - cnt)], 1);
+    order[col * nactive + slot] = lin;
+}
+
 __global__ void k_count(const int *__restrict__ cell_of, int N, int *__restrict__ count)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,6 +685,7 @@ struct CbArgs {
     DevModel m0;
     const DevModel *models;
     int cap;                   // candidates staged in LDS per wavefront (multiple of 64)
+    const int *order;          // per colour: cells sorted by population, descending (may be null)
     unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
     double *e_particle;        // optional per-particle energies (id order)
 };
@@ -724,6 +893,13 @@ template <int D>
 __device__ __forceinline__ bool decode_cell(const CbArgs &a, int aidx, int cell[3], int &lin)
 {
     int r = aidx;
+    if (!a.all_cells && a.order) {
+        lin = a.order[a.colour * a.nactive + aidx];
+        r = lin;
+#pragma unroll
+        for (int q = D - 1; q >= 0; q--) { cell[q] = r % a.n[q]; r /= a.n[q]; }
+        return true;
+    }
     if (a.all_cells) {
 #pragma unroll
         for (int q = D - 1; q >= 0; q--) { cell[q] = r % a.n[q]; r /= a.n[q]; }
@@ -804,7 +980,7 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
     WaveNbh h;
     const DevModel *tab = setup_lds<D, MULTI>(a, smem, h);
     const int lane = wave_lane();
-    int aidx = xcd_remap(blockIdx.x, gridDim.x);
+    int aidx = a.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     if (aidx >= a.nactive) return;
     int cell[3] = {0, 0, 0}, lin;
     decode_cell<D>(a, aidx, cell, lin);
