@@ -711,6 +711,7 @@ struct WaveNbh {
     int nc;        // centre-cell population (candidates [0, nc))
     int k0;        // CSR offset of the centre cell
     int lin;
+    bool nowrap;   // every staged candidate is in the same periodic image as the centre cell
 };
 
 __device__ __forceinline__ int nbh_find(const WaveNbh &h, int NN, int k)
@@ -769,6 +770,22 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
         if (MULTI) h.csp[k] = a.ssp[src];
     }
     __syncthreads();
+    // No-wrap test: if rint((x_ref - x_j) / L) == 0 in every dimension for every candidate, it is 0
+    // for every in-range pair of this cell visit (all centre particles then share x_ref's image and
+    // stay inside the cell), so dx - rint(dx/L)*L == dx bit for bit and the image search can be skipped.
+    {
+        bool wrapped = (h.ncand > h.cap) || (h.nc == 0);
+        if (!wrapped) {
+            const double xr = h.cx[0], yr = h.cy[0], zr = (D == 3) ? h.cz[0] : 0.0;
+            for (int k = lane; k < lim; k += PMC_WAVE) {
+                bool w0 = rint((xr - h.cx[k]) * a.invL[0]) != 0.0;
+                bool w1 = rint((yr - h.cy[k]) * a.invL[1]) != 0.0;
+                bool w2 = (D == 3) ? (rint((zr - h.cz[k]) * a.invL[2]) != 0.0) : false;
+                wrapped = wrapped || w0 || w1 || w2;
+            }
+        }
+        h.nowrap = (__ballot(wrapped) == 0ull);
+    }
     if (lane < min(h.nc, PMC_CFL)) {
         h.cfl[0 * PMC_CFL + lane] = mc_coord<D>(h.cx[lane], a.shift[0], a.w[0]);
         h.cfl[1 * PMC_CFL + lane] = mc_coord<D>(h.cy[lane], a.shift[1], a.w[1]);
@@ -794,6 +811,20 @@ __device__ __forceinline__ void nbh_load(const CbArgs &a, const WaveNbh &h, int 
         zj = (D == 3) ? a.sz[src] : 0.0;
         sj = MULTI ? (int)a.ssp[src] : 0;
     }
+}
+
+// squared distance when the minimum image is known to be the identity (WaveNbh::nowrap)
+template <int D>
+__device__ __forceinline__ double dist2_nowrap(double xi, double yi, double zi, double xj, double yj, double zj)
+{
+    double vx = xi - xj, vy = yi - yj;
+    double r2 = vx * vx;
+    r2 = r2 + vy * vy;
+    if (D == 3) {
+        double vz = zi - zj;
+        r2 = r2 + vz * vz;
+    }
+    return r2;
 }
 
 template <int D>
@@ -1043,14 +1074,27 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
                     const int si = MULTI ? (int)h.csp[p] : 0;
                     double dsum = 0.0;             // sum_j q(u_new) - q(u_old): every term and the sum are exact
                     const int lim = min(h.ncand, h.cap);
-                    for (int k = lane; k < lim; k += PMC_WAVE) {
-                        const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
-                        const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
-                        const double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
-                        const double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
-                        if (k != p) {
-                            if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
-                            if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                    if (h.nowrap) {
+                        for (int k = lane; k < lim; k += PMC_WAVE) {
+                            const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
+                            const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
+                            const double r2o = dist2_nowrap<D>(xo, yo, zo, xj, yj, zj);
+                            const double r2n = dist2_nowrap<D>(xn, yn, zn, xj, yj, zj);
+                            if (k != p) {
+                                if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
+                                if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                            }
+                        }
+                    } else {
+                        for (int k = lane; k < lim; k += PMC_WAVE) {
+                            const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
+                            const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
+                            const double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
+                            const double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
+                            if (k != p) {
+                                if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
+                                if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                            }
                         }
                     }
                     for (int k = lim + lane; k < h.ncand; k += PMC_WAVE) {
