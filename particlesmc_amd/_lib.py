@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libpmc_hip.so")
+SO_PATH = os.environ.get("PMC_LIB") or os.path.join(_HERE, "csrc", "libpmc_hip.so")   # PMC_LIB: debug builds
 
 PMC_OK, PMC_ERR_BADARG, PMC_ERR_HIP, PMC_ERR_NONFINITE, PMC_ERR_UNSUPPORTED, PMC_ERR_STATE = 0, -1, -2, -3, -4, -5
 MODEL_LJ, MODEL_SOFT_INT, MODEL_SOFT_FLOAT, MODEL_SMOOTH_LJ = 0, 1, 2, 3
