@@ -1055,7 +1055,7 @@ void orc_cb_sweeps(orc_cb *c, const orc_move *pool, int32_t npool, uint64_t swee
                         double e1 = cb_energy_excl(c, xo, c->species[i], cand, ncand, i, -1);
                         double e2 = cb_energy_excl(c, xn, c->species[i], cand, ncand, i, -1);
                         double de = e2 - e1;
-                        if (lnu < -de / c->temperature) {
+                        if (c->temperature * lnu < -de) {   /* accept iff T ln u < -dE (DESIGN.md "schedule") */
                             for (int a = 0; a < d; a++) xo[a] = xn[a];
                             c->e_fix += (int64_t)(de * CB_FIX);
                             stats->accepted[m]++;
@@ -1082,7 +1082,7 @@ void orc_cb_sweeps(orc_cb *c, const orc_move *pool, int32_t npool, uint64_t swee
                         double e2 = cb_energy_excl(c, xi, sb, cand, ncand, i, j) +
                                     cb_energy_excl(c, xj, sa, cand, ncand, i, j);
                         double de = e2 - e1;
-                        if (lnu < -de / c->temperature) {
+                        if (c->temperature * lnu < -de) {   /* accept iff T ln u < -dE (DESIGN.md "schedule") */
                             c->species[i] = sb;
                             c->species[j] = sa;
                             c->e_fix += (int64_t)(de * CB_FIX);

@@ -9,6 +9,7 @@
 //    checkerboard colour passes.
 #pragma once
 #include "pmc_device.h"
+#include <type_traits>
 
 #define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
 #define PMC_CFL 64           // centre-cell particles whose cell coordinates are cached
@@ -705,18 +706,22 @@ struct WaveNbh {
     double *cfl;   // [D][PMC_CFL]: floor((x - shift) / w) of the first centre-cell particles
     int cap;
     unsigned char *csp;
-    int *segoff;   // PMC_MAXNN + 1
-    int *segsrc;   // PMC_MAXNN
+    int *segoff;   // nseg + 1 prefix offsets of the staged segments
+    int *segsrc;   // CSR offset of every segment
+    int nseg;
     int ncand;
-    int nc;        // centre-cell population (candidates [0, nc))
+    int nc;        // centre-cell population: candidates [ctr, ctr + nc)
+    int ctr;       // LDS slot of the first centre-cell particle
     int k0;        // CSR offset of the centre cell
     int lin;
     bool nowrap;   // every staged candidate is in the same periodic image as the centre cell
+    bool bounds;   // lo/hi below are valid: "stays in the cell" is  lo_a <= x_a < hi_a
+    double lo[3], hi[3];
 };
 
-__device__ __forceinline__ int nbh_find(const WaveNbh &h, int NN, int k)
+__device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
 {
-    int lo = 0, hi = NN;
+    int lo = 0, hi = h.nseg;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (h.segoff[mid] <= k) lo = mid; else hi = mid;
@@ -724,27 +729,58 @@ __device__ __forceinline__ int nbh_find(const WaveNbh &h, int NN, int k)
     return h.segsrc[lo] + (k - h.segoff[lo]);
 }
 
-// Stage the 3^D neighbour cells of cell `cell` (centre first) into LDS.
+// Stage the 3^D neighbour cells of `cell` into LDS.
+//  * Fast path (the cell's last-dimension neighbours do not wrap): the 3 cells of one column are
+//    contiguous in the cell-sorted arrays, so the neighbourhood is 3^(D-1) runs; every run is
+//    loaded with one coalesced load per array and all loads are in flight together.
+//  * Generic path: 3^D segments, centre first, located per candidate by binary search.
 template <int D, bool MULTI>
 __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
+    constexpr int NR = (D == 3) ? 9 : 3;
+    constexpr int LD = D - 1;
     const int lane = wave_lane();
+    const bool runs_ok = (cell[LD] >= 1) && (cell[LD] + 1 < a.n[LD]);
     int seg_start = 0, seg_cnt = 0;
-    if (lane < NN) {
-        // lane 0 <-> centre (offset index (NN-1)/2), that lane takes offset 0
-        int o = (lane == 0) ? (NN - 1) / 2 : ((lane == (NN - 1) / 2) ? 0 : lane);
-        int lin2 = 0, r = o;
+    int lin_c = 0;
 #pragma unroll
-        for (int q = 0; q < D; q++) {
-            int cq = cell[q] + (r % 3) - 1;
-            r /= 3;
-            if (cq < 0) cq += a.n[q];
-            if (cq >= a.n[q]) cq -= a.n[q];
-            lin2 = lin2 * a.n[q] + cq;
+    for (int q = 0; q < D; q++) lin_c = lin_c * a.n[q] + cell[q];
+    h.k0 = a.start[lin_c];
+    h.nc = a.start[lin_c + 1] - h.k0;
+    if (runs_ok) {
+        h.nseg = NR;
+        if (lane < NR) {
+            int lin2 = 0, r = lane;
+#pragma unroll
+            for (int q = 0; q < LD; q++) {
+                int cq = cell[q] + (r % 3) - 1;
+                r /= 3;
+                if (cq < 0) cq += a.n[q];
+                if (cq >= a.n[q]) cq -= a.n[q];
+                lin2 = lin2 * a.n[q] + cq;
+            }
+            lin2 = lin2 * a.n[LD] + (cell[LD] - 1);
+            seg_start = a.start[lin2];
+            seg_cnt = a.start[lin2 + 3] - seg_start;
         }
-        seg_start = a.start[lin2];
-        seg_cnt = a.start[lin2 + 1] - seg_start;
+    } else {
+        h.nseg = NN;
+        if (lane < NN) {
+            // lane 0 <-> centre (offset index (NN-1)/2), that lane takes offset 0
+            int o = (lane == 0) ? (NN - 1) / 2 : ((lane == (NN - 1) / 2) ? 0 : lane);
+            int lin2 = 0, r = o;
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                int cq = cell[q] + (r % 3) - 1;
+                r /= 3;
+                if (cq < 0) cq += a.n[q];
+                if (cq >= a.n[q]) cq -= a.n[q];
+                lin2 = lin2 * a.n[q] + cq;
+            }
+            seg_start = a.start[lin2];
+            seg_cnt = a.start[lin2 + 1] - seg_start;
+        }
     }
     int incl = seg_cnt;
 #pragma unroll
@@ -752,31 +788,75 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
         int v = __shfl_up(incl, s, PMC_WAVE);
         if (lane >= s) incl += v;
     }
-    if (lane < NN) {
-        h.segoff[lane] = incl - seg_cnt;
+    const int seg_off = incl - seg_cnt;
+    if (lane < h.nseg) {
+        h.segoff[lane] = seg_off;
         h.segsrc[lane] = seg_start;
     }
-    h.ncand = __shfl(incl, NN - 1, PMC_WAVE);
-    if (lane == 0) h.segoff[NN] = h.ncand;
-    h.nc = __shfl(seg_cnt, 0, PMC_WAVE);
-    h.k0 = __shfl(seg_start, 0, PMC_WAVE);
-    __syncthreads();
-    int lim = min(h.ncand, h.cap);
-    for (int k = lane; k < lim; k += PMC_WAVE) {
-        int src = nbh_find(h, NN, k);
-        h.cx[k] = a.sx[src];
-        h.cy[k] = a.sy[src];
-        if (D == 3) h.cz[k] = a.sz[src];
-        if (MULTI) h.csp[k] = a.ssp[src];
+    h.ncand = __shfl(incl, h.nseg - 1, PMC_WAVE);
+    if (lane == 0) h.segoff[h.nseg] = h.ncand;
+    const int lim = min(h.ncand, h.cap);
+    if (runs_ok) {
+        // centre cell sits inside the middle run
+        h.ctr = __shfl(seg_off, (NR - 1) / 2, PMC_WAVE) + (h.k0 - __shfl(seg_start, (NR - 1) / 2, PMC_WAVE));
+        double tx[NR], ty[NR], tz[NR];
+        unsigned char ts[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int s0 = __builtin_amdgcn_readlane(seg_start, r), c0 = __builtin_amdgcn_readlane(seg_cnt, r);
+            tx[r] = ty[r] = tz[r] = 0.0;
+            ts[r] = 0;
+            if (lane < c0) {
+                tx[r] = a.sx[s0 + lane];
+                ty[r] = a.sy[s0 + lane];
+                if (D == 3) tz[r] = a.sz[s0 + lane];
+                if (MULTI) ts[r] = a.ssp[s0 + lane];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int c0 = __builtin_amdgcn_readlane(seg_cnt, r), o0 = __builtin_amdgcn_readlane(seg_off, r);
+            if (lane < c0 && o0 + lane < lim) {
+                h.cx[o0 + lane] = tx[r];
+                h.cy[o0 + lane] = ty[r];
+                if (D == 3) h.cz[o0 + lane] = tz[r];
+                if (MULTI) h.csp[o0 + lane] = ts[r];
+            }
+        }
+        // runs longer than one wavefront (rare)
+        for (int r = 0; r < NR; r++) {
+            const int s0 = __builtin_amdgcn_readlane(seg_start, r), c0 = __builtin_amdgcn_readlane(seg_cnt, r);
+            const int o0 = __builtin_amdgcn_readlane(seg_off, r);
+            for (int l = PMC_WAVE + lane; l < c0; l += PMC_WAVE) {
+                if (o0 + l < lim) {
+                    h.cx[o0 + l] = a.sx[s0 + l];
+                    h.cy[o0 + l] = a.sy[s0 + l];
+                    if (D == 3) h.cz[o0 + l] = a.sz[s0 + l];
+                    if (MULTI) h.csp[o0 + l] = a.ssp[s0 + l];
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        h.ctr = 0;
+        __syncthreads();
+        for (int k = lane; k < lim; k += PMC_WAVE) {
+            int src = nbh_find(h, k);
+            h.cx[k] = a.sx[src];
+            h.cy[k] = a.sy[src];
+            if (D == 3) h.cz[k] = a.sz[src];
+            if (MULTI) h.csp[k] = a.ssp[src];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // No-wrap test: if rint((x_ref - x_j) / L) == 0 in every dimension for every candidate, it is 0
-    // for every in-range pair of this cell visit (all centre particles then share x_ref's image and
-    // stay inside the cell), so dx - rint(dx/L)*L == dx bit for bit and the image search can be skipped.
+    // No-wrap test: if rint((x_ref - x_j) / L) == 0 in every dimension for every candidate (x_ref = a
+    // centre particle), all candidates lie in the unfolded 3-cell span around the centre cell, every
+    // centre particle lies in one unfolded cell, and |x_p - x_j| < 2 w <= L/2 for every pair: the
+    // minimum image is the identity, dx - rint(dx/L)*L == dx bit for bit.
     {
-        bool wrapped = (h.ncand > h.cap) || (h.nc == 0);
+        bool wrapped = (h.ncand > h.cap) || (h.nc == 0) || (h.ctr + h.nc > h.cap);
         if (!wrapped) {
-            const double xr = h.cx[0], yr = h.cy[0], zr = (D == 3) ? h.cz[0] : 0.0;
+            const double xr = h.cx[h.ctr], yr = h.cy[h.ctr], zr = (D == 3) ? h.cz[h.ctr] : 0.0;
             for (int k = lane; k < lim; k += PMC_WAVE) {
                 bool w0 = rint((xr - h.cx[k]) * a.invL[0]) != 0.0;
                 bool w1 = rint((yr - h.cy[k]) * a.invL[1]) != 0.0;
@@ -786,26 +866,60 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
         }
         h.nowrap = (__ballot(wrapped) == 0ull);
     }
-    if (lane < min(h.nc, PMC_CFL)) {
-        h.cfl[0 * PMC_CFL + lane] = mc_coord<D>(h.cx[lane], a.shift[0], a.w[0]);
-        h.cfl[1 * PMC_CFL + lane] = mc_coord<D>(h.cy[lane], a.shift[1], a.w[1]);
-        if (D == 3) h.cfl[2 * PMC_CFL + lane] = mc_coord<D>(h.cz[lane], a.shift[2], a.w[2]);
+    if (lane < min(h.nc, PMC_CFL) && h.ctr + lane < h.cap) {
+        h.cfl[0 * PMC_CFL + lane] = mc_coord<D>(h.cx[h.ctr + lane], a.shift[0], a.w[0]);
+        h.cfl[1 * PMC_CFL + lane] = mc_coord<D>(h.cy[h.ctr + lane], a.shift[1], a.w[1]);
+        if (D == 3) h.cfl[2 * PMC_CFL + lane] = mc_coord<D>(h.cz[h.ctr + lane], a.shift[2], a.w[2]);
     }
     __syncthreads();
+}
+
+// Exact cell boundaries: g(x) = floor((x - shift) / w) is monotone, so {x : g(x) == f} is an
+// interval [lo, hi) of doubles.  lanes 0..D-1 search lo (target f), lanes 3..3+D-1 search hi
+// (target f + 1) by stepping single ulps from shift + f w; a final check guards the result.
+// Valid only when all centre particles share one unfolded cell (WaveNbh::nowrap).
+template <int D>
+__device__ void cell_bounds(const CbArgs &a, WaveNbh &h)
+{
+    const int lane = wave_lane();
+    h.bounds = false;
+    if (!h.nowrap) return;
+    const int q = (lane < 3) ? lane : lane - 3;
+    bool ok = true;
+    double x = 0.0;
+    if (lane < 6 && q < D) {
+        const double s = (q == 0) ? a.shift[0] : ((q == 1) ? a.shift[1] : a.shift[2]);
+        const double w = (q == 0) ? a.w[0] : ((q == 1) ? a.w[1] : a.w[2]);
+        const double f = h.cfl[q * PMC_CFL] + ((lane >= 3) ? 1.0 : 0.0);
+        x = s + f * w;
+        for (int it = 0; it < 8; it++) {            // walk down while still inside [f, ...)
+            double xd = nextafter(x, -INFINITY);
+            if (floor((xd - s) / w) >= f) x = xd; else break;
+        }
+        for (int it = 0; it < 8; it++) {            // walk up until inside
+            if (floor((x - s) / w) < f) x = nextafter(x, INFINITY); else break;
+        }
+        ok = (floor((x - s) / w) >= f) && (floor((nextafter(x, -INFINITY) - s) / w) < f);
+    }
+    h.bounds = (__ballot(!ok) == 0ull);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        h.lo[d] = readlane_double(x, d);
+        h.hi[d] = readlane_double(x, 3 + d);
+    }
 }
 
 template <int D, bool MULTI>
 __device__ __forceinline__ void nbh_load(const CbArgs &a, const WaveNbh &h, int k, double &xj, double &yj,
                                          double &zj, int &sj)
 {
-    constexpr int NN = (D == 3) ? 27 : 9;
     if (k < h.cap) {
         xj = h.cx[k];
         yj = h.cy[k];
         zj = (D == 3) ? h.cz[k] : 0.0;
         sj = MULTI ? (int)h.csp[k] : 0;
     } else {
-        int src = nbh_find(h, NN, k);
+        int src = nbh_find(h, k);
         xj = a.sx[src];
         yj = a.sy[src];
         zj = (D == 3) ? a.sz[src] : 0.0;
@@ -872,8 +986,8 @@ __device__ __forceinline__ double pot_kind(double r2, const DevModel &m)
     return dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m);
 }
 
-// exact per-particle energy of a particle at (xi,yi,zi) with species si against
-// the staged neighbourhood, skipping candidates ex1 / ex2; result in every lane
+// exact per-particle energy of a particle at (xi,yi,zi) with species si against the staged
+// neighbourhood, skipping the LDS slots ex1 / ex2; result in every lane
 template <int D, int KIND, bool MULTI>
 __device__ __forceinline__ double nbh_energy(const CbArgs &a, const WaveNbh &h, const DevModel *tab,
                                              double xi, double yi, double zi, int si, int ex1, int ex2)
@@ -962,24 +1076,25 @@ __global__ __launch_bounds__(64) void k_total_energy(CbArgs a)
     h.lin = lin;
     stage_neighbourhood<D, MULTI>(a, cell, h);
     if (h.nc == 0) return;
-    if (h.nc > h.cap) { if (wave_lane() == 0) atomicOr(&a.stats[17], 1ull); return; }
+    if (h.ctr + h.nc > h.cap) { if (wave_lane() == 0) atomicOr(&a.stats[17], 1ull); return; }
     long long tot = 0;
     for (int p = 0; p < h.nc; p++) {
-        double xi = h.cx[p], yi = h.cy[p], zi = (D == 3) ? h.cz[p] : 0.0;
-        int si = MULTI ? (int)h.csp[p] : 0;
-        double e = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, si, p, -1);
+        const int pc = h.ctr + p;
+        double xi = h.cx[pc], yi = h.cy[pc], zi = (D == 3) ? h.cz[pc] : 0.0;
+        int si = MULTI ? (int)h.csp[pc] : 0;
+        double e = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, si, pc, -1);
         tot += (long long)(e * PMC_FIX);
         if (a.e_particle && wave_lane() == 0) a.e_particle[a.ids[h.k0 + p]] = e;
     }
     if (wave_lane() == 0) atomicAdd(&a.stats[16], (unsigned long long)tot);
 }
 
-// k-th (0-based) centre-cell particle of species sp, in cell order; uniform
+// k-th (0-based) centre-cell particle of species sp, in cell order (index inside the cell); uniform
 __device__ __forceinline__ int kth_of_species(const WaveNbh &h, int sp, int k)
 {
     for (int c0 = 0; c0 < h.nc; c0 += PMC_WAVE) {
         int idx = c0 + wave_lane();
-        bool is = idx < h.nc && (int)h.csp[idx] == sp;
+        bool is = idx < h.nc && (int)h.csp[h.ctr + idx] == sp;
         unsigned long long b = __ballot(is);
         int cnt = __popcll(b);
         if (k < cnt) {
@@ -996,7 +1111,7 @@ __device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
     int n = 0;
     for (int c0 = 0; c0 < h.nc; c0 += PMC_WAVE) {
         int idx = c0 + wave_lane();
-        n += __popcll(__ballot(idx < h.nc && (int)h.csp[idx] == sp));
+        n += __popcll(__ballot(idx < h.nc && (int)h.csp[h.ctr + idx] == sp));
     }
     return n;
 }
@@ -1019,26 +1134,28 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
     stage_neighbourhood<D, MULTI>(a, cell, h);
     const int nc = h.nc;
     if (nc == 0) return;
-    if (nc > h.cap) { if (lane == 0) atomicOr(&a.stats[17], 1ull); return; }
+    if (h.ctr + nc > h.cap) { if (lane == 0) atomicOr(&a.stats[17], 1ull); return; }
+    cell_bounds<D>(a, h);
 
     unsigned long long att[8] = {0}, acc[8] = {0};
     long long efix = 0;
     bool dirty = false;
     const double my_shift = (lane == 0) ? a.shift[0] : ((lane == 1) ? a.shift[1] : a.shift[2]);
     const double my_w = (lane == 0) ? a.w[0] : ((lane == 1) ? a.w[1] : a.w[2]);
+    const int lim = min(h.ncand, h.cap);
 
     for (int chunk = 0; chunk < nc; chunk += PMC_WAVE) {
         // lanes generate the slots of this chunk in parallel
         int t = chunk + lane;
         int g_m = 0;
         uint32_t g_w1 = 0, g_w2 = 0;
-        double g_dx = 0, g_dy = 0, g_dz = 0, g_lnu = 0;
+        double g_dx = 0, g_dy = 0, g_dz = 0, g_tlnu = 0;
         if (t < nc) {
             uint32_t R[4], Q[4];
             philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT0 << 24), a.key0, a.key1, R);
             philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT1 << 24), a.key0, a.key1, Q);
             g_m = select_move(a.pool, R[0]);
-            g_lnu = det_log(uniform53(R[2], R[3]));
+            g_tlnu = a.temperature * det_log(uniform53(R[2], R[3]));
             g_w1 = R[1];
             g_w2 = Q[0];
             double z[4];
@@ -1050,71 +1167,78 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
             g_dz = sg * z[2];
         }
         int nslots = min(PMC_WAVE, nc - chunk);
+#ifdef PMC_DEBUG_NOSLOTS   // profiling builds only: price the staging alone
+        nslots = 0;
+#endif
         for (int s = 0; s < nslots; s++) {
             const int m = __builtin_amdgcn_readlane(g_m, s);
             const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, s);
-            const double lnu = readlane_double(g_lnu, s);
+            const double tlnu = readlane_double(g_tlnu, s);     // T * ln u: accept iff T ln u < -dE
             bool ok = false;
             if (a.pool.kind[m] == 0) {
                 const int p = (int)mulhi32(w1, (uint32_t)nc);
-                const double xo = h.cx[p], yo = h.cy[p], zo = (D == 3) ? h.cz[p] : 0.0;
+                const int pc = h.ctr + p;
+                const double xo = h.cx[pc], yo = h.cy[pc], zo = (D == 3) ? h.cz[pc] : 0.0;
                 const double xn = xo + readlane_double(g_dx, s);
                 const double yn = yo + readlane_double(g_dy, s);
                 const double zn = (D == 3) ? zo + readlane_double(g_dz, s) : 0.0;
-                // "stays in its cell": lane a evaluates dimension a; the old coordinate is cached
-                // (an accepted move never changes it)
-                bool bad = false;
-                if (lane < D) {
-                    const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
-                    const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
-                    const double fo = (p < PMC_CFL) ? h.cfl[lane * PMC_CFL + p] : mc_coord<D>(xs_o, my_shift, my_w);
-                    bad = mc_coord<D>(xs_n, my_shift, my_w) != fo;
-                }
-                if (__ballot(bad) == 0ull) {
-                    const int si = MULTI ? (int)h.csp[p] : 0;
-                    double dsum = 0.0;             // sum_j q(u_new) - q(u_old): every term and the sum are exact
-                    const int lim = min(h.ncand, h.cap);
-                    if (h.nowrap) {
-                        for (int k = lane; k < lim; k += PMC_WAVE) {
-                            const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
-                            const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
-                            const double r2o = dist2_nowrap<D>(xo, yo, zo, xj, yj, zj);
-                            const double r2n = dist2_nowrap<D>(xn, yn, zn, xj, yj, zj);
-                            if (k != p) {
-                                if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
-                                if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
-                            }
-                        }
-                    } else {
-                        for (int k = lane; k < lim; k += PMC_WAVE) {
-                            const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
-                            const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
-                            const double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
-                            const double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
-                            if (k != p) {
-                                if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
-                                if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
-                            }
-                        }
+                // "stays in its cell"  <=>  floor((x_new - shift)/w) == floor((x_old - shift)/w)
+                bool inside;
+                if (h.bounds) {
+                    inside = (xn >= h.lo[0]) && (xn < h.hi[0]) && (yn >= h.lo[1]) && (yn < h.hi[1]);
+                    if (D == 3) inside = inside && (zn >= h.lo[2]) && (zn < h.hi[2]);
+                } else {
+                    bool bad = false;
+                    if (lane < D) {
+                        const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
+                        const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
+                        const double fo = (p < PMC_CFL) ? h.cfl[lane * PMC_CFL + p] : mc_coord<D>(xs_o, my_shift, my_w);
+                        bad = mc_coord<D>(xs_n, my_shift, my_w) != fo;
                     }
+                    inside = (__ballot(bad) == 0ull);
+                }
+                if (inside) {
+                    const int si = MULTI ? (int)h.csp[pc] : 0;
+                    double dsum = 0.0;             // sum_j q(u_new) - q(u_old): every term and the sum are exact
+                    auto term = [&](int k, double xj, double yj, double zj, int sj, auto nowrap_tag) {
+                        constexpr bool NOWRAP = decltype(nowrap_tag)::value;
+                        const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
+                        const double r2o = NOWRAP ? dist2_nowrap<D>(xo, yo, zo, xj, yj, zj) : dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
+                        const double r2n = NOWRAP ? dist2_nowrap<D>(xn, yn, zn, xj, yj, zj) : dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
+                        if (k != pc) {
+                            if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
+                            if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                        }
+                    };
+                    // LDS-resident candidates, two per lane and trip: both loads are issued before the first
+                    // evaluation, so the second candidate's LDS latency hides behind the first one's arithmetic
+                    auto sweep_lds = [&](auto nowrap_tag) {
+                        int k = lane;
+                        for (; k + PMC_WAVE < lim; k += 2 * PMC_WAVE) {
+                            const int k2 = k + PMC_WAVE;
+                            const double xa = h.cx[k], ya = h.cy[k], za = (D == 3) ? h.cz[k] : 0.0;
+                            const double xb = h.cx[k2], yb = h.cy[k2], zb = (D == 3) ? h.cz[k2] : 0.0;
+                            const int sa_ = MULTI ? (int)h.csp[k] : 0, sb_ = MULTI ? (int)h.csp[k2] : 0;
+                            term(k, xa, ya, za, sa_, nowrap_tag);
+                            term(k2, xb, yb, zb, sb_, nowrap_tag);
+                        }
+                        if (k < lim) term(k, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0, MULTI ? (int)h.csp[k] : 0, nowrap_tag);
+                    };
+                    if (h.nowrap) sweep_lds(std::true_type{}); else sweep_lds(std::false_type{});
                     for (int k = lim + lane; k < h.ncand; k += PMC_WAVE) {
                         double xj, yj, zj;
                         int sj;
                         nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
-                        const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
-                        const double r2o = dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
-                        const double r2n = dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
-                        if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
-                        if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                        term(k, xj, yj, zj, sj, std::false_type{});
                     }
                     const double de = wave_sum_exact(dsum);
-                    ok = lnu < -de / a.temperature;
+                    ok = tlnu < -de;
                     if (ok) {
                         __syncthreads();
                         if (lane == 0) {
-                            h.cx[p] = xn;
-                            h.cy[p] = yn;
-                            if (D == 3) h.cz[p] = zn;
+                            h.cx[pc] = xn;
+                            h.cy[pc] = yn;
+                            if (D == 3) h.cz[pc] = zn;
                         }
                         __syncthreads();
                         efix += (long long)(de * PMC_FIX);
@@ -1126,8 +1250,8 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
                 const int sa = a.pool.sp0[m], sb = a.pool.sp1[m];
                 const int na = count_species(h, sa), nb = count_species(h, sb);
                 if (na > 0 && nb > 0 && sa != sb) {
-                    const int pi = kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
-                    const int pj = kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
+                    const int pi = h.ctr + kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
+                    const int pj = h.ctr + kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
                     const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
                     const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
                     double e1 = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, sa, pi, pj) +
@@ -1135,7 +1259,7 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
                     double e2 = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, sb, pi, pj) +
                                 nbh_energy<D, KIND, MULTI>(a, h, tab, xj, yj, zj, sa, pi, pj);
                     const double de = e2 - e1;
-                    ok = lnu < -de / a.temperature;
+                    ok = tlnu < -de;
                     if (ok) {
                         __syncthreads();
                         if (lane == 0) {
@@ -1157,18 +1281,19 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
     }
     if (dirty) {
         for (int k = lane; k < nc; k += PMC_WAVE) {
+            const int kc = h.ctr + k;
             int id = a.ids[h.k0 + k];
-            a.sx[h.k0 + k] = h.cx[k];
-            a.sy[h.k0 + k] = h.cy[k];
-            a.pos[(size_t)id * D + 0] = h.cx[k];
-            a.pos[(size_t)id * D + 1] = h.cy[k];
+            a.sx[h.k0 + k] = h.cx[kc];
+            a.sy[h.k0 + k] = h.cy[kc];
+            a.pos[(size_t)id * D + 0] = h.cx[kc];
+            a.pos[(size_t)id * D + 1] = h.cy[kc];
             if (D == 3) {
-                a.sz[h.k0 + k] = h.cz[k];
-                a.pos[(size_t)id * D + 2] = h.cz[k];
+                a.sz[h.k0 + k] = h.cz[kc];
+                a.pos[(size_t)id * D + 2] = h.cz[kc];
             }
             if (MULTI) {
-                a.ssp[h.k0 + k] = h.csp[k];
-                a.species[id] = (int)h.csp[k];
+                a.ssp[h.k0 + k] = h.csp[kc];
+                a.species[id] = (int)h.csp[kc];
             }
         }
     }
