@@ -13,7 +13,7 @@
 
 #define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
 #define PMC_CFL 64           // centre-cell particles whose cell coordinates are cached
-#define PMC_REF_MAXC 64      // chain length handled by the fast ordered path
+#define PMC_REF_IDS 4096     // neighbourhood size (ids) the ordered-energy LDS buffer holds
 #define PMC_MAXNN 27
 
 // ------------------------------------------------------------------------------
@@ -385,36 +385,43 @@ __device__ __forceinline__ double readlane_double(double v, int l)
 }
 
 // compute_energy_particle with the LinkedIterator order (src/atoms.jl:81-88,
-// src/neighbours.jl:332-377).  One wavefront: lanes walk the <= 27 chains in
-// parallel, pair terms are evaluated in parallel per cell, and the sum is taken
-// strictly in iterator order.  lds_ids: PMC_MAXNN * PMC_REF_MAXC ints.
+// src/neighbours.jl:332-377).  One wavefront: the <= 27 chains are walked by <= 27 lanes
+// concurrently into one LDS id buffer (offsets from the maintained per-cell counts), pair terms
+// are evaluated 64 at a time, and the sum is taken strictly in iterator order.
+// lds_ids: PMC_REF_IDS ints; neighbourhoods larger than that take the serial path.
 template <int D>
 __device__ double wave_ordered_energy(const RefArgs &a, int i, const double *xi, int spi, int *lds_ids)
 {
     const int lane = wave_lane();
     int c = ref_cell_of<D>(a, xi);
     int cnt = a.nbrcnt[c];
-    int len = 0;
-    if (lane < cnt) {
-        int c2 = a.nbr[(size_t)c * a.nnmax + lane];
-        int j = a.head[c2];
-        while (j != -1) {
-            if (len < PMC_REF_MAXC) lds_ids[lane * PMC_REF_MAXC + len] = j;
-            len++;
-            j = a.list[j];
-        }
+    int c2 = (lane < cnt) ? a.nbr[(size_t)c * a.nnmax + lane] : 0;
+    int len = (lane < cnt) ? a.ccount[c2] : 0;
+    int incl = len;
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) {
+        int v = __shfl_up(incl, s, PMC_WAVE);
+        if (lane >= s) incl += v;
     }
-    bool ovf = __any(len > PMC_REF_MAXC);
-    __syncthreads();
+    const int off = incl - len;
+    const int total = __shfl(incl, 31, PMC_WAVE);
+    const bool fits = total <= PMC_REF_IDS;
     double acc = 0.0;
-    if (!ovf) {
-        for (int l = 0; l < cnt; l++) {
-            int n = __builtin_amdgcn_readlane(len, l);
-            double u = 0.0;
-            if (lane < n) {
-                int j = lds_ids[l * PMC_REF_MAXC + lane];
-                u = ref_energy_ij<D>(a, i, j, xi, spi);
+    __syncthreads();
+    if (fits) {
+        if (lane < cnt) {
+            int j = a.head[c2], k = 0;
+            while (j != -1 && k < len) {
+                lds_ids[off + k] = j;
+                k++;
+                j = a.list[j];
             }
+        }
+        __syncthreads();
+        for (int base = 0; base < total; base += PMC_WAVE) {
+            const int n = min(PMC_WAVE, total - base);
+            double u = 0.0;
+            if (lane < n) u = ref_energy_ij<D>(a, i, lds_ids[base + lane], xi, spi);
             for (int k = 0; k < n; k++) acc += readlane_double(u, k);
         }
     } else {
@@ -435,7 +442,7 @@ template <int D>
 __global__ __launch_bounds__(64) void k_ref_energy(RefArgs a, const int *__restrict__ which, int n,
                                                     double *__restrict__ out)
 {
-    __shared__ int lds_ids[PMC_MAXNN * PMC_REF_MAXC];
+    __shared__ int lds_ids[PMC_REF_IDS];
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         int i = which ? which[b] : b;
         double xi[3] = {0, 0, 0};
@@ -606,7 +613,7 @@ __device__ void ref_swap_revert(const RefArgs &a, int i, int j, int s1, int s2, 
 template <int D>
 __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
 {
-    __shared__ int lds_ids[PMC_MAXNN * PMC_REF_MAXC];
+    __shared__ int lds_ids[PMC_REF_IDS];
     const int lane = wave_lane();
     double e1 = 0, e2 = 0, de = 0;
     if (o.op == OP_DISP_PERFORM) {
@@ -741,7 +748,7 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
     constexpr int NR = (D == 3) ? 9 : 3;
     constexpr int LD = D - 1;
     const int lane = wave_lane();
-    const bool runs_ok = (cell[LD] >= 1) && (cell[LD] + 1 < a.n[LD]);
+    bool runs_ok = (cell[LD] >= 1) && (cell[LD] + 1 < a.n[LD]);
     int seg_start = 0, seg_cnt = 0;
     int lin_c = 0;
 #pragma unroll
@@ -749,7 +756,8 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
     h.k0 = a.start[lin_c];
     h.nc = a.start[lin_c + 1] - h.k0;
     if (runs_ok) {
-        h.nseg = NR;
+        // the run layout keeps the centre cell mid-buffer: only use it when everything fits in LDS
+        int tot = 0;
         if (lane < NR) {
             int lin2 = 0, r = lane;
 #pragma unroll
@@ -763,7 +771,16 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
             lin2 = lin2 * a.n[LD] + (cell[LD] - 1);
             seg_start = a.start[lin2];
             seg_cnt = a.start[lin2 + 3] - seg_start;
+            tot = seg_cnt;
         }
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) tot += __shfl_xor(tot, sft, PMC_WAVE);
+        tot = __shfl(tot, 0, PMC_WAVE);
+        runs_ok = tot <= h.cap;
+        if (!runs_ok) { seg_start = 0; seg_cnt = 0; }
+    }
+    if (runs_ok) {
+        h.nseg = NR;
     } else {
         h.nseg = NN;
         if (lane < NN) {

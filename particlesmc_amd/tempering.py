@@ -80,3 +80,32 @@ def run_tempering(system, pool, ladder, nsweeps, exchange_every, seed, rank=0, w
         system.temperature = rex.exchange(st.energy)
         trace.append((done, int(rex.label[rank]), st.energy))
     return rex, trace
+
+
+def run_tempering_local(systems, pool, ladder, nsweeps, exchange_every, seed, mode="checkerboard"):
+    """Parallel tempering with all replicas as handles of this process (one GPU, or several
+    devices through the handles' `device`): same decisions as the one-rank-per-GPU driver, the
+    energies simply need no collective.  Returns (labels, accepted, attempted, per-replica energy traces)."""
+    from .simulation import mc_sweep
+    n = len(systems)
+    ladder = np.ascontiguousarray(ladder, dtype=np.float64)
+    label = np.arange(n, dtype=np.int32)
+    for r, s in enumerate(systems):
+        s.temperature = float(ladder[label[r]])
+    done, rnd, acc, att = 0, 0, 0, 0
+    traces = [[] for _ in range(n)]
+    while done < nsweeps:
+        k = min(exchange_every, nsweeps - done)
+        energies = np.zeros(n)
+        for r, s in enumerate(systems):
+            st = mc_sweep(s, pool, nsweeps=k, mode=mode)
+            energies[r] = st.energy
+            traces[r].append((int(label[r]), st.energy))
+        done += k
+        label, nacc = pt_decide(seed, rnd, energies, ladder, label)
+        att += max(0, (n - (rnd & 1)) // 2)
+        acc += nacc
+        rnd += 1
+        for r, s in enumerate(systems):
+            s.temperature = float(ladder[label[r]])
+    return label, acc, att, traces

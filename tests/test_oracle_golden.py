@@ -277,3 +277,35 @@ def test_checkerboard_statistics_match_sequential_chain(O):
     assert abs(es.mean() - ec.mean()) < 4 * np.hypot(err(es), err(ec)) + 5e-3
     a_s, a_c = acc_s / (prod * N), acc_c / (prod * N)
     assert abs(a_s - a_c) < 0.06 and a_c < a_s + 0.01
+
+
+@pytest.mark.timeout(900)
+def test_oracle_reproduces_the_references_published_mixture_results(O):
+    """Statistical pin at the driver level: the reference's own results for
+    examples/lj-mixture (calculated-energies.csv) -- mean energy and BOTH acceptance rates -- are
+    reproduced by the oracle's sequential chain with the same protocol (N = 1000, rcut = 4,
+    unshifted, 90/10 Displacement/DiscreteSwap, sigma = 0.05; here 400 sweeps, second half
+    averaged).  This is the only reference data that constrains the Metropolis accept rule."""
+    from mixture import EPS, SIG, RCUT, N, make_config, reference_rows
+    row = reference_rows()[0]                 # T = 1.2183, x = 0.5, rho = 0.8
+    pos, sp, rho = make_config(row["x"], row["density"], seed=1)
+    models = O.model_matrix(lambda e, s: O.lennard_jones(e, s, RCUT, False), EPS, SIG)
+    s = O.System(pos, sp, rho, row["t"], models, O.LINKEDLIST)
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.9},
+                        {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}])
+    sweeps = 400
+    en = []
+    att = np.zeros(2)
+    acc = np.zeros(2)
+    for t in range(sweeps):
+        a, c = s.mc_steps(pool, 42, 0, t * N, N)
+        att += a
+        acc += c
+        en.append(s.energy / N)
+    e = np.array(en[sweeps // 2:])
+    blocks = e[: len(e) // 10 * 10].reshape(10, -1).mean(1)
+    err = blocks.std(ddof=1) / np.sqrt(10)
+    assert abs(e.mean() - row["energy"]) < 4 * np.hypot(err, row["energy_err"]) + 0.02
+    assert abs(acc[0] / att[0] - row["acceptance_rate_displacement"]) < 0.02
+    assert abs(acc[1] / att[1] - row["acceptance_rate_swap"]) < 0.04
+    assert abs(att[1] / att.sum() - 0.1) < 0.01
