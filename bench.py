@@ -8,7 +8,7 @@ One "step" = one sweep = N attempted moves.  With --gpus N every rank runs its o
 independent chain (seed 42 + rank) on its own GPU: weak scaling, no data-path
 collective.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 100] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--lattice 100] [--no-cpu]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=100, help="lattice sites per side (N = n^3)")
+    ap.add_argument("--lattice", type=int, default=100, help="lattice sites per side (N = lattice^3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -73,10 +73,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one rank per GPU over RCCL; if a box has fewer GPUs than ranks (functional testing only) the
+        # ranks share devices and the two scalar reductions of this script go over gloo instead
+        backend = "nccl" if ndev >= world else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     ngpus = world
 
     import particlesmc_amd as pmc
@@ -84,17 +93,20 @@ def main():
 
     if pmc.device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device; the HIP path has no CPU fallback")
-    pos, sp, rho = lj_lattice(args.n, jitter=0.05, seed=42)
+    pos, sp, rho = lj_lattice(args.lattice, jitter=0.05, seed=42)
     N = len(pos)
     system = pmc.System(pos, sp, rho, TEMPERATURE, pmc.LennardJones(1.0, 1.0), seed=42 + rank, chain=rank,
-                        device=local_rank)
+                        device=dev_index)
     pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": SIGMA_MOVE}, 1.0)]
     e0, _ = system.total_energy()
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     if args.warmup > 0:
@@ -106,7 +118,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -137,7 +149,7 @@ def main():
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={N} 3D LJ rho=1.0 T=1.0 rcut=2.5 shifted, Displacement sigma=0.05, "
-                                   f"jittered {args.n}^3 lattice, one independent chain per GPU",
+                                   f"jittered {args.lattice}^3 lattice, one independent chain per GPU",
                        "schedule": "checkerboard", "grid": [int(v) for v in system.grid()[0]],
                        "reference_cells": [int(v) for v in ncell_ref]},
             "sweeps_per_s": args.steps * ngpus / elapsed,
