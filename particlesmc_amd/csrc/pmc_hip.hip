@@ -43,6 +43,7 @@ struct pmc_system {
     int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
     int *d_arrival = nullptr, *d_tile_sum = nullptr, *d_order = nullptr, *d_hist = nullptr;
     bool use_order = true;
+    int team = 1;                // wavefronts that share one cell in k_cb_pass (1, 2 or 4)
     int *d_start_ref = nullptr, *d_ids_ref = nullptr;
     // throughput grid
     bool mc_ok = false;
@@ -383,6 +384,14 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     CR(hipMalloc(&h->d_order, ncmax * sizeof(int)));
     CR(hipMalloc(&h->d_hist, (8 * 256 + 1) * sizeof(int)));
     if (const char *e = getenv("PMC_NO_ORDER")) h->use_order = !(e[0] == '1');
+    {
+        // wavefronts per cell: small systems have too few cells per colour to fill 256 CUs with one
+        // wavefront each (measured: N=32768 +54 % with 4, N=10^6 +2 % with 2, N>=8 10^6 best with 1)
+        long long nact = 1;
+        for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
+        h->team = (nact <= 512) ? 4 : ((nact <= 8192) ? 2 : 1);
+        if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4) h->team = t; }
+    }
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
     CR(hipMalloc(&h->d_ids_ref, N * sizeof(int)));
     if (h->mc_ok) {
@@ -912,6 +921,28 @@ static size_t cb_lds_bytes(const pmc_system *h)
     return b;
 }
 
+// k_cb_pass additionally carries the team size NW (wavefronts per cell)
+#define DISPATCH_CB_ONE(DD, KK, NWV, h, grid, lds, args)                                                        \
+    if (!done_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV) {                                        \
+        if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        done_ = true;                                                                                           \
+    }
+#define DISPATCH_CB_KIND(DD, KK, h, grid, lds, args)                                                            \
+    DISPATCH_CB_ONE(DD, KK, 1, h, grid, lds, args)                                                              \
+    DISPATCH_CB_ONE(DD, KK, 2, h, grid, lds, args)                                                              \
+    DISPATCH_CB_ONE(DD, KK, 4, h, grid, lds, args)
+#define DISPATCH_CB(h, grid, lds, args)                                                                         \
+    do {                                                                                                        \
+        bool done_ = false;                                                                                     \
+        DISPATCH_CB_KIND(3, 0, h, grid, lds, args) DISPATCH_CB_KIND(3, 1, h, grid, lds, args)                    \
+        DISPATCH_CB_KIND(3, 2, h, grid, lds, args) DISPATCH_CB_KIND(3, 3, h, grid, lds, args)                    \
+        DISPATCH_CB_KIND(3, 4, h, grid, lds, args) DISPATCH_CB_KIND(2, 0, h, grid, lds, args)                    \
+        DISPATCH_CB_KIND(2, 1, h, grid, lds, args) DISPATCH_CB_KIND(2, 2, h, grid, lds, args)                    \
+        DISPATCH_CB_KIND(2, 3, h, grid, lds, args) DISPATCH_CB_KIND(2, 4, h, grid, lds, args)                    \
+        (void)done_;                                                                                            \
+    } while (0)
+
 #define DISPATCH_ONE(KERNEL, DD, KK, h, grid, lds, args)                                                     \
     if (!done_ && (h)->D == DD && (h)->kind == KK) {                                                            \
         if ((h)->S > 1) hipLaunchKernelGGL((KERNEL<DD, KK, true>), dim3(grid), dim3(64), lds, (h)->stream, args);   \
@@ -1114,7 +1145,7 @@ static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, in
         }
         for (int col = 0; col < ncol; col++) {
             a.colour = col;
-            DISPATCH_KERNEL(k_cb_pass, h, nactive, lds, a);
+            DISPATCH_CB(h, nactive, lds, a);
             launches++;
         }
         if (timed) {

@@ -724,7 +724,13 @@ struct WaveNbh {
     bool nowrap;   // every staged candidate is in the same periodic image as the centre cell
     bool bounds;   // lo/hi below are valid: "stays in the cell" is  lo_a <= x_a < hi_a
     double lo[3], hi[3];
+    double *part;  // [8] per-wavefront partial sums (workgroups of several wavefronts)
+    int *flag;     // [4] workgroup flags
 };
+
+// thread index / stride of the NW wavefronts that share one cell
+template <int NW> __device__ __forceinline__ int team_tid() { return NW == 1 ? wave_lane() : (int)threadIdx.x; }
+template <int NW> __device__ __forceinline__ int team_wave() { return NW == 1 ? 0 : (int)(threadIdx.x >> 6); }
 
 __device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
 {
@@ -741,13 +747,19 @@ __device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
 //    contiguous in the cell-sorted arrays, so the neighbourhood is 3^(D-1) runs; every run is
 //    loaded with one coalesced load per array and all loads are in flight together.
 //  * Generic path: 3^D segments, centre first, located per candidate by binary search.
-template <int D, bool MULTI>
+template <int D, bool MULTI, int NW = 1>
 __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
     constexpr int NR = (D == 3) ? 9 : 3;
     constexpr int LD = D - 1;
+    constexpr int TS = NW * PMC_WAVE;             // team stride
     const int lane = wave_lane();
+    const int tid = team_tid<NW>(), wv = team_wave<NW>();
+    if (NW > 1) {
+        if (tid == 0) h.flag[0] = 0;
+        __syncthreads();
+    }
     bool runs_ok = (cell[LD] >= 1) && (cell[LD] + 1 < a.n[LD]);
     int seg_start = 0, seg_cnt = 0;
     int lin_c = 0;
@@ -823,7 +835,7 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
             const int s0 = __builtin_amdgcn_readlane(seg_start, r), c0 = __builtin_amdgcn_readlane(seg_cnt, r);
             tx[r] = ty[r] = tz[r] = 0.0;
             ts[r] = 0;
-            if (lane < c0) {
+            if ((r % NW) == wv && lane < c0) {
                 tx[r] = a.sx[s0 + lane];
                 ty[r] = a.sy[s0 + lane];
                 if (D == 3) tz[r] = a.sz[s0 + lane];
@@ -833,7 +845,7 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const int c0 = __builtin_amdgcn_readlane(seg_cnt, r), o0 = __builtin_amdgcn_readlane(seg_off, r);
-            if (lane < c0 && o0 + lane < lim) {
+            if ((r % NW) == wv && lane < c0 && o0 + lane < lim) {
                 h.cx[o0 + lane] = tx[r];
                 h.cy[o0 + lane] = ty[r];
                 if (D == 3) h.cz[o0 + lane] = tz[r];
@@ -845,7 +857,7 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
             const int s0 = __builtin_amdgcn_readlane(seg_start, r), c0 = __builtin_amdgcn_readlane(seg_cnt, r);
             const int o0 = __builtin_amdgcn_readlane(seg_off, r);
             for (int l = PMC_WAVE + lane; l < c0; l += PMC_WAVE) {
-                if (o0 + l < lim) {
+                if ((r % NW) == wv && o0 + l < lim) {
                     h.cx[o0 + l] = a.sx[s0 + l];
                     h.cy[o0 + l] = a.sy[s0 + l];
                     if (D == 3) h.cz[o0 + l] = a.sz[s0 + l];
@@ -857,7 +869,7 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
     } else {
         h.ctr = 0;
         __syncthreads();
-        for (int k = lane; k < lim; k += PMC_WAVE) {
+        for (int k = tid; k < lim; k += TS) {
             int src = nbh_find(h, k);
             h.cx[k] = a.sx[src];
             h.cy[k] = a.sy[src];
@@ -874,7 +886,7 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
         bool wrapped = (h.ncand > h.cap) || (h.nc == 0) || (h.ctr + h.nc > h.cap);
         if (!wrapped) {
             const double xr = h.cx[h.ctr], yr = h.cy[h.ctr], zr = (D == 3) ? h.cz[h.ctr] : 0.0;
-            for (int k = lane; k < lim; k += PMC_WAVE) {
+            for (int k = tid; k < lim; k += TS) {
                 bool w0 = rint((xr - h.cx[k]) * a.invL[0]) != 0.0;
                 bool w1 = rint((yr - h.cy[k]) * a.invL[1]) != 0.0;
                 bool w2 = (D == 3) ? (rint((zr - h.cz[k]) * a.invL[2]) != 0.0) : false;
@@ -882,11 +894,16 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
             }
         }
         h.nowrap = (__ballot(wrapped) == 0ull);
+        if (NW > 1) {
+            if (!h.nowrap && lane == 0) atomicOr(&h.flag[0], 1);
+            __syncthreads();
+            h.nowrap = (h.flag[0] == 0);
+        }
     }
-    if (lane < min(h.nc, PMC_CFL) && h.ctr + lane < h.cap) {
-        h.cfl[0 * PMC_CFL + lane] = mc_coord<D>(h.cx[h.ctr + lane], a.shift[0], a.w[0]);
-        h.cfl[1 * PMC_CFL + lane] = mc_coord<D>(h.cy[h.ctr + lane], a.shift[1], a.w[1]);
-        if (D == 3) h.cfl[2 * PMC_CFL + lane] = mc_coord<D>(h.cz[h.ctr + lane], a.shift[2], a.w[2]);
+    if (tid < min(h.nc, PMC_CFL) && h.ctr + tid < h.cap) {
+        h.cfl[0 * PMC_CFL + tid] = mc_coord<D>(h.cx[h.ctr + tid], a.shift[0], a.w[0]);
+        h.cfl[1 * PMC_CFL + tid] = mc_coord<D>(h.cy[h.ctr + tid], a.shift[1], a.w[1]);
+        if (D == 3) h.cfl[2 * PMC_CFL + tid] = mc_coord<D>(h.cz[h.ctr + tid], a.shift[2], a.w[2]);
     }
     __syncthreads();
 }
@@ -996,6 +1013,22 @@ __device__ __forceinline__ double wave_sum_exact(double v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// exact sum over all lanes of the NW wavefronts of a team; result in every lane (2 barriers when NW > 1)
+template <int NW>
+__device__ __forceinline__ double team_sum_exact(const WaveNbh &h, double v)
+{
+    v = wave_sum_exact(v);
+    if (NW == 1) return v;
+    if (wave_lane() == 0) h.part[team_wave<NW>()] = v;
+    __syncthreads();
+    double r = h.part[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) r += h.part[w];
+    __syncthreads();
+    return r;
+}
+
+
 template <int KIND>
 __device__ __forceinline__ double pot_kind(double r2, const DevModel &m)
 {
@@ -1005,18 +1038,19 @@ __device__ __forceinline__ double pot_kind(double r2, const DevModel &m)
 
 // exact per-particle energy of a particle at (xi,yi,zi) with species si against the staged
 // neighbourhood, skipping the LDS slots ex1 / ex2; result in every lane
-template <int D, int KIND, bool MULTI>
+template <int D, int KIND, bool MULTI, int NW = 1>
 __device__ __forceinline__ double nbh_energy(const CbArgs &a, const WaveNbh &h, const DevModel *tab,
                                              double xi, double yi, double zi, int si, int ex1, int ex2)
 {
     double e = 0.0;
     const int lim = min(h.ncand, h.cap);
-    for (int k = wave_lane(); k < lim; k += PMC_WAVE) {          // staged candidates: LDS
+    constexpr int TS = NW * PMC_WAVE;
+    for (int k = team_tid<NW>(); k < lim; k += TS) {             // staged candidates: LDS
         const DevModel &m = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
         double r2 = dist2_fast<D>(a, xi, yi, zi, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0);
         if (k != ex1 && k != ex2 && !(r2 > m.rcut2)) e += dev_quant(pot_kind<KIND>(r2, m));
     }
-    for (int k = lim + wave_lane(); k < h.ncand; k += PMC_WAVE) { // overflow beyond the LDS capacity: HBM/L2
+    for (int k = lim + team_tid<NW>(); k < h.ncand; k += TS) {   // overflow beyond the LDS capacity: HBM/L2
         double xj, yj, zj;
         int sj;
         nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
@@ -1024,12 +1058,12 @@ __device__ __forceinline__ double nbh_energy(const CbArgs &a, const WaveNbh &h, 
         double r2 = dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
         if (!(r2 > m.rcut2)) e += dev_quant(pot_kind<KIND>(r2, m));
     }
-    return wave_sum_exact(e);
+    return team_sum_exact<NW>(h, e);
 }
 
 __host__ __device__ inline size_t pmc_lds_wave_bytes(int cap)
 {
-    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 2 * 32 * 4 + cap;
+    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + 4 * 4 + 2 * 32 * 4 + cap;
 }
 
 template <int D, bool MULTI>
@@ -1040,7 +1074,9 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cy = h.cx + h.cap;
     h.cz = h.cy + h.cap;
     h.cfl = h.cz + h.cap;
-    h.segoff = reinterpret_cast<int *>(h.cfl + 3 * PMC_CFL);
+    h.part = h.cfl + 3 * PMC_CFL;
+    h.flag = reinterpret_cast<int *>(h.part + 8);
+    h.segoff = h.flag + 4;
     h.segsrc = h.segoff + 32;
     h.csp = reinterpret_cast<unsigned char *>(h.segsrc + 32);
     DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap) + 15) & ~(size_t)15));
@@ -1136,22 +1172,24 @@ __device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
 // One colour pass of the checkerboard sweep: one wavefront per active cell.
 // The cell's n_c proposal slots run in order against the LDS-resident
 // neighbourhood; Displacement slots that would leave the cell are rejected.
-template <int D, int KIND, bool MULTI>
-__global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
+template <int D, int KIND, bool MULTI, int NW>
+__global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;
     const DevModel *tab = setup_lds<D, MULTI>(a, smem, h);
     const int lane = wave_lane();
+    const int tid = team_tid<NW>(), wv = team_wave<NW>();
+    constexpr int TS = NW * PMC_WAVE;
     int aidx = a.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     if (aidx >= a.nactive) return;
     int cell[3] = {0, 0, 0}, lin;
     decode_cell<D>(a, aidx, cell, lin);
     h.lin = lin;
-    stage_neighbourhood<D, MULTI>(a, cell, h);
+    stage_neighbourhood<D, MULTI, NW>(a, cell, h);
     const int nc = h.nc;
     if (nc == 0) return;
-    if (h.ctr + nc > h.cap) { if (lane == 0) atomicOr(&a.stats[17], 1ull); return; }
+    if (h.ctr + nc > h.cap) { if (tid == 0) atomicOr(&a.stats[17], 1ull); return; }
     cell_bounds<D>(a, h);
 
     unsigned long long att[8] = {0}, acc[8] = {0};
@@ -1230,9 +1268,9 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
                     // LDS-resident candidates, two per lane and trip: both loads are issued before the first
                     // evaluation, so the second candidate's LDS latency hides behind the first one's arithmetic
                     auto sweep_lds = [&](auto nowrap_tag) {
-                        int k = lane;
-                        for (; k + PMC_WAVE < lim; k += 2 * PMC_WAVE) {
-                            const int k2 = k + PMC_WAVE;
+                        int k = tid;
+                        for (; k + TS < lim; k += 2 * TS) {
+                            const int k2 = k + TS;
                             const double xa = h.cx[k], ya = h.cy[k], za = (D == 3) ? h.cz[k] : 0.0;
                             const double xb = h.cx[k2], yb = h.cy[k2], zb = (D == 3) ? h.cz[k2] : 0.0;
                             const int sa_ = MULTI ? (int)h.csp[k] : 0, sb_ = MULTI ? (int)h.csp[k2] : 0;
@@ -1242,25 +1280,35 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
                         if (k < lim) term(k, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0, MULTI ? (int)h.csp[k] : 0, nowrap_tag);
                     };
                     if (h.nowrap) sweep_lds(std::true_type{}); else sweep_lds(std::false_type{});
-                    for (int k = lim + lane; k < h.ncand; k += PMC_WAVE) {
+                    for (int k = lim + tid; k < h.ncand; k += TS) {
                         double xj, yj, zj;
                         int sj;
                         nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
                         term(k, xj, yj, zj, sj, std::false_type{});
                     }
-                    const double de = wave_sum_exact(dsum);
+                    double de = wave_sum_exact(dsum);
+                    if (NW > 1) {
+                        // combine the wavefronts' partial sums (exact, so the order is free); after this
+                        // barrier nobody reads the old position any more, so the writer may proceed
+                        if (lane == 0) h.part[wv] = de;
+                        __syncthreads();
+                        de = h.part[0];
+#pragma unroll
+                        for (int w = 1; w < NW; w++) de += h.part[w];
+                    }
                     ok = tlnu < -de;
                     if (ok) {
-                        __syncthreads();
-                        if (lane == 0) {
+                        if (NW == 1) __syncthreads();
+                        if (tid == 0) {
                             h.cx[pc] = xn;
                             h.cy[pc] = yn;
                             if (D == 3) h.cz[pc] = zn;
                         }
-                        __syncthreads();
+                        if (NW == 1) __syncthreads();
                         efix += (long long)(de * PMC_FIX);
                         dirty = true;
                     }
+                    if (NW > 1) __syncthreads();   // publishes the move and frees part[] for the next slot
                 }
             } else if (MULTI) {
                 const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)g_w2, s);
@@ -1271,15 +1319,15 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
                     const int pj = h.ctr + kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
                     const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
                     const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
-                    double e1 = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, sa, pi, pj) +
-                                nbh_energy<D, KIND, MULTI>(a, h, tab, xj, yj, zj, sb, pi, pj);
-                    double e2 = nbh_energy<D, KIND, MULTI>(a, h, tab, xi, yi, zi, sb, pi, pj) +
-                                nbh_energy<D, KIND, MULTI>(a, h, tab, xj, yj, zj, sa, pi, pj);
+                    double e1 = nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xi, yi, zi, sa, pi, pj) +
+                                nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xj, yj, zj, sb, pi, pj);
+                    double e2 = nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xi, yi, zi, sb, pi, pj) +
+                                nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xj, yj, zj, sa, pi, pj);
                     const double de = e2 - e1;
                     ok = tlnu < -de;
                     if (ok) {
                         __syncthreads();
-                        if (lane == 0) {
+                        if (tid == 0) {
                             h.csp[pi] = (unsigned char)sb;
                             h.csp[pj] = (unsigned char)sa;
                         }
@@ -1297,7 +1345,7 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
         }
     }
     if (dirty) {
-        for (int k = lane; k < nc; k += PMC_WAVE) {
+        for (int k = tid; k < nc; k += TS) {
             const int kc = h.ctr + k;
             int id = a.ids[h.k0 + k];
             a.sx[h.k0 + k] = h.cx[kc];
@@ -1314,7 +1362,7 @@ __global__ __launch_bounds__(64) void k_cb_pass(CbArgs a)
             }
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         for (int q = 0; q < a.pool.npool; q++) {
             if (att[q]) atomicAdd(&a.stats[q], att[q]);
             if (acc[q]) atomicAdd(&a.stats[8 + q], acc[q]);
