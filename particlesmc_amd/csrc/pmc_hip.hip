@@ -924,8 +924,9 @@ static size_t cb_lds_bytes(const pmc_system *h)
 // k_cb_pass additionally carries the team size NW (wavefronts per cell)
 #define DISPATCH_CB_ONE(DD, KK, NWV, h, grid, lds, args)                                                        \
     if (!done_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV) {                                        \
-        if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
-        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
         done_ = true;                                                                                           \
     }
 #define DISPATCH_CB_KIND(DD, KK, h, grid, lds, args)                                                            \
@@ -935,6 +936,7 @@ static size_t cb_lds_bytes(const pmc_system *h)
 #define DISPATCH_CB(h, grid, lds, args)                                                                         \
     do {                                                                                                        \
         bool done_ = false;                                                                                     \
+        const bool one_ = (args).pool.npool == 1 && (args).pool.kind[0] == 0;                                   \
         DISPATCH_CB_KIND(3, 0, h, grid, lds, args) DISPATCH_CB_KIND(3, 1, h, grid, lds, args)                    \
         DISPATCH_CB_KIND(3, 2, h, grid, lds, args) DISPATCH_CB_KIND(3, 3, h, grid, lds, args)                    \
         DISPATCH_CB_KIND(3, 4, h, grid, lds, args) DISPATCH_CB_KIND(2, 0, h, grid, lds, args)                    \

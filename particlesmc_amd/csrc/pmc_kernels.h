@@ -1172,7 +1172,8 @@ __device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
 // One colour pass of the checkerboard sweep: one wavefront per active cell.
 // The cell's n_c proposal slots run in order against the LDS-resident
 // neighbourhood; Displacement slots that would leave the cell are rejected.
-template <int D, int KIND, bool MULTI, int NW>
+// ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
+template <int D, int KIND, bool MULTI, int NW, bool ONE>
 __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1193,6 +1194,7 @@ __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
     cell_bounds<D>(a, h);
 
     unsigned long long att[8] = {0}, acc[8] = {0};
+    unsigned long long att1 = 0, acc1 = 0;
     long long efix = 0;
     bool dirty = false;
     const double my_shift = (lane == 0) ? a.shift[0] : ((lane == 1) ? a.shift[1] : a.shift[2]);
@@ -1209,14 +1211,14 @@ __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
             uint32_t R[4], Q[4];
             philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT0 << 24), a.key0, a.key1, R);
             philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT1 << 24), a.key0, a.key1, Q);
-            g_m = select_move(a.pool, R[0]);
+            g_m = ONE ? 0 : select_move(a.pool, R[0]);
             g_tlnu = a.temperature * det_log(uniform53(R[2], R[3]));
             g_w1 = R[1];
             g_w2 = Q[0];
             double z[4];
             box_muller(Q[0], Q[1], &z[0], &z[1]);
             box_muller(Q[2], Q[3], &z[2], &z[3]);
-            double sg = a.pool.sigma[g_m];
+            double sg = ONE ? a.pool.sigma[0] : a.pool.sigma[g_m];
             g_dx = sg * z[0];
             g_dy = sg * z[1];
             g_dz = sg * z[2];
@@ -1226,11 +1228,11 @@ __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
         nslots = 0;
 #endif
         for (int s = 0; s < nslots; s++) {
-            const int m = __builtin_amdgcn_readlane(g_m, s);
+            const int m = ONE ? 0 : __builtin_amdgcn_readlane(g_m, s);
             const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, s);
             const double tlnu = readlane_double(g_tlnu, s);     // T * ln u: accept iff T ln u < -dE
             bool ok = false;
-            if (a.pool.kind[m] == 0) {
+            if (ONE || a.pool.kind[m] == 0) {
                 const int p = (int)mulhi32(w1, (uint32_t)nc);
                 const int pc = h.ctr + p;
                 const double xo = h.cx[pc], yo = h.cy[pc], zo = (D == 3) ? h.cz[pc] : 0.0;
@@ -1310,7 +1312,7 @@ __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
                     }
                     if (NW > 1) __syncthreads();   // publishes the move and frees part[] for the next slot
                 }
-            } else if (MULTI) {
+            } else if (MULTI && !ONE) {
                 const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)g_w2, s);
                 const int sa = a.pool.sp0[m], sb = a.pool.sp1[m];
                 const int na = count_species(h, sa), nb = count_species(h, sb);
@@ -1337,10 +1339,15 @@ __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
                     }
                 }
             }
+            if (ONE) {
+                att1 += 1;
+                acc1 += ok ? 1 : 0;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                att[q] += (q == m);
-                acc[q] += (q == m && ok);
+                for (int q = 0; q < 8; q++) {
+                    att[q] += (q == m);
+                    acc[q] += (q == m && ok);
+                }
             }
         }
     }
@@ -1363,9 +1370,14 @@ __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
         }
     }
     if (tid == 0) {
-        for (int q = 0; q < a.pool.npool; q++) {
-            if (att[q]) atomicAdd(&a.stats[q], att[q]);
-            if (acc[q]) atomicAdd(&a.stats[8 + q], acc[q]);
+        if (ONE) {
+            atomicAdd(&a.stats[0], att1);
+            if (acc1) atomicAdd(&a.stats[8], acc1);
+        } else {
+            for (int q = 0; q < a.pool.npool; q++) {
+                if (att[q]) atomicAdd(&a.stats[q], att[q]);
+                if (acc[q]) atomicAdd(&a.stats[8 + q], acc[q]);
+            }
         }
         if (efix) atomicAdd(&a.stats[16], (unsigned long long)efix);
     }
