@@ -196,13 +196,21 @@ __device__ __forceinline__ int cell_colour(int lin, const int n[3])
     return col;
 }
 
+// histogram of cell populations per colour; block-private LDS bins keep the global atomics few
 template <int D>
-__global__ void k_order_hist(const int *__restrict__ start, int ncell, GridGeom g, int *__restrict__ hist)
+__global__ __launch_bounds__(256) void k_order_hist(const int *__restrict__ start, int ncell, GridGeom g, int *__restrict__ hist)
 {
+    __shared__ int lh[8 * 256];
+    for (int k = threadIdx.x; k < 8 * 256; k += 256) lh[k] = 0;
+    __syncthreads();
     int lin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= ncell) return;
-    int cnt = min(start[lin + 1] - start[lin], 255);
-    atomicAdd(&hist[cell_colour<D>(lin, g.n) * 256 + (255 - cnt)], 1);
+    if (lin < ncell) {
+        int cnt = min(start[lin + 1] - start[lin], 255);
+        atomicAdd(&lh[cell_colour<D>(lin, g.n) * 256 + (255 - cnt)], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 8 * 256; k += 256)
+        if (lh[k]) atomicAdd(&hist[k], lh[k]);
 }
 
 __global__ void k_order_scan(int *__restrict__ hist, int ncol)   // one wave per colour, 256 buckets
@@ -224,16 +232,27 @@ __global__ void k_order_scan(int *__restrict__ hist, int ncol)   // one wave per
     }
 }
 
+// slot = (running offset of the bin, reserved once per block) + (rank inside the block)
 template <int D>
-__global__ void k_order_fill(const int *__restrict__ start, int ncell, GridGeom g, int *__restrict__ hist,
-                             int nactive, int *__restrict__ order)
+__global__ __launch_bounds__(256) void k_order_fill(const int *__restrict__ start, int ncell, GridGeom g, int *__restrict__ hist,
+                                                    int nactive, int *__restrict__ order)
 {
+    __shared__ int lh[8 * 256];
+    for (int k = threadIdx.x; k < 8 * 256; k += 256) lh[k] = 0;
+    __syncthreads();
     int lin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= ncell) return;
-    int cnt = min(start[lin + 1] - start[lin], 255);
-    int col = cell_colour<D>(lin, g.n);
-    int slot = atomicAdd(&hist[col * 256 + (255 - cnt)], 1);
-    order[col * nactive + slot] = lin;
+    int bin = -1, rank = 0, col = 0;
+    if (lin < ncell) {
+        int cnt = min(start[lin + 1] - start[lin], 255);
+        col = cell_colour<D>(lin, g.n);
+        bin = col * 256 + (255 - cnt);
+        rank = atomicAdd(&lh[bin], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 8 * 256; k += 256)
+        if (lh[k]) lh[k] = atomicAdd(&hist[k], lh[k]);     // count -> base of this block's share
+    __syncthreads();
+    if (bin >= 0) order[col * nactive + lh[bin] + rank] = lin;
 }
 
 __global__ void k_count(const int *__restrict__ cell_of, int N, int *__restrict__ count)
