@@ -181,6 +181,8 @@ int pmc_sequential_words(uint64_t seed, uint32_t chain, uint64_t step, uint32_t 
 /* -- debug / test hooks ----------------------------------------------------- */
 int pmc_debug_rng(pmc_system *h, int64_t n, const uint32_t *w1, const uint32_t *w2,
                   double *z0, double *z1, double *lnu);           /* device Box-Muller / log, for bit-parity tests */
+int pmc_debug_div(pmc_system *h, int64_t n, const double *num, const double *den,
+                  double *q_ieee, double *q_fast);                 /* guard-free device division vs IEEE, for bit-parity tests */
 const char *pmc_version(void);
 
 #ifdef __cplusplus

@@ -97,6 +97,7 @@ SYMBOLS = {
     "pmc_log_uniform": (C.c_int, [C.c_uint32, C.c_uint32, _dp]),
     "pmc_sequential_words": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, _up, _up]),
     "pmc_debug_rng": (C.c_int, [_h, C.c_int64, _up, _up, _dp, _dp, _dp]),
+    "pmc_debug_div": (C.c_int, [_h, C.c_int64, _dp, _dp, _dp, _dp]),
     "pmc_version": (C.c_char_p, []),
 }
 

@@ -66,6 +66,26 @@ __device__ __forceinline__ double dev_pow_int(double x, long long n)
     return x * y;
 }
 
+// n / d for operands whose quotient needs no range scaling (here: d = r2 inside a cutoff, n = 1
+// or sigma^2).  These are exactly the operations hipcc emits for an IEEE double division --
+// v_rcp_f64, two Newton steps, quotient, residual, correction -- minus v_div_scale / v_div_fixup,
+// which are identities in that range: bit-identical to n / d there (tests/test_gpu_parity.py).
+__device__ __forceinline__ double dev_div_inrange(double n, double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = n * y;
+    double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, y, q);
+}
+
+// throughput-engine variants of the pair potentials (same operations, guard-free division)
+template <int KIND>
+__device__ __forceinline__ double dev_potential_inrange(double r2, const DevModel &m);
+
 // potential(r2, model): src/models.jl:72-74, 121-123, 162-167
 template <int KIND>
 __device__ __forceinline__ double dev_potential(double r2, const DevModel &m)
@@ -80,6 +100,23 @@ __device__ __forceinline__ double dev_potential(double r2, const DevModel &m)
         double lj = dev_lennard_jones(r2, m.eps4, m.sigma2);
         double sh = m.eps4 * (m.C0 + r2 * __builtin_fma(r2, m.C4_s4, m.C2_s2));
         return lj + sh;
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ double dev_potential_inrange(double r2, const DevModel &m)
+{
+    if (KIND == K_LJ || KIND == K_SMOOTH_LJ) {
+        double x = m.sigma2 * dev_div_inrange(1.0, r2);
+        double x3 = x * x * x;
+        double lj = m.eps4 * (x3 * x3 - x3);
+        if (KIND == K_LJ) return lj - m.shift;
+        double sh = m.eps4 * (m.C0 + r2 * __builtin_fma(r2, m.C4_s4, m.C2_s2));
+        return lj + sh;
+    } else if (KIND == K_SOFT_INT) {
+        return m.eps * dev_pow_int(dev_div_inrange(m.sigma2, r2), m.ndiv2_i) - m.shift;
+    } else {
+        return dev_potential<KIND>(r2, m);
     }
 }
 

@@ -1272,6 +1272,25 @@ extern "C" int pmc_sequential_words(uint64_t seed, uint32_t chain, uint64_t step
     return PMC_OK;
 }
 
+extern "C" int pmc_debug_div(pmc_system *h, int64_t n, const double *num, const double *den, double *q_ieee,
+                             double *q_fast)
+{
+    if (!h || n < 1 || !num || !den || !q_ieee || !q_fast) return fail(h, PMC_ERR_BADARG, "pmc_debug_div: bad argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    double *d = nullptr;
+    HIPCHK(h, hipMalloc(&d, (size_t)n * 4 * sizeof(double)));
+    (void)hipMemcpy(d, num, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d + n, den, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_debug_div, dim3(nblk((int)n, 256)), dim3(256), 0, h->stream, (int)n, d, d + n, d + 2 * n, d + 3 * n);
+    hipError_t er = hipStreamSynchronize(h->stream);
+    if (er == hipSuccess) er = hipMemcpy(q_ieee, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(q_fast, d + 3 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (er != hipSuccess) return fail(h, PMC_ERR_HIP, hipGetErrorString(er));
+    return PMC_OK;
+}
+
 // ---- debug ----------------------------------------------------------------------------
 
 extern "C" int pmc_debug_rng(pmc_system *h, int64_t n, const uint32_t *w1, const uint32_t *w2, double *z0, double *z1,

@@ -1052,7 +1052,7 @@ template <int KIND>
 __device__ __forceinline__ double pot_kind(double r2, const DevModel &m)
 {
     if (KIND == 4) return dev_potential_dyn(r2, m);
-    return dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m);
+    return dev_potential_inrange<(KIND == 4 ? 0 : KIND)>(r2, m);
 }
 
 // exact per-particle energy of a particle at (xi,yi,zi) with species si against the staged
@@ -1458,6 +1458,16 @@ __global__ __launch_bounds__(64) void k_delta_e(CbArgs a, int n, const int *__re
         double eb = stream_energy<D>(a, xn[0], xn[1], xn[2], si, i);
         if (wave_lane() == 0) { e1[b] = ea; e2[b] = eb; }
     }
+}
+
+// test hook: the guard-free division against the IEEE one
+__global__ void k_debug_div(int n, const double *__restrict__ num, const double *__restrict__ den,
+                            double *__restrict__ q_ieee, double *__restrict__ q_fast)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    q_ieee[i] = num[i] / den[i];
+    q_fast[i] = dev_div_inrange(num[i], den[i]);
 }
 
 __global__ void k_debug_rng(int n, const uint32_t *__restrict__ w1, const uint32_t *__restrict__ w2,

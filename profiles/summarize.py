@@ -22,23 +22,24 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 def counters(sub):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:                      # newest run only
         for r in csv.DictReader(open(f)):
             out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
-stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    shutil.copy(stats[-1], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
 summary = {}
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     for k, v in counters(sub).items():
         for c, vals in v.items():
             summary.setdefault(k, {})[c] = {"launches": len(vals), "mean": sum(vals) / len(vals)}
 json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 for k, v in summary.items():
-    if k.startswith("void k_cb_pass<3, 0, false>") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    if k.startswith("void k_cb_pass<3, 0, false") and "FETCH_SIZE" in v and "WRITE_SIZE" in v and "SQ_WAVES" in v:
         fetch_kib, write_kib = v["FETCH_SIZE"]["mean"], v["WRITE_SIZE"]["mean"]
         traffic = {
             "kernel": k, "round": tag,
@@ -49,4 +50,9 @@ for k, v in summary.items():
         }
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
         print(traffic)
+bj = os.path.join(SRC, "bench_full.json")
+if os.path.exists(bj):
+    line = [l for l in open(bj) if l.startswith('{"metric"')]
+    if line:
+        json.dump(json.loads(line[0]), open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w"), indent=1)
 print("wrote", tag)

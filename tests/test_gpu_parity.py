@@ -51,6 +51,25 @@ def test_device_rng_bitwise(gpu):
         assert L.orc_det_log(L.orc_uniform53(int(w1[k]), int(w2[k]))) == lnu[k], k
 
 
+def test_guard_free_division_is_ieee_in_range(gpu):
+    """dev_div_inrange (the throughput kernels' 1/r2 and sigma2/r2) equals the IEEE quotient bit for bit
+    over the whole range a cutoff allows, including very close pairs."""
+    pmc = gpu
+    pos, sp, rho = lj_lattice(6)
+    s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0))
+    rng = np.random.default_rng(5)
+    n = 400000
+    den = np.concatenate([rng.uniform(0.3, 16.0, n // 2), 10.0 ** rng.uniform(-12, 2, n // 2)])
+    num = np.concatenate([np.ones(n // 4), rng.uniform(0.5, 2.0, n // 4), np.ones(n // 4), rng.uniform(0.5, 2.0, n // 4)])
+    qi, qf = np.zeros(n), np.zeros(n)
+    dp = C.POINTER(C.c_double)
+    rc = pmc.lib().pmc_debug_div(s._h, n, num.ctypes.data_as(dp), den.ctypes.data_as(dp), qi.ctypes.data_as(dp),
+                                 qf.ctypes.data_as(dp))
+    assert rc == 0
+    assert np.array_equal(qi, num / den)          # device IEEE division == host IEEE division
+    assert np.array_equal(qf, qi)
+
+
 def test_golden_jbb_energy_on_device(gpu):
     """test/runtests.jl:36-38: energy/N = -2.676832 +- 1e-6 under JBB, LinkedList."""
     from oracle import oracle as O
