@@ -44,6 +44,8 @@ struct pmc_system {
     int *d_arrival = nullptr, *d_tile_sum = nullptr, *d_order = nullptr, *d_hist = nullptr;
     bool use_order = true;
     int team = 1;                // wavefronts that share one cell in k_cb_pass (1, 2 or 4)
+    double maxcut = 0.0;
+    bool use_filter = true;
     int *d_start_ref = nullptr, *d_ids_ref = nullptr;
     // throughput grid
     bool mc_ok = false;
@@ -311,6 +313,8 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         if (m.kind < 0 || m.kind > 3) { delete h; return fail(nullptr, PMC_ERR_BADARG, "pmc_create: unknown model kind"); }
         maxcut = std::max(maxcut, m.rcut);
     }
+    h->maxcut = maxcut;
+    if (const char *e = getenv("PMC_NO_FILTER")) h->use_filter = !(e[0] == '1');
     // reference LinkedList geometry comes from the host (src/neighbours.jl:237-238)
     long long nref = 1;
     for (int a = 0; a < h->D; a++) {
@@ -902,6 +906,8 @@ static CbArgs cb_args(pmc_system *h)
     a.models = h->d_models;
     a.stats = h->d_stats;
     a.cap = h->mc_ok ? cb_cap(h) : 128;
+    a.rc2pad = h->maxcut * h->maxcut * (1.0 + 1e-9);
+    a.filter = h->use_filter ? 1 : 0;
     return a;
 }
 
@@ -1164,6 +1170,9 @@ static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, in
     h->cells_built = false;
     rc = check_kernel_flags(h, st);
     if (rc) return rc;
+#ifdef PMC_DEBUG_COUNT
+    fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], (double)st[24] / st[21]);
+#endif
     h->e_fix += (long long)st[16];
     h->energy = (double)h->e_fix / PMC_FIX;
     if (out) {

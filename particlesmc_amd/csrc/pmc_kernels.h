@@ -712,6 +712,8 @@ struct CbArgs {
     DevModel m0;
     const DevModel *models;
     int cap;                   // candidates staged in LDS per wavefront (multiple of 64)
+    double rc2pad;             // (largest cutoff)^2 * (1 + 1e-9): box-distance filter of the staging
+    int filter;                // 1: drop candidates that are out of range of the whole centre cell
     const int *order;          // per colour: cells sorted by population, descending (may be null)
     unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
     double *e_particle;        // optional per-particle energies (id order)
@@ -925,6 +927,89 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
         if (D == 3) h.cfl[2 * PMC_CFL + tid] = mc_coord<D>(h.cz[h.ctr + tid], a.shift[2], a.w[2]);
     }
     __syncthreads();
+}
+
+// Box filter.  A candidate farther than the largest cutoff from the centre cell's box is out of
+// range of every particle that stays inside that cell: it contributes exactly 0 to every slot of
+// this visit, and since every sum is exact, dropping it changes no result.  This compacts the
+// staged candidates in place (LDS -> registers -> LDS), keeping the centre cell contiguous.
+// Preconditions: everything is staged (ncand <= cap), all candidates share the box's periodic
+// image (nowrap), the centre particles' cell coordinates are cached (cfl).  About 30 % of a
+// 27-cell neighbourhood goes away at w ~ rcut.
+template <int D, bool MULTI, int NW>
+__device__ void compact_candidates(const CbArgs &a, WaveNbh &h)
+{
+    constexpr int MAXC = 8;                       // chunks of 64 candidates per wavefront held in registers
+    const int lane = wave_lane(), wv = team_wave<NW>();
+    const int nchunk = (h.ncand + PMC_WAVE - 1) / PMC_WAVE;
+    if (!a.filter || !h.nowrap || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW) return;
+    double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < D; q++) {
+        const double f = h.cfl[q * PMC_CFL];
+        const double eps = 1e-9 * a.w[q];
+        blo[q] = (a.shift[q] + f * a.w[q]) - eps;
+        bhi[q] = (a.shift[q] + (f + 1.0) * a.w[q]) + eps;
+    }
+    double tx[MAXC], ty[MAXC], tz[MAXC];
+    unsigned char ts[MAXC];
+    unsigned long long keepm[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        const int chunk = c * NW + wv;
+        const int k = chunk * PMC_WAVE + lane;
+        tx[c] = ty[c] = tz[c] = 0.0;
+        ts[c] = 0;
+        bool keep = false;
+        if (chunk < nchunk && k < h.ncand) {
+            tx[c] = h.cx[k];
+            ty[c] = h.cy[k];
+            if (D == 3) tz[c] = h.cz[k];
+            if (MULTI) ts[c] = h.csp[k];
+            const double ex = fmax(fmax(blo[0] - tx[c], tx[c] - bhi[0]), 0.0);
+            const double ey = fmax(fmax(blo[1] - ty[c], ty[c] - bhi[1]), 0.0);
+            double d2 = ex * ex + ey * ey;
+            if (D == 3) {
+                const double ez = fmax(fmax(blo[2] - tz[c], tz[c] - bhi[2]), 0.0);
+                d2 += ez * ez;
+            }
+            keep = (k >= h.ctr && k < h.ctr + h.nc) || !(d2 > a.rc2pad);
+        }
+        keepm[c] = __ballot(keep);
+        if (lane == 0 && chunk < 32) h.segoff[chunk] = __popcll(keepm[c]);   // kept count of this chunk
+    }
+    __syncthreads();                              // all reads of the old layout are done; counts published
+    int base_of[MAXC];
+    {
+        int run = 0;
+#pragma unroll
+        for (int chunk = 0; chunk < MAXC * NW; chunk++) {
+            if ((chunk % NW) == wv) base_of[chunk / NW] = run;
+            if (chunk < nchunk) run += h.segoff[chunk];
+        }
+        __syncthreads();                          // counts consumed before segoff is rewritten
+        const int total = run;
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) {
+            const int chunk = c * NW + wv;
+            const int k = chunk * PMC_WAVE + lane;
+            const unsigned long long m = keepm[c];
+            if ((m >> lane) & 1ull) {
+                const int pos = base_of[c] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                h.cx[pos] = tx[c];
+                h.cy[pos] = ty[c];
+                if (D == 3) h.cz[pos] = tz[c];
+                if (MULTI) h.csp[pos] = ts[c];
+                if (k == h.ctr) h.flag[1] = pos;
+            }
+        }
+        __syncthreads();
+        h.ctr = h.flag[1];
+        h.ncand = total;
+        h.nseg = 1;
+        if (lane == 0 && wv == 0) { h.segoff[0] = 0; h.segoff[1] = total; h.segsrc[0] = 0; }
+        __syncthreads();
+    }
 }
 
 // Exact cell boundaries: g(x) = floor((x - shift) / w) is monotone, so {x : g(x) == f} is an
@@ -1210,7 +1295,11 @@ __global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
     const int nc = h.nc;
     if (nc == 0) return;
     if (h.ctr + nc > h.cap) { if (tid == 0) atomicOr(&a.stats[17], 1ull); return; }
+    compact_candidates<D, MULTI, NW>(a, h);
     cell_bounds<D>(a, h);
+#ifdef PMC_DEBUG_COUNT   // profiling builds only
+    if (tid == 0) { atomicAdd(&a.stats[20], (unsigned long long)h.ncand); atomicAdd(&a.stats[21], 1ull); atomicAdd(&a.stats[22], (unsigned long long)h.nowrap); atomicAdd(&a.stats[23], (unsigned long long)h.bounds); atomicAdd(&a.stats[24], (unsigned long long)h.nseg); }
+#endif
 
     unsigned long long att[8] = {0}, acc[8] = {0};
     unsigned long long att1 = 0, acc1 = 0;
