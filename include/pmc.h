@@ -162,6 +162,13 @@ int pmc_grid(pmc_system *h, int64_t *n_mc, double *w);            /* checkerboar
 int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
               int64_t nsweeps, pmc_stats *out);
 
+/* The same sweep split in two so that several handles (chains with parallel=true,
+ * src/ParticlesMC.jl:164,246; replicas of a tempering ladder) run concurrently on one GPU: begin
+ * enqueues on the handle's stream and returns, end waits and collects.  No other call on the
+ * handle between the two. */
+int pmc_sweep_begin(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool, int64_t nsweeps);
+int pmc_sweep_end(pmc_system *h, pmc_stats *out);
+
 /* -- parallel tempering (no reference counterpart: README.md:33 "soon") ----- */
 /* Deterministic swap decisions for one exchange round over n replicas:
  * label[r] = index of the temperature replica r currently holds; pairs of

@@ -13,5 +13,5 @@ from .system import (Atoms, System, compute_energy_particle, compute_energy_part
 from .moves import (DiscreteSwap, Displacement, DoubleUniform, Move, SequentialStream, SimpleGaussian,  # noqa: F401
                     delta_log_target_density, invert_action, log_proposal_density, mc_step,
                     perform_action, revert_action, reward, sample_action, unnormalised_log_target_density)
-from .simulation import Metropolis, Simulation, build_schedule, energy, mc_sweep, run  # noqa: F401
+from .simulation import Metropolis, Simulation, build_schedule, energy, mc_sweep, mc_sweep_many, run  # noqa: F401
 from .io import EXYZ, LAMMPS, XYZ, load_chains, load_configuration  # noqa: F401

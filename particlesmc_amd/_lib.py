@@ -91,6 +91,8 @@ SYMBOLS = {
     "pmc_delta_e": (C.c_int, [_h, C.c_int64, _lp, _dp, _dp, _dp]),
     "pmc_grid": (C.c_int, [_h, _lp, _dp]),
     "pmc_sweep": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64, C.POINTER(Stats)]),
+    "pmc_sweep_begin": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64]),
+    "pmc_sweep_end": (C.c_int, [_h, C.POINTER(Stats)]),
     "pmc_pt_decide": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int32, _dp, _dp, _ip, _ip]),
     "pmc_philox4x32": (C.c_int, [_up, _up, _up]),
     "pmc_box_muller": (C.c_int, [C.c_uint32, C.c_uint32, _dp, _dp]),

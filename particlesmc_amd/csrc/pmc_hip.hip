@@ -46,6 +46,12 @@ struct pmc_system {
     int team = 1;                // wavefronts that share one cell in k_cb_pass (1, 2 or 4)
     double maxcut = 0.0;
     bool use_filter = true;
+    // a sweep in flight (pmc_sweep_begin .. pmc_sweep_end)
+    bool pending = false;
+    int pending_mode = 0;
+    int64_t pending_nsweeps = 0, pending_timed = 0;
+    unsigned long long *h_stats = nullptr;   // pinned host copy of d_stats
+    pmc_stats done_stats{};
     int *d_start_ref = nullptr, *d_ids_ref = nullptr;
     // throughput grid
     bool mc_ok = false;
@@ -409,6 +415,7 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     CR(hipMalloc(&h->d_stats, 32 * sizeof(unsigned long long)));
     CR(hipMemset(h->d_stats, 0, 32 * sizeof(unsigned long long)));
     CR(hipMalloc(&h->d_result, 8 * sizeof(double)));
+    CR(hipHostMalloc(&h->h_stats, 32 * sizeof(unsigned long long)));
 #undef CR
     *out = h;
     return PMC_OK;
@@ -423,6 +430,7 @@ extern "C" int pmc_destroy(pmc_system *h)
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
                     h->d_sz, h->d_ssp, h->d_stats, h->d_result};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (h->h_stats) (void)hipHostFree(h->h_stats);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (hipEvent_t e : h->pass_ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1100,8 +1108,9 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
     return PMC_OK;
 }
 
-static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing)
 {
+    pmc_stats *out = want_timing ? &h->done_stats : nullptr;
     if (!h->mc_ok)
         return fail(h, PMC_ERR_UNSUPPORTED, "checkerboard mode needs >= 4 cells of width >= rcut per side; use PMC_SEQUENTIAL");
     int rc;
@@ -1118,7 +1127,6 @@ static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, in
     int nactive = 1;
     for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
     const size_t lds = cb_lds_bytes(h);
-    float pass_ms = 0.f;
     int64_t launches = 0, timed_sweeps = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     for (int64_t sw = 0; sw < nsweeps; sw++) {
@@ -1163,12 +1171,26 @@ static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, in
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    unsigned long long st[32];
-    HIPCHK(h, hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    (void)launches;
+    h->pending = true;
+    h->pending_mode = PMC_CHECKERBOARD;
+    h->pending_nsweeps = nsweeps;
+    h->pending_timed = timed_sweeps;
+    return PMC_OK;
+}
+
+static int cb_finish(pmc_system *h, pmc_stats *out)
+{
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->pending = false;
+    const unsigned long long *st = h->h_stats;
+    const int64_t nsweeps = h->pending_nsweeps, timed_sweeps = h->pending_timed;
+    const int ncol = 1 << h->D;
+    float pass_ms = 0.f;
     h->sweep_ctr += (uint64_t)nsweeps;
     h->cells_built = false;
-    rc = check_kernel_flags(h, st);
+    int rc = check_kernel_flags(h, st);
     if (rc) return rc;
 #ifdef PMC_DEBUG_COUNT
     fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], (double)st[24] / st[21]);
@@ -1187,9 +1209,70 @@ static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, in
         }
         out->sweep_kernel_ms = pass_ms;
         out->sweep_kernel_launches = timed_sweeps * ncol;
-        (void)launches;
         out->energy = h->energy;
         out->energy_fix = h->e_fix;
+    }
+    return PMC_OK;
+}
+
+static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    int rc = cb_enqueue(h, pool, npool, nsweeps, out != nullptr);
+    if (rc) return rc;
+    return cb_finish(h, out);
+}
+
+static int validate_pool(pmc_system *h, const pmc_move *pool, int32_t npool, int64_t nsweeps);
+
+extern "C" int pmc_sweep_begin(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool, int64_t nsweeps)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_sweep_begin: null handle");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "pmc_sweep_begin: a sweep is already in flight on this handle");
+    int rc = validate_pool(h, pool, npool, nsweeps);
+    if (rc) return rc;
+    rc = set_device(h);
+    if (rc) return rc;
+    memset(&h->done_stats, 0, sizeof h->done_stats);
+    if (mode == PMC_CHECKERBOARD) return cb_enqueue(h, pool, npool, nsweeps, true);
+    if (mode == PMC_SEQUENTIAL) {
+        rc = sweep_sequential(h, pool, npool, nsweeps, &h->done_stats);   // one wavefront: run it now
+        if (rc) return rc;
+        h->pending = true;
+        h->pending_mode = PMC_SEQUENTIAL;
+        return PMC_OK;
+    }
+    return fail(h, PMC_ERR_BADARG, "pmc_sweep_begin: unknown mode");
+}
+
+extern "C" int pmc_sweep_end(pmc_system *h, pmc_stats *out)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_sweep_end: null handle");
+    if (!h->pending) return fail(h, PMC_ERR_STATE, "pmc_sweep_end: no sweep in flight");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (h->pending_mode == PMC_CHECKERBOARD) {
+        rc = cb_finish(h, &h->done_stats);
+        if (rc) return rc;
+    }
+    h->pending = false;
+    if (out) *out = h->done_stats;
+    return PMC_OK;
+}
+
+static int validate_pool(pmc_system *h, const pmc_move *pool, int32_t npool, int64_t nsweeps)
+{
+    if (!h || !pool || npool < 1 || npool > PMC_MAX_MOVES || nsweeps < 0)
+        return fail(h, PMC_ERR_BADARG, "pmc_sweep: bad argument");
+    for (int m = 0; m < npool; m++) {
+        if (pool[m].kind == PMC_MOVE_DISPLACEMENT) {
+            if (!(pool[m].sigma > 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_sweep: Displacement needs sigma > 0");
+        } else if (pool[m].kind == PMC_MOVE_SWAP) {
+            if (pool[m].species[0] < 1 || pool[m].species[0] > h->S || pool[m].species[1] < 1 || pool[m].species[1] > h->S)
+                return fail(h, PMC_ERR_BADARG, "pmc_sweep: DiscreteSwap species out of range");
+        } else {
+            return fail(h, PMC_ERR_BADARG, "pmc_sweep: unsupported action");
+        }
+        if (!(pool[m].probability >= 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_sweep: negative probability");
     }
     return PMC_OK;
 }
@@ -1197,6 +1280,7 @@ static int sweep_checkerboard(pmc_system *h, const pmc_move *pool, int npool, in
 extern "C" int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool, int64_t nsweeps,
                          pmc_stats *out)
 {
+    if (h && h->pending) return fail(h, PMC_ERR_STATE, "pmc_sweep: a sweep is in flight on this handle (pmc_sweep_end first)");
     if (!h || !pool || npool < 1 || npool > PMC_MAX_MOVES || nsweeps < 0)
         return fail(h, PMC_ERR_BADARG, "pmc_sweep: bad argument");
     for (int m = 0; m < npool; m++) {

@@ -52,22 +52,6 @@ __device__ __forceinline__ double mc_coord(double x, double shift, double w)
     return floor((x - shift) / w);
 }
 
-template <int D>
-__global__ void k_mc_cell_index(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    long long lin = 0;
-#pragma unroll
-    for (int a = 0; a < D; a++) {
-        long long q = (long long)mc_coord<D>(pos[(size_t)i * D + a], g.shift[a], g.w[a]);
-        long long r = q % g.n[a];
-        if (r < 0) r += g.n[a];
-        lin = lin * g.n[a] + r;
-    }
-    cell_of[i] = (int)lin;
-}
-
 // throughput-grid binning, pass A: cell index + arrival ticket inside the cell
 template <int D>
 __global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of,
@@ -261,31 +245,6 @@ __global__ void k_count(const int *__restrict__ cell_of, int N, int *__restrict_
     if (i < N) atomicAdd(&count[cell_of[i]], 1);
 }
 
-// exclusive scan of count[0..n) into start[0..n], single block of 1024 threads
-__global__ void k_scan(const int *__restrict__ count, int n, int *__restrict__ start)
-{
-    __shared__ int part[1024];
-    int t = threadIdx.x;
-    int per = (n + 1023) / 1024;
-    int lo = t * per, hi = min(lo + per, n);
-    int s = 0;
-    for (int k = lo; k < hi; k++) s += count[k];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (t >= off) ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int base = (t == 0) ? 0 : part[t - 1];
-    for (int k = lo; k < hi; k++) {
-        start[k] = base;
-        base += count[k];
-    }
-    if (t == 1023) start[n] = part[1023];
-}
-
 __global__ void k_scatter(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
                           int *__restrict__ fill, int *__restrict__ tmp_ids)
 {
@@ -330,20 +289,6 @@ __global__ void k_ref_links(const int *__restrict__ cell_of, int N, const int *_
         head[t] = (hi > lo) ? ids[hi - 1] : -1;
         ccount[t] = hi - lo;
     }
-}
-
-template <int D>
-__global__ void k_mc_gather(const double *__restrict__ pos, const int *__restrict__ species, int N,
-                            const int *__restrict__ ids, double *__restrict__ sx, double *__restrict__ sy,
-                            double *__restrict__ sz, unsigned char *__restrict__ ssp)
-{
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    int i = ids[k];
-    sx[k] = pos[(size_t)i * D + 0];
-    sy[k] = pos[(size_t)i * D + 1];
-    if (D == 3) sz[k] = pos[(size_t)i * D + 2];
-    ssp[k] = (unsigned char)species[i];
 }
 
 // ------------------------------------------------------------------------------

@@ -62,6 +62,21 @@ def mc_sweep(system, pool, rng=None, mc_steps=None, mode="checkerboard", nsweeps
     return SweepStats(st, len(pool))
 
 
+def mc_sweep_many(systems, pool, nsweeps=1, mode="checkerboard"):
+    """The chains of a `parallel=true` run (src/ParticlesMC.jl:164,246): every chain's sweeps are
+    enqueued on its own HIP stream before any is waited for, so small chains share the GPU."""
+    arr = c_pool(pool)
+    L = _lib.lib()
+    for s in systems:
+        _lib.check(L.pmc_sweep_begin(s._h, MODES[mode], arr, len(pool), int(nsweeps)), s._h)
+    out = []
+    for s in systems:
+        st = _lib.Stats()
+        _lib.check(L.pmc_sweep_end(s._h, C.byref(st)), s._h)
+        out.append(SweepStats(st, len(pool)))
+    return out
+
+
 # ---- schedulers (Arianna build_schedule; semantics not pinned by the reference tree) -----
 def build_schedule(steps, burn, block):
     if isinstance(block, (int, np.integer)):
@@ -126,8 +141,7 @@ def run(sim):
     t_now = 0
     for t in [0] + [x for x in times if x > 0] if 0 in times else times:
         if t > t_now:
-            for c, system in enumerate(sim.chains):
-                st = mc_sweep(system, pool, nsweeps=t - t_now, mode=mode)
+            for c, st in enumerate(mc_sweep_many(sim.chains, pool, nsweeps=t - t_now, mode=mode)):
                 att[c] += st.attempted
                 acc[c] += st.accepted
             t_now = t

@@ -86,7 +86,7 @@ def run_tempering_local(systems, pool, ladder, nsweeps, exchange_every, seed, mo
     """Parallel tempering with all replicas as handles of this process (one GPU, or several
     devices through the handles' `device`): same decisions as the one-rank-per-GPU driver, the
     energies simply need no collective.  Returns (labels, accepted, attempted, per-replica energy traces)."""
-    from .simulation import mc_sweep
+    from .simulation import mc_sweep_many
     n = len(systems)
     ladder = np.ascontiguousarray(ladder, dtype=np.float64)
     label = np.arange(n, dtype=np.int32)
@@ -97,8 +97,7 @@ def run_tempering_local(systems, pool, ladder, nsweeps, exchange_every, seed, mo
     while done < nsweeps:
         k = min(exchange_every, nsweeps - done)
         energies = np.zeros(n)
-        for r, s in enumerate(systems):
-            st = mc_sweep(s, pool, nsweeps=k, mode=mode)
+        for r, st in enumerate(mc_sweep_many(systems, pool, nsweeps=k, mode=mode)):
             energies[r] = st.energy
             traces[r].append((int(label[r]), st.energy))
         done += k

@@ -165,3 +165,70 @@ def test_local_parallel_tempering(gpu):
     for r, s in enumerate(systems):
         assert s.temperature == ladder[label[r]]
         _, fix = s.total_energy()
+
+
+def test_concurrent_chains_begin_end(gpu):
+    """pmc_sweep_begin / pmc_sweep_end: four chains in flight together give exactly the results of
+    four chains run one after the other; a second begin on a busy handle is refused."""
+    import ctypes as C
+    from particlesmc_amd import _lib
+    from particlesmc_amd.simulation import c_pool
+    pmc = gpu
+    pos, sp, rho = lj_lattice(16, jitter=0.05, seed=2)
+    pool = [_disp(pmc, 0.06)]
+    a = [pmc.System(pos, sp, rho, 1.0 + 0.1 * r, pmc.LennardJones(1.0, 1.0), seed=7, chain=r) for r in range(4)]
+    b = [pmc.System(pos, sp, rho, 1.0 + 0.1 * r, pmc.LennardJones(1.0, 1.0), seed=7, chain=r) for r in range(4)]
+    sa = pmc.mc_sweep_many(a, pool, nsweeps=5)
+    sb = [pmc.mc_sweep(s, pool, nsweeps=5) for s in b]
+    for r in range(4):
+        assert np.array_equal(a[r].position, b[r].position)
+        assert sa[r].energy_fix == sb[r].energy_fix and sa[r].accepted[0] == sb[r].accepted[0]
+    assert len({s.accepted[0] for s in sa}) > 1                      # chains differ from each other
+    L = _lib.lib()
+    arr = c_pool(pool)
+    assert L.pmc_sweep_begin(a[0]._h, _lib.CHECKERBOARD, arr, 1, 1) == 0
+    assert L.pmc_sweep_begin(a[0]._h, _lib.CHECKERBOARD, arr, 1, 1) == _lib.PMC_ERR_STATE
+    st = _lib.Stats()
+    assert L.pmc_sweep(a[0]._h, _lib.CHECKERBOARD, arr, 1, 1, C.byref(st)) == _lib.PMC_ERR_STATE
+    assert L.pmc_sweep_end(a[0]._h, C.byref(st)) == 0 and st.attempted[0] == len(pos)
+    assert L.pmc_sweep_end(a[0]._h, C.byref(st)) == _lib.PMC_ERR_STATE
+
+
+def test_checkerboard_reproduces_published_mixture_thermodynamics(gpu):
+    """The parallel schedule (cell-local DoubleUniform swaps included) against the reference's own
+    published results for examples/lj-mixture: same state point, same models and move pool, N = 8000
+    so that the checkerboard grid exists (the energy per particle of this short-range-cut model has
+    no visible size dependence at this accuracy).  Mean energy within errors, swap acceptance within
+    a few percent, Displacement acceptance lower only by the cell-leaving rejections."""
+    from mixture import EPS, SIG, RCUT, reference_rows
+    pmc = gpu
+    row = reference_rows()[0]                               # T = 1.2183, x = 0.5, rho = 0.8
+    n = 20
+    N = n ** 3
+    L = (N / row["density"]) ** (1 / 3)
+    g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
+    pos = (g + 0.5) * (L / n)
+    sp = np.ones(N, dtype=np.int32)
+    sp[np.random.default_rng(3).permutation(N)[: N // 2]] = 2
+    mm = [[pmc.LennardJones(EPS[i][j], SIG[i][j], rcut=RCUT, shift_potential=False) for j in range(2)] for i in range(2)]
+    s = pmc.System(pos, sp, N / L ** 3, row["t"], mm, seed=42)
+    assert tuple(s.grid()[0]) == (4, 4, 4)
+    pool = [_disp(pmc, 0.05, 0.9), pmc.Move(pmc.DiscreteSwap([1, 2], s), pmc.DoubleUniform(), [], 0.1)]
+    s.total_energy()
+    pmc.mc_sweep(s, pool, nsweeps=500)                       # equilibration (the reference discards its first half)
+    en = []
+    att = np.zeros(2)
+    acc = np.zeros(2)
+    for _ in range(100):
+        st = pmc.mc_sweep(s, pool, nsweeps=5)
+        att += st.attempted
+        acc += st.accepted
+        en.append(st.energy / N)
+    en = np.array(en)
+    err = en.reshape(10, -1).mean(1).std(ddof=1) / np.sqrt(10)
+    assert abs(en.mean() - row["energy"]) < 4 * np.hypot(err, row["energy_err"]) + 0.01
+    assert abs(acc[1] / att[1] - row["acceptance_rate_swap"]) < 0.03
+    a_d = acc[0] / att[0]
+    assert row["acceptance_rate_displacement"] - 0.06 < a_d < row["acceptance_rate_displacement"] + 0.01
+    _, fix = s.total_energy()
+    assert fix == st.energy_fix
