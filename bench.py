@@ -132,9 +132,16 @@ def main():
         value = moves / elapsed
         ncell_ref = system.neighbour_list.ncells
         b_alg = algorithmic_bytes_per_move(N, 3, ncell_ref)
-        launches = max(1, int(st.sweep_kernel_launches))
-        avg_launch_s = st.sweep_kernel_ms * 1e-3 / launches
-        moves_per_launch = N * min(args.steps, 4096) / launches
+        launches = int(st.sweep_kernel_launches)
+        if launches > 0 and st.sweep_kernel_ms > 0:
+            avg_launch_s = st.sweep_kernel_ms * 1e-3 / launches
+            moves_per_launch = N * min(args.steps, 4096) / launches
+        else:
+            # sweeps replayed from a hipGraph (small systems) carry no per-pass events: price the
+            # colour passes at the whole sweep time (an upper bound of their duration)
+            launches = args.steps * 8
+            avg_launch_s = elapsed / launches
+            moves_per_launch = N / 8.0
         achieved = b_alg * moves_per_launch / avg_launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
