@@ -94,3 +94,103 @@ def test_cli_rejects_bad_input(pmc, tmp_path):
                  '[simulation]\nsteps = 1\nseed = 1\nparallel = false\n')
     with pytest.raises(FileNotFoundError, match="Configuration file"):
         cli.particlesmc(str(p))
+
+
+def test_run_writes_the_reference_output_layout(pmc, tmp_path, monkeypatch):
+    """run!(Simulation) on the host side, with the device sweeps stubbed out: scheduler times, the
+    chains/<c>/energy.dat, moves/<m>/acceptance.dat, trajectory and last-frame files of
+    src/ParticlesMC.jl:249-291 (no GPU needed)."""
+    from particlesmc_amd import simulation as sim
+    from particlesmc_amd import io as pio
+
+    class Fake(_FakeSystem):
+        def __init__(self):
+            rng = np.random.default_rng(0)
+            super().__init__(rng.uniform(0, 5, (12, 3)), rng.integers(1, 3, 12).astype(np.int32), [5.0, 5.0, 5.0])
+            self.e = -3.0
+            self.energy = self
+
+        def __getitem__(self, k):
+            return self.e
+
+    calls = []
+
+    def fake_many(systems, pool, nsweeps=1, mode="checkerboard"):
+        calls.append(nsweeps)
+        out = []
+        for s in systems:
+            s.e -= 0.1 * nsweeps
+
+            class St:
+                attempted = np.array([12 * nsweeps, 4 * nsweeps])
+                accepted = np.array([6 * nsweeps, 1 * nsweeps])
+            out.append(St())
+        return out
+
+    monkeypatch.setattr(sim, "mc_sweep_many", fake_many)
+    chains = [Fake(), Fake()]
+    pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.05}, 0.75),
+            pmc.Move(pmc.DiscreteSwap(1, 1, (1, 2), (6, 6), 0.0), pmc.DoubleUniform(), [], 0.25)]
+    algs = [dict(algorithm="Metropolis", pool=pool, seed=1, parallel=True, sweepstep=12),
+            dict(algorithm="StoreCallbacks", callbacks=[sim.energy], scheduler=sim.build_schedule(20, 0, 5)),
+            dict(algorithm="StoreAcceptance", dependencies=["Metropolis"], scheduler=sim.build_schedule(20, 0, 10)),
+            dict(algorithm="StoreTrajectories", scheduler=sim.build_schedule(20, 0, 10), fmt=pio.EXYZ()),
+            dict(algorithm="StoreLastFrames", scheduler=[20], fmt=pio.LAMMPS()),
+            dict(algorithm="PrintTimeSteps", scheduler=sim.build_schedule(20, 0, 10))]
+    s = sim.run(sim.Simulation(chains, algs, 20, path=str(tmp_path / "out")))
+    assert calls == [5, 5, 5, 5] and s.attempted.shape == (2, 2) and s.attempted[0, 0] == 240
+    for c in (1, 2):
+        en = np.loadtxt(tmp_path / "out" / "chains" / str(c) / "energy.dat")
+        assert list(en[:, 0]) == [0, 5, 10, 15, 20]
+        assert np.allclose(en[:, 1], [(-3.0 - 0.1 * t) / 12 for t in (0, 5, 10, 15, 20)])
+        last = pmc.load_configuration(str(tmp_path / "out" / "chains" / str(c) / "lastframe.lammpstrj"))
+        assert last["N"] == 12 and last["d"] == 3
+        traj = open(tmp_path / "out" / "chains" / str(c) / "trajectory.exyz").read().split("\n")
+        assert traj[0] == "12" and traj[1].startswith('Lattice="5.0 0.0 0.0 0.0 5.0 0.0 0.0 0.0 5.0"') and traj[14] == "12"
+    a1 = np.loadtxt(tmp_path / "out" / "moves" / "1" / "acceptance.dat")
+    a2 = np.loadtxt(tmp_path / "out" / "moves" / "2" / "acceptance.dat")
+    assert list(a1[:, 0]) == [0, 10, 20] and a1[-1, 1] == 0.5 and a2[-1, 1] == 0.25
+
+
+def test_toml_surface_builds_the_same_objects(pmc, tmp_path, monkeypatch):
+    """The keys of src/ParticlesMC.jl:137-299 -> pool and output algorithms (device creation stubbed)."""
+    from particlesmc_amd import cli
+
+    class FakeChain:
+        N = 1290
+        box = np.array([32.8962, 32.8962])
+        species = np.array([1] * 600 + [2] * 330 + [3] * 360)
+
+        def __len__(self):
+            return self.N
+
+    seen = {}
+
+    def fake_load_chains(config, args=None, seed=0, **kw):
+        seen.update(args)
+        seen["seed"] = seed
+        return [FakeChain()]
+
+    monkeypatch.setattr(cli, "load_chains", fake_load_chains)
+    (tmp_path / "c.xyz").write_text("0\n")
+    params = {
+        "system": {"config": "c.xyz", "temperature": 0.231, "density": 1.19, "model": "JBB", "list_type": "LinkedList"},
+        "simulation": {"steps": 100, "seed": 10, "parallel": False, "output_path": "data",
+                       "move": [{"action": "Displacement", "probability": 0.2, "policy": "SimpleGaussian", "parameters": {"sigma": 0.05}},
+                                {"action": "DiscreteSwap", "probability": 0.8, "policy": "DoubleUniform", "parameters": {"species": [1, 3]}}],
+                       "output": [{"algorithm": "StoreCallbacks", "callbacks": ["energy"], "scheduler_params": {"linear_interval": 10}},
+                                  {"algorithm": "StoreLastFrames", "scheduler_params": {"linear_interval": 100}, "fmt": "EXYZ"}]},
+    }
+    s = cli.build_simulation(params, base_dir=str(tmp_path))
+    assert seen["temperature"] == 0.231 and seen["model"] == "JBB" and seen["seed"] == 10 and seen["list_type"] == "LinkedList"
+    metro = s.algorithm_list[0]
+    assert metro["sweepstep"] == 1290 and [m.probability for m in metro["pool"]] == [0.2, 0.8]
+    assert metro["pool"][0].sigma == 0.05 and metro["pool"][1].action.species == (1, 3)
+    assert metro["pool"][1].action.particles_per_species == (600, 360)
+    assert s.algorithm_list[1]["scheduler"] == list(range(0, 101, 10)) and s.algorithm_list[2]["fmt"].extension == ".exyz"
+    bad = dict(params, simulation=dict(params["simulation"], move=[{"action": "Displacement", "probability": 1.0, "policy": "SimpleGaussian"}]))
+    with pytest.raises(ValueError, match="Missing parameter 'sigma'"):
+        cli.build_simulation(bad, base_dir=str(tmp_path))
+    bad = dict(params, simulation=dict(params["simulation"], move=[{"action": "MoleculeFlip", "probability": 1.0, "policy": "DoubleUniform"}]))
+    with pytest.raises(ValueError, match="Unsupported action"):
+        cli.build_simulation(bad, base_dir=str(tmp_path))
