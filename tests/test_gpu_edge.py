@@ -232,3 +232,54 @@ def test_checkerboard_reproduces_published_mixture_thermodynamics(gpu):
     assert row["acceptance_rate_displacement"] - 0.06 < a_d < row["acceptance_rate_displacement"] + 0.01
     _, fix = s.total_energy()
     assert fix == st.energy_fix
+
+
+def test_dilute_gas_empty_cells_and_tiny_systems(gpu):
+    """Ragged inputs: a dilute gas (most cells empty, many with one particle), and systems of one
+    and two particles (the oracle runs the same schedule)."""
+    from oracle import oracle as O
+    pmc = gpu
+    rng = np.random.default_rng(11)
+    N, rho = 400, 0.01
+    L = (N / rho) ** (1 / 3)
+    pos = rng.uniform(0, L, (N, 3))
+    sp = np.ones(N, dtype=np.int32)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=3)
+    o = O.System(pos, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    assert np.array_equal(g.get_cells(), o.cells()) and g.energy[0] == o.energy
+    cb = O.Checkerboard(pos, sp, o.box, 1.0, o.models, seed=3)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.5)], nsweeps=5)
+    att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.5}]), 0, 5)
+    assert st.attempted[0] == att[0] == 5 * N and st.accepted[0] == acc[0]
+    assert np.array_equal(g.position, cb.positions()) and st.energy_fix == cb.energy_fix
+    for n in (1, 2):
+        p2 = np.array([[1.0, 2.0, 3.0], [1.9, 2.2, 3.1]])[:n]
+        s2 = np.ones(n, dtype=np.int32)
+        rho2 = n / 12.0 ** 3
+        g2 = pmc.System(p2, s2, rho2, 1.0, pmc.LennardJones(1.0, 1.0), seed=1)
+        o2 = O.System(p2, s2, rho2, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+        assert g2.energy[0] == o2.energy
+        cb2 = O.Checkerboard(p2, s2, o2.box, 1.0, o2.models, seed=1)
+        st2 = pmc.mc_sweep(g2, [_disp(pmc, 0.1)], nsweeps=20)
+        a2, c2 = cb2.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.1}]), 0, 20)
+        assert st2.accepted[0] == c2[0] and np.array_equal(g2.position, cb2.positions())
+        st3 = pmc.mc_sweep(g2, [_disp(pmc, 0.1)], nsweeps=5, mode="sequential")
+        assert st3.attempted[0] == 5 * n
+
+
+def test_eight_million_particles(gpu):
+    """Maximum-size case: N = 8 * 10^6 (720 MB of device state).  Cell membership against numpy,
+    exact energy bookkeeping across sweeps, reproducibility."""
+    pmc = gpu
+    pos, sp, rho = lj_lattice(200, jitter=0.05, seed=9)
+    N = len(pos)
+    a = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=1)
+    assert a.neighbour_list.ncells == (79, 79, 79)
+    mc = np.floor_divide(pos, a.neighbour_list.box).astype(np.int64) % 79
+    assert np.array_equal(a.get_cells(), 1 + (mc[:, 0] * 79 + mc[:, 1]) * 79 + mc[:, 2])
+    e_ref = a.energy[0]
+    e_fix, _ = a.total_energy()
+    assert abs(e_fix - e_ref) <= 1e-9 * abs(e_ref)
+    st = pmc.mc_sweep(a, [_disp(pmc)], nsweeps=3)
+    assert st.attempted[0] == 3 * N and 0.2 < st.accepted[0] / st.attempted[0] < 0.5
+    assert a.total_energy()[1] == st.energy_fix
