@@ -10,7 +10,7 @@ from .models import (BHHP, JBB, KobAndersen, LennardJones, Model, SmoothLennardJ
 from .neighbours import EmptyList, LinkedList, NeighbourList  # noqa: F401
 from .system import (Atoms, System, compute_energy_particle, compute_energy_particles, fold_back,  # noqa: F401
                      get_box, get_model, get_neighbour_list, get_position, get_species)
-from .moves import (DiscreteSwap, Displacement, DoubleUniform, Move, SequentialStream, SimpleGaussian,  # noqa: F401
+from .moves import (DiscreteSwap, Displacement, DoubleUniform, EnergyBias, Move, SequentialStream, SimpleGaussian,  # noqa: F401
                     delta_log_target_density, invert_action, log_proposal_density, mc_step,
                     perform_action, revert_action, reward, sample_action, unnormalised_log_target_density)
 from .simulation import Metropolis, Simulation, build_schedule, energy, mc_sweep, mc_sweep_many, run  # noqa: F401

@@ -13,6 +13,9 @@
 
 #define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
 #define PMC_CFL 64           // centre-cell particles whose cell coordinates are cached
+#ifndef PMC_CB_MINWAVES
+#define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget)
+#endif
 #define PMC_REF_IDS 4096     // neighbourhood size (ids) the ordered-energy LDS buffer holds
 #define PMC_MAXNN 27
 
@@ -1223,7 +1226,7 @@ __device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
 // neighbourhood; Displacement slots that would leave the cell are rejected.
 // ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
 template <int D, int KIND, bool MULTI, int NW, bool ONE>
-__global__ __launch_bounds__(NW * 64) void k_cb_pass(CbArgs a)
+__global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;

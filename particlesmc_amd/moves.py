@@ -60,6 +60,11 @@ class DoubleUniform(Policy):
     """src/moves.jl:226."""
 
 
+class EnergyBias(Policy):
+    """src/moves.jl:246 -- pick the swap pair with probabilities ~ exp(theta_k * e_particle); needs the
+    per-particle energies of both species for every proposal (sequential chain only)."""
+
+
 class Move:
     """Arianna Move(action, policy, parameters, probability)."""
 
@@ -113,8 +118,29 @@ def revert_action(system, action):
         _lib.check(L.pmc_swap_revert(system._h, action.i, action.j, action.de), system._h)
 
 
+def _theta(parameters):
+    if isinstance(parameters, dict):
+        return float(parameters.get("theta1", parameters.get("θ₁"))), float(parameters.get("theta2", parameters.get("θ₂")))
+    return float(parameters[0]), float(parameters[1])
+
+
+def _energy_bias_tables(action, parameters, system):
+    """exp.(theta .* compute_energy_particle(system, sp_ids[species])) for both species (moves.jl:270-273);
+    the energies are the device's reference-order sums."""
+    from .system import compute_energy_particles
+    th1, th2 = _theta(parameters)
+    e = compute_energy_particles(system)
+    ids1, ids2 = system.species_ids(action.species[0]), system.species_ids(action.species[1])
+    return ids1, ids2, e, np.exp(th1 * e[ids1 - 1]), np.exp(th2 * e[ids2 - 1])
+
+
 def log_proposal_density(action, policy, parameters, system):
-    """src/moves.jl:110-112, 231-233."""
+    """src/moves.jl:110-112, 231-233, 254-263."""
+    if isinstance(policy, EnergyBias):
+        th1, th2 = _theta(parameters)
+        ids1, ids2, e, w1, w2 = _energy_bias_tables(action, parameters, system)
+        numerator = th1 * e[action.i - 1] + th2 * e[action.j - 1]
+        return float(numerator - math.log(w1.sum()) - math.log(w2.sum()))
     if isinstance(action, Displacement):
         sigma = parameters["sigma"] if isinstance(parameters, dict) else float(parameters)
         n2 = float(np.dot(action.delta[: system.d], action.delta[: system.d]))
@@ -190,6 +216,15 @@ class SequentialStream:
 
 def sample_action(action, policy, parameters, system, rng):
     """Arianna.sample_action! -- src/moves.jl:120-123, 238-241; rng is a SequentialStream."""
+    if isinstance(policy, EnergyBias):
+        # rand(rng, Categorical(w / sum(w))) for both species (moves.jl:274-279): inverse-CDF picks from the
+        # step's two 32-bit words
+        ids1, ids2, _, w1, w2 = _energy_bias_tables(action, parameters, system)
+        u1, u2 = rng.R[1] * (1.0 / 4294967296.0), rng.Q[0] * (1.0 / 4294967296.0)
+        k1 = min(int(np.searchsorted(np.cumsum(w1 / w1.sum()), u1, side="right")), len(ids1) - 1)
+        k2 = min(int(np.searchsorted(np.cumsum(w2 / w2.sum()), u2, side="right")), len(ids2) - 1)
+        action.i, action.j = int(ids1[k1]), int(ids2[k2])
+        return
     if isinstance(action, Displacement):
         sigma = parameters["sigma"] if isinstance(parameters, dict) else float(parameters)
         action.i = 1 + rng.mulhi(rng.R[1], system.N)

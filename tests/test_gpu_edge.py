@@ -283,3 +283,35 @@ def test_eight_million_particles(gpu):
     st = pmc.mc_sweep(a, [_disp(pmc)], nsweeps=3)
     assert st.attempted[0] == 3 * N and 0.2 < st.accepted[0] / st.attempted[0] < 0.5
     assert a.total_energy()[1] == st.energy_fix
+
+
+def test_energy_bias_policy(gpu):
+    """EnergyBias (src/moves.jl:246-280) on the per-move verbs: the proposal density uses the device's
+    reference-order per-particle energies, so it equals the same formula fed with the oracle's energies;
+    mc_step with it keeps the chain consistent (energy bookkeeping exact against a recomputation)."""
+    import math
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = binary_lattice(729, frac_b=0.3, rho=1.1, jitter=0.08, seed=5)
+    g = pmc.System(pos, sp, rho, 0.7, pmc.KobAndersen(), seed=9)
+    o = O.System(pos, sp, rho, 0.7, O.kob_andersen(), O.LINKEDLIST)
+    act = pmc.DiscreteSwap([1, 2], g)
+    pol, par = pmc.EnergyBias(), {"theta1": 0.3, "theta2": -0.2}
+    rng = pmc.SequentialStream(seed=9, chain=0, step=0)
+    pmc.sample_action(act, pol, par, g, rng)
+    e = o.energy_particles()
+    ids1, ids2 = o.species_ids(1), o.species_ids(2)
+    w1, w2 = np.exp(0.3 * e[ids1 - 1]), np.exp(-0.2 * e[ids2 - 1])
+    k1 = int(np.searchsorted(np.cumsum(w1 / w1.sum()), rng.R[1] / 2 ** 32, side="right"))
+    k2 = int(np.searchsorted(np.cumsum(w2 / w2.sum()), rng.Q[0] / 2 ** 32, side="right"))
+    assert (act.i, act.j) == (int(ids1[k1]), int(ids2[k2]))
+    want = 0.3 * e[act.i - 1] - 0.2 * e[act.j - 1] - math.log(w1.sum()) - math.log(w2.sum())
+    assert pmc.log_proposal_density(act, pol, par, g) == want
+    acc = 0
+    for _ in range(30):
+        acc += bool(pmc.mc_step(g, act, pol, par, rng))
+        rng.advance()
+    assert 0 <= acc <= 30 and np.count_nonzero(g.species == 2) == np.count_nonzero(sp == 2)
+    running = g.energy[0]
+    g.build_neighbour_list()
+    assert abs(pmc.compute_energy_particles(g).sum() / 2 - running) <= 1e-9 * abs(running)
