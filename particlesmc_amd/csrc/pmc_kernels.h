@@ -881,24 +881,25 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
 // range of every particle that stays inside that cell: it contributes exactly 0 to every slot of
 // this visit, and since every sum is exact, dropping it changes no result.  This compacts the
 // staged candidates in place (LDS -> registers -> LDS), keeping the centre cell contiguous.
-// Preconditions: everything is staged (ncand <= cap), all candidates share the box's periodic
-// image (nowrap), the centre particles' cell coordinates are cached (cfl).  About 30 % of a
-// 27-cell neighbourhood goes away at w ~ rcut.
+// Preconditions: everything is staged (ncand <= cap) and the centre particles' cell coordinates
+// are cached (cfl).  About 30 % of a 27-cell neighbourhood goes away at w ~ rcut.
 template <int D, bool MULTI, int NW>
 __device__ void compact_candidates(const CbArgs &a, WaveNbh &h)
 {
     constexpr int MAXC = 8;                       // chunks of 64 candidates per wavefront held in registers
     const int lane = wave_lane(), wv = team_wave<NW>();
     const int nchunk = (h.ncand + PMC_WAVE - 1) / PMC_WAVE;
-    if (!a.filter || !h.nowrap || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW) return;
-    double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
+    if (!a.filter || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW) return;
+    // box centre (in the frame of the first centre particle) and padded half width; candidates in
+    // another periodic image are brought to the box by the minimum image (|t| <= 2 w <= L/2)
+    double bc[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < D; q++) {
         const double f = h.cfl[q * PMC_CFL];
-        const double eps = 1e-9 * a.w[q];
-        blo[q] = (a.shift[q] + f * a.w[q]) - eps;
-        bhi[q] = (a.shift[q] + (f + 1.0) * a.w[q]) + eps;
+        bc[q] = a.shift[q] + (f + 0.5) * a.w[q];
+        bh[q] = 0.5 * a.w[q] * (1.0 + 1e-9);
     }
+    const bool wrap = !h.nowrap;
     double tx[MAXC], ty[MAXC], tz[MAXC];
     unsigned char ts[MAXC];
     unsigned long long keepm[MAXC];
@@ -914,11 +915,17 @@ __device__ void compact_candidates(const CbArgs &a, WaveNbh &h)
             ty[c] = h.cy[k];
             if (D == 3) tz[c] = h.cz[k];
             if (MULTI) ts[c] = h.csp[k];
-            const double ex = fmax(fmax(blo[0] - tx[c], tx[c] - bhi[0]), 0.0);
-            const double ey = fmax(fmax(blo[1] - ty[c], ty[c] - bhi[1]), 0.0);
+            double t0 = tx[c] - bc[0], t1 = ty[c] - bc[1], t2 = (D == 3) ? tz[c] - bc[2] : 0.0;
+            if (wrap) {
+                t0 -= rint(t0 * a.invL[0]) * a.L[0];
+                t1 -= rint(t1 * a.invL[1]) * a.L[1];
+                if (D == 3) t2 -= rint(t2 * a.invL[2]) * a.L[2];
+            }
+            const double ex = fmax(fabs(t0) - bh[0], 0.0);
+            const double ey = fmax(fabs(t1) - bh[1], 0.0);
             double d2 = ex * ex + ey * ey;
             if (D == 3) {
-                const double ez = fmax(fmax(blo[2] - tz[c], tz[c] - bhi[2]), 0.0);
+                const double ez = fmax(fabs(t2) - bh[2], 0.0);
                 d2 += ez * ez;
             }
             keep = (k >= h.ctr && k < h.ctr + h.nc) || !(d2 > a.rc2pad);
