@@ -167,7 +167,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_cb_pass<3,LJ,single-species>", "algorithmic_bytes_per_move": b_alg,
                          "moves_per_launch": moves_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
-                         "reference_traversal_bytes_per_move": 2 * 27 * (N / float(np.prod(ncell_ref))) * 40.0},
+                         "reference_traversal_bytes_per_move": 2 * 27 * (N / float(np.prod(ncell_ref))) * 40.0,
+                         "note": "contract figure (algorithmic bytes / measured launch time); the kernel is FP64-VALU-"
+                                 "bound (SQ_ACTIVE_INST_VALU ~82 % of SIMD cycles, profiles/r01_pmc.json), its real HBM "
+                                 "traffic is `traffic` bytes per launch"},
         }
         if ngpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(pos, sp, rho, 3_000_000)

@@ -4,8 +4,8 @@
 //  * reference-order engine: device-resident head/list linked cells exactly as
 //    src/neighbours.jl:224-302, per-particle energies summed in the LinkedIterator
 //    order (src/neighbours.jl:332-377) -> bit-identical to the sequential Julia path;
-//  * throughput engine: cell-sorted SoA + CSR over an even grid, one wavefront per
-//    active cell, 3^d neighbour cells staged in LDS, exact (order-free) sums,
+//  * throughput engine: cell-sorted SoA + CSR over an even grid, one workgroup of 1, 2 or 4
+//    wavefronts per active cell, 3^d neighbour cells staged in LDS, exact (order-free) sums,
 //    checkerboard colour passes.
 #pragma once
 #include "pmc_device.h"
@@ -667,8 +667,8 @@ struct CbArgs {
     double *e_particle;        // optional per-particle energies (id order)
 };
 
-// bijective remap so that blocks sharing an XCD (b % 8) work on one contiguous
-// slab of cells: their neighbour cells then hit that XCD's L2
+// bijective remap so that blocks sharing an XCD (b % 8) work on one contiguous slab of cells
+// (used by k_total_energy and when the longest-first order is switched off)
 __device__ __forceinline__ int xcd_remap(int b, int nb)
 {
     int q = nb >> 3, r = nb & 7;
@@ -1228,9 +1228,10 @@ __device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
     return n;
 }
 
-// One colour pass of the checkerboard sweep: one wavefront per active cell.
-// The cell's n_c proposal slots run in order against the LDS-resident
-// neighbourhood; Displacement slots that would leave the cell are rejected.
+// One colour pass of the checkerboard sweep: one workgroup (NW wavefronts) per active cell.
+// The cell's n_c proposal slots run in order against the LDS-resident neighbourhood, the
+// wavefronts splitting every candidate loop; Displacement slots that would leave the cell are
+// rejected.
 // ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
 template <int D, int KIND, bool MULTI, int NW, bool ONE>
 __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
