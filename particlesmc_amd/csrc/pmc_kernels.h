@@ -1120,6 +1120,41 @@ __device__ __forceinline__ double nbh_energy(const CbArgs &a, const WaveNbh &h, 
     return team_sum_exact<NW>(h, e);
 }
 
+// dE of exchanging the species of the particles in slots pi (species sa) and pj (species sb):
+// [E(x_i, sb) + E(x_j, sa)] - [E(x_i, sa) + E(x_j, sb)] over the neighbourhood without pi, pj, in
+// one pass (each distance is computed once and used with both species); every term is exact, so
+// this equals the difference of the four separate sums bit for bit.
+template <int D, int KIND, bool MULTI, int NW>
+__device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, const DevModel *tab, int pi, int pj,
+                                             int sa, int sb)
+{
+    const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
+    const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
+    constexpr int TS = NW * PMC_WAVE;
+    const int lim = min(h.ncand, h.cap);
+    double d = 0.0;
+    auto term = [&](int k, double xk, double yk, double zk, int sk) {
+        const DevModel &ma = tab[sa * a.S + sk];
+        const DevModel &mb = tab[sb * a.S + sk];
+        const double r2i = dist2_fast<D>(a, xi, yi, zi, xk, yk, zk);
+        const double r2j = dist2_fast<D>(a, xj, yj, zj, xk, yk, zk);
+        if (k != pi && k != pj) {
+            if (!(r2i > mb.rcut2)) d += dev_quant(pot_kind<KIND>(r2i, mb));
+            if (!(r2j > ma.rcut2)) d += dev_quant(pot_kind<KIND>(r2j, ma));
+            if (!(r2i > ma.rcut2)) d -= dev_quant(pot_kind<KIND>(r2i, ma));
+            if (!(r2j > mb.rcut2)) d -= dev_quant(pot_kind<KIND>(r2j, mb));
+        }
+    };
+    for (int k = team_tid<NW>(); k < lim; k += TS) term(k, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0, (int)h.csp[k]);
+    for (int k = lim + team_tid<NW>(); k < h.ncand; k += TS) {
+        double xk, yk, zk;
+        int sk;
+        nbh_load<D, MULTI>(a, h, k, xk, yk, zk, sk);
+        term(k, xk, yk, zk, sk);
+    }
+    return team_sum_exact<NW>(h, d);
+}
+
 __host__ __device__ inline size_t pmc_lds_wave_bytes(int cap)
 {
     return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + 4 * 4 + 2 * 32 * 4 + cap;
@@ -1383,13 +1418,7 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                 if (na > 0 && nb > 0 && sa != sb) {
                     const int pi = h.ctr + kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
                     const int pj = h.ctr + kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
-                    const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
-                    const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
-                    double e1 = nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xi, yi, zi, sa, pi, pj) +
-                                nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xj, yj, zj, sb, pi, pj);
-                    double e2 = nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xi, yi, zi, sb, pi, pj) +
-                                nbh_energy<D, KIND, MULTI, NW>(a, h, tab, xj, yj, zj, sa, pi, pj);
-                    const double de = e2 - e1;
+                    const double de = swap_delta<D, KIND, MULTI, NW>(a, h, tab, pi, pj, sa, sb);
                     ok = tlnu < -de;
                     if (ok) {
                         __syncthreads();
