@@ -79,6 +79,14 @@ struct pmc_system {
         }                                                                                       \
     } while (0)
 
+// temporary device allocation that is released on every return path
+struct DevTmp {
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 static int fail(pmc_system *h, int code, const char *msg)
 {
     if (h) h->err = msg;
@@ -425,6 +433,7 @@ extern "C" int pmc_destroy(pmc_system *h)
 {
     if (!h) return PMC_OK;
     (void)hipSetDevice(h->p.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);   // a sweep may still be in flight
     void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
@@ -667,15 +676,12 @@ extern "C" int pmc_energy_particles(pmc_system *h, double *e)
     if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_energy_particles: call pmc_build_cells first");
     int rc = set_device(h);
     if (rc) return rc;
-    double *d_out = nullptr;
-    HIPCHK(h, hipMalloc(&d_out, (size_t)h->N * sizeof(double)));
-    rc = ref_energy_launch(h, nullptr, h->N, d_out);
-    if (!rc) {
-        hipError_t er = hipMemcpy(e, d_out, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost);
-        if (er != hipSuccess) rc = fail(h, PMC_ERR_HIP, hipGetErrorString(er));
-    }
-    (void)hipFree(d_out);
-    return rc;
+    DevTmp out;
+    HIPCHK(h, out.alloc((size_t)h->N * sizeof(double)));
+    rc = ref_energy_launch(h, nullptr, h->N, out.as<double>());
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(e, out.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
+    return PMC_OK;
 }
 
 // Base sum(::Vector{Float64}) is pairwise with 1024-element leaves (base/reduce.jl)
@@ -1050,11 +1056,12 @@ extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const dou
         if (i[k] < 1 || i[k] > h->N) return fail(h, PMC_ERR_BADARG, "pmc_delta_e: particle id out of range");
         w[(size_t)k] = (int)i[k] - 1;
     }
-    int *d_w = nullptr;
-    double *d_d = nullptr, *d_e = nullptr;
-    HIPCHK(h, hipMalloc(&d_w, (size_t)n * sizeof(int)));
-    HIPCHK(h, hipMalloc(&d_d, (size_t)n * h->D * sizeof(double)));
-    HIPCHK(h, hipMalloc(&d_e, (size_t)n * 2 * sizeof(double)));
+    DevTmp tw, td, te;
+    HIPCHK(h, tw.alloc((size_t)n * sizeof(int)));
+    HIPCHK(h, td.alloc((size_t)n * h->D * sizeof(double)));
+    HIPCHK(h, te.alloc((size_t)n * 2 * sizeof(double)));
+    int *d_w = tw.as<int>();
+    double *d_d = td.as<double>(), *d_e = te.as<double>();
     (void)hipMemcpyAsync(d_w, w.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream);
     (void)hipMemcpyAsync(d_d, delta, (size_t)n * h->D * sizeof(double), hipMemcpyHostToDevice, h->stream);
     CbArgs a = cb_args(h);
@@ -1065,7 +1072,6 @@ extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const dou
     if (er == hipSuccess) er = hipMemcpyAsync(e1, d_e, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (er == hipSuccess) er = hipMemcpyAsync(e2, d_e + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_w); (void)hipFree(d_d); (void)hipFree(d_e);
     if (er != hipSuccess) return fail(h, PMC_ERR_HIP, hipGetErrorString(er));
     return PMC_OK;
 }
@@ -1371,15 +1377,15 @@ extern "C" int pmc_debug_div(pmc_system *h, int64_t n, const double *num, const 
     if (!h || n < 1 || !num || !den || !q_ieee || !q_fast) return fail(h, PMC_ERR_BADARG, "pmc_debug_div: bad argument");
     int rc = set_device(h);
     if (rc) return rc;
-    double *d = nullptr;
-    HIPCHK(h, hipMalloc(&d, (size_t)n * 4 * sizeof(double)));
+    DevTmp tmp;
+    HIPCHK(h, tmp.alloc((size_t)n * 4 * sizeof(double)));
+    double *d = tmp.as<double>();
     (void)hipMemcpy(d, num, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
     (void)hipMemcpy(d + n, den, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_debug_div, dim3(nblk((int)n, 256)), dim3(256), 0, h->stream, (int)n, d, d + n, d + 2 * n, d + 3 * n);
     hipError_t er = hipStreamSynchronize(h->stream);
     if (er == hipSuccess) er = hipMemcpy(q_ieee, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (er == hipSuccess) er = hipMemcpy(q_fast, d + 3 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
     if (er != hipSuccess) return fail(h, PMC_ERR_HIP, hipGetErrorString(er));
     return PMC_OK;
 }
@@ -1392,10 +1398,11 @@ extern "C" int pmc_debug_rng(pmc_system *h, int64_t n, const uint32_t *w1, const
     if (!h || n < 1 || !w1 || !w2 || !z0 || !z1 || !lnu) return fail(h, PMC_ERR_BADARG, "pmc_debug_rng: bad argument");
     int rc = set_device(h);
     if (rc) return rc;
-    uint32_t *d_w = nullptr;
-    double *d_o = nullptr;
-    HIPCHK(h, hipMalloc(&d_w, (size_t)n * 2 * sizeof(uint32_t)));
-    HIPCHK(h, hipMalloc(&d_o, (size_t)n * 3 * sizeof(double)));
+    DevTmp tw, to;
+    HIPCHK(h, tw.alloc((size_t)n * 2 * sizeof(uint32_t)));
+    HIPCHK(h, to.alloc((size_t)n * 3 * sizeof(double)));
+    uint32_t *d_w = tw.as<uint32_t>();
+    double *d_o = to.as<double>();
     (void)hipMemcpy(d_w, w1, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
     (void)hipMemcpy(d_w + n, w2, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_debug_rng, dim3(nblk((int)n, 256)), dim3(256), 0, h->stream, (int)n, d_w, d_w + n, d_o, d_o + n,
@@ -1404,7 +1411,6 @@ extern "C" int pmc_debug_rng(pmc_system *h, int64_t n, const uint32_t *w1, const
     if (er == hipSuccess) er = hipMemcpy(z0, d_o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (er == hipSuccess) er = hipMemcpy(z1, d_o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (er == hipSuccess) er = hipMemcpy(lnu, d_o + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d_w); (void)hipFree(d_o);
     if (er != hipSuccess) return fail(h, PMC_ERR_HIP, hipGetErrorString(er));
     return PMC_OK;
 }
