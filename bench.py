@@ -150,6 +150,21 @@ def main():
                 traffic = json.load(open(tpath)).get("k_cb_pass_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # second, honest roofline: the kernel's real limiter is FP64 VALU issue.  Instructions per
+        # launch come from the committed PMC summary of the same command (profiles/), the rate from this run.
+        valu = None
+        ppath = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(ppath) and args.lattice == 100:
+            try:
+                pmcs = json.load(open(ppath))
+                k = next(v for name, v in pmcs.items() if name.startswith("void k_cb_pass<3, 0, false") and "SQ_INSTS_VALU" in v)
+                per_move = k["SQ_INSTS_VALU"]["mean"] / 125000.0
+                peak = 256 * 4 * 2.4e9 / 4.0          # FP64 wave-instructions/s: 256 CUs x 4 SIMDs, 4 cycles each
+                ach = per_move * moves_per_launch / avg_launch_s
+                valu = {"bound": "fp64-valu-issue", "wave_instructions_per_move": per_move, "achieved": ach,
+                        "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak}
+            except Exception:
+                valu = None
         out = {
             "metric": "attempted MC moves/sec, N=10^6 3D LJ rho=1.0 (one sweep = N attempted moves)",
             "value": value, "unit": "attempted moves/s", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
@@ -172,6 +187,7 @@ def main():
                                  "bound (SQ_ACTIVE_INST_VALU ~82 % of SIMD cycles, profiles/r01_pmc.json), its real HBM "
                                  "traffic is `traffic` bytes per launch"},
         }
+        out["roofline_valu"] = valu
         if ngpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(pos, sp, rho, 3_000_000)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()

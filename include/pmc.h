@@ -152,6 +152,7 @@ int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de);/* src/moves
 
 /* -- throughput engine ----------------------------------------------------- */
 int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix);  /* sum(local)/2 src/atoms.jl:51-52, exact fixed-point */
+int pmc_energy_particles_exact(pmc_system *h, double *e);         /* all compute_energy_particle(i) at once (src/ParticlesMC.jl:104-113), exact sums */
 int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const double *delta,
                 double *e1, double *e2);                          /* independent batch of Displacement dE */
 int pmc_grid(pmc_system *h, int64_t *n_mc, double *w);            /* checkerboard grid geometry */

@@ -8,7 +8,8 @@ from ._lib import PMCError, device_count, lib  # noqa: F401
 from .models import (BHHP, JBB, KobAndersen, LennardJones, Model, SmoothLennardJones,  # noqa: F401
                      SoftSpheres, cutoff, cutoff2, potential)
 from .neighbours import EmptyList, LinkedList, NeighbourList  # noqa: F401
-from .system import (Atoms, System, compute_energy_particle, compute_energy_particles, fold_back,  # noqa: F401
+from .system import (Atoms, System, compute_energy_particle, compute_energy_particles,
+                     compute_energy_particles_exact, fold_back,  # noqa: F401
                      get_box, get_model, get_neighbour_list, get_position, get_species)
 from .moves import (DiscreteSwap, Displacement, DoubleUniform, EnergyBias, Move, SequentialStream, SimpleGaussian,  # noqa: F401
                     delta_log_target_density, invert_action, log_proposal_density, mc_step,

@@ -88,6 +88,7 @@ SYMBOLS = {
     "pmc_swap_perform": (C.c_int, [_h, C.c_int64, C.c_int64, _dp, _dp, _dp]),
     "pmc_swap_revert": (C.c_int, [_h, C.c_int64, C.c_int64, C.c_double]),
     "pmc_total_energy": (C.c_int, [_h, _dp, _lp]),
+    "pmc_energy_particles_exact": (C.c_int, [_h, _dp]),
     "pmc_delta_e": (C.c_int, [_h, C.c_int64, _lp, _dp, _dp, _dp]),
     "pmc_grid": (C.c_int, [_h, _lp, _dp]),
     "pmc_sweep": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64, C.POINTER(Stats)]),

@@ -1039,6 +1039,35 @@ extern "C" int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix)
     return PMC_OK;
 }
 
+extern "C" int pmc_energy_particles_exact(pmc_system *h, double *e)
+{
+    if (!h || !e) return fail(h, PMC_ERR_BADARG, "pmc_energy_particles_exact: null argument");
+    if (!h->mc_ok) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_energy_particles_exact: box too small for the cell grid");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "pmc_energy_particles_exact: a sweep is in flight");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (!h->mc_binned) {
+        const double z[3] = {0, 0, 0};
+        rc = mc_bin(h, z);
+        if (rc) return rc;
+    }
+    DevTmp out;
+    HIPCHK(h, out.alloc((size_t)h->N * sizeof(double)));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    CbArgs a = cb_args(h);
+    a.all_cells = 1;
+    a.nactive = h->ncell_mc;
+    a.e_particle = out.as<double>();
+    size_t lds = cb_lds_bytes(h);
+    DISPATCH_KERNEL(k_total_energy, h, a.nactive, lds, a);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long st[32];
+    HIPCHK(h, hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(e, out.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return check_kernel_flags(h, st);
+}
+
 extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const double *delta, double *e1, double *e2)
 {
     if (!h || n < 0 || (n > 0 && (!i || !delta || !e1 || !e2))) return fail(h, PMC_ERR_BADARG, "pmc_delta_e: bad argument");

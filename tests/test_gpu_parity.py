@@ -255,6 +255,21 @@ def test_delta_e_batch(gpu):
         assert abs(e1[k] - ref) <= 1e-9 * max(1.0, abs(ref))
 
 
+def test_exact_per_particle_energies(gpu):
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = binary_lattice(3375, frac_b=0.2, rho=1.2, jitter=0.05, seed=3)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.KobAndersen(), seed=1)
+    o = O.System(pos, sp, rho, 1.0, O.kob_andersen(), O.LINKEDLIST)
+    cb = O.Checkerboard(pos, sp, o.box, 1.0, o.models, seed=1)
+    e = pmc.compute_energy_particles_exact(g)
+    ref = o.energy_particles()
+    assert np.allclose(e, ref, rtol=0, atol=5e-8)      # <= ~100 in-range terms, each rounded to 2^-32 (2.3e-10)
+    for i in (1, 77, 3375):
+        assert e[i - 1] == cb.energy_at(i, pos[i - 1], int(sp[i - 1]))
+    assert int(round(e.sum() / 2 * 2.0 ** 32)) == cb.energy_fix
+
+
 def test_soft_spheres_2d(gpu):
     """test/ss142d.jl shape (2-D 50:50 BHHP soft spheres) at a size the cell grid accepts; n = 12 and 14."""
     from oracle import oracle as O
