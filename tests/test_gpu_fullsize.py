@@ -161,3 +161,29 @@ fmt = "XYZ"
 def pmc_load(path):
     import particlesmc_amd as pmc
     return pmc.load_configuration(str(path))
+
+
+def test_bench_line_contract(gpu):
+    """bench.py prints one JSON line with the driver's fields, the roofline and (at N = 1 GPU) the
+    CPU baseline object; checked on a small lattice so that it runs in seconds."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2",
+                                   "--lattice", "32"], stderr=subprocess.DEVNULL, timeout=600).decode().strip().split("\n")
+    line = [l for l in out if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e3 and "sample" in c
+    assert d["value"] > 1e6 and d["running_energy_equals_recomputed"] is True
+    assert abs(d["value"] - 32768 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
