@@ -404,10 +404,11 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     if (const char *e = getenv("PMC_NO_ORDER")) h->use_order = !(e[0] == '1');
     {
         // wavefronts per cell: small systems have too few cells per colour to fill 256 CUs with one
-        // wavefront each (measured: N=32768 +54 % with 4, N=10^6 +2 % with 2, N>=8 10^6 best with 1)
+        // wavefront each (measured: N=32768 +54 % with 4); from N=2.6e5 to 8e6 two wavefronts per cell
+        // beat one by 5-15 % (half the LDS per wavefront, half the latency of a cell visit)
         long long nact = 1;
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
-        h->team = (nact <= 512) ? 4 : ((nact <= 8192) ? 2 : 1);
+        h->team = (nact <= 512) ? 4 : 2;
         if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4) h->team = t; }
     }
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
