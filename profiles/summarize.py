@@ -45,8 +45,8 @@ for k, v in summary.items():
             "kernel": k, "round": tag,
             "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
             "k_cb_pass_hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
-            "note": "read side doubled (gfx950 FETCH_SIZE correction); 8-B-per-lane gathers are not a calibrated "
-                    "access width, so treat the absolute as +-2x; it is ~35x below the algorithmic bytes",
+            "note": "2 x FETCH_SIZE + WRITE_SIZE; the factor 2 is calibrated for this access width "
+                    "(8 B per lane, profiles/calib/RESULT.md); ~13x below the algorithmic bytes",
         }
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
         print(traffic)
