@@ -609,7 +609,10 @@ extern "C" int pmc_build_cells(pmc_system *h)
 extern "C" int pmc_get_cells(pmc_system *h, int64_t *cs)
 {
     if (!h || !cs) return fail(h, PMC_ERR_BADARG, "pmc_get_cells: null argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_get_cells: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     std::vector<int> t(h->N);
@@ -621,7 +624,10 @@ extern "C" int pmc_get_cells(pmc_system *h, int64_t *cs)
 extern "C" int pmc_get_linked_list(pmc_system *h, int64_t *head, int64_t *list)
 {
     if (!h || !head || !list) return fail(h, PMC_ERR_BADARG, "pmc_get_linked_list: null argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_get_linked_list: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     std::vector<int> t(std::max(h->N, h->ncell_ref));
@@ -674,7 +680,10 @@ static int ref_energy_launch(pmc_system *h, const int *d_which, int n, double *d
 extern "C" int pmc_energy_particles(pmc_system *h, double *e)
 {
     if (!h || !e) return fail(h, PMC_ERR_BADARG, "pmc_energy_particles: null argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_energy_particles: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     DevTmp out;
@@ -717,7 +726,10 @@ extern "C" int pmc_init_energy(pmc_system *h, double *e)
 extern "C" int pmc_energy_particle(pmc_system *h, int64_t i, double *e)
 {
     if (!h || !e || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_energy_particle: bad argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_energy_particle: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     int i0 = (int)i - 1;
@@ -788,7 +800,10 @@ extern "C" int pmc_displacement_perform(pmc_system *h, int64_t i, const double *
                                         double *de)
 {
     if (!h || !delta || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_displacement_perform: bad argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_displacement_perform: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     RefOp o;
@@ -810,7 +825,10 @@ extern "C" int pmc_displacement_perform(pmc_system *h, int64_t i, const double *
 extern "C" int pmc_displacement_revert(pmc_system *h, int64_t i, const double *minus_delta, double de)
 {
     if (!h || !minus_delta || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_displacement_revert: bad argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_displacement_revert: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     RefOp o;
@@ -825,7 +843,10 @@ extern "C" int pmc_displacement_revert(pmc_system *h, int64_t i, const double *m
 extern "C" int pmc_swap_perform(pmc_system *h, int64_t i, int64_t j, double *e1, double *e2, double *de)
 {
     if (!h || i < 1 || i > h->N || j < 1 || j > h->N) return fail(h, PMC_ERR_BADARG, "pmc_swap_perform: bad argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_swap_perform: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     RefOp o;
@@ -847,7 +868,10 @@ extern "C" int pmc_swap_perform(pmc_system *h, int64_t i, int64_t j, double *e1,
 extern "C" int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de)
 {
     if (!h || i < 1 || i > h->N || j < 1 || j > h->N) return fail(h, PMC_ERR_BADARG, "pmc_swap_revert: bad argument");
-    if (!h->cells_built) return fail(h, PMC_ERR_STATE, "pmc_swap_revert: call pmc_build_cells first");
+    if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     RefOp o;

@@ -336,3 +336,27 @@ def test_soft_spheres_odd_exponent(gpu):
     st = pmc.mc_sweep(g, [_disp(pmc, 0.05)], nsweeps=4)
     assert st.attempted[0] == 4 * len(pos) and 0.1 < st.accepted[0] / st.attempted[0] < 0.95
     assert g.total_energy()[1] == st.energy_fix
+
+
+def test_engines_interleave_without_manual_rebuilds(gpu):
+    """Checkerboard sweeps, then per-move verbs and reference-order energies, then sweeps again: the
+    LinkedList is rebuilt on demand (in the reference it is always current) and both energy
+    bookkeepings stay consistent with the oracle at the same positions."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(12, jitter=0.05, seed=21)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=8)
+    pmc.mc_sweep(g, [_disp(pmc)], nsweeps=3)
+    p1 = g.position
+    o = O.System(p1, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    assert pmc.compute_energy_particle(g, 5) == o.energy_particle(5)          # no explicit build_neighbour_list
+    assert np.array_equal(g.get_cells(), o.cells())
+    act = pmc.Displacement(7, np.array([0.3, -0.2, 0.1]), 0.0)
+    e1, e2 = pmc.perform_action(g, act)
+    r1, r2, rde = o.displacement_perform(7, np.array([0.3, -0.2, 0.1]))
+    assert (e1, e2, act.de) == (r1, r2, rde)
+    st = pmc.mc_sweep(g, [_disp(pmc)], nsweeps=2)                             # back to the throughput engine
+    cb = O.Checkerboard(o.positions(), sp, o.box, 1.0, o.models, seed=8)
+    att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 3, 2)
+    assert st.accepted[0] == acc[0] and np.array_equal(g.position, cb.positions())
+    assert st.energy_fix == cb.energy_fix
