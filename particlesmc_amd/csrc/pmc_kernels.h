@@ -16,7 +16,7 @@
 #ifndef PMC_CB_MINWAVES
 #define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget)
 #endif
-#define PMC_REF_IDS 4096     // neighbourhood size (ids) the ordered-energy LDS buffer holds
+#define PMC_REF_IDS 2048     // neighbourhood size (ids) the ordered-energy LDS buffer holds (8 KB: 20 wavefronts per CU)
 #define PMC_MAXNN 27
 
 // ------------------------------------------------------------------------------
