@@ -471,6 +471,7 @@ static int build_species_list(pmc_system *h, const std::vector<int> &sp0)
 extern "C" int pmc_upload(pmc_system *h, const double *pos, const int32_t *species)
 {
     if (!h || !pos) return fail(h, PMC_ERR_BADARG, "pmc_upload: null argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     int rc = set_device(h);
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(h->d_pos, pos, (size_t)h->N * h->D * sizeof(double), hipMemcpyHostToDevice));
@@ -498,6 +499,7 @@ extern "C" int pmc_upload(pmc_system *h, const double *pos, const int32_t *speci
 extern "C" int pmc_download(pmc_system *h, double *pos, int32_t *species)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_download: null handle");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     int rc = set_device(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -513,6 +515,7 @@ extern "C" int pmc_download(pmc_system *h, double *pos, int32_t *species)
 extern "C" int pmc_set_temperature(pmc_system *h, double T)
 {
     if (!h || !(T > 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_set_temperature: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     h->p.temperature = T;
     return PMC_OK;
 }
@@ -584,6 +587,7 @@ static int bin_by_cell(pmc_system *h, int ncell, int *d_start, int *d_ids)
 extern "C" int pmc_build_cells(pmc_system *h)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_build_cells: null handle");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     int rc = set_device(h);
     if (rc) return rc;
     const int N = h->N;
@@ -680,6 +684,7 @@ static int ref_energy_launch(pmc_system *h, const int *d_which, int n, double *d
 extern "C" int pmc_energy_particles(pmc_system *h, double *e)
 {
     if (!h || !e) return fail(h, PMC_ERR_BADARG, "pmc_energy_particles: null argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
         int rb = pmc_build_cells(h);
         if (rb) return rb;
@@ -709,6 +714,7 @@ static double pairwise_sum(const double *v, long long lo, long long hi)
 extern "C" int pmc_init_energy(pmc_system *h, double *e)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_init_energy: null handle");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     int rc = pmc_build_cells(h);                       // src/atoms.jl:50
     if (rc) return rc;
     std::vector<double> loc((size_t)h->N);
@@ -726,6 +732,7 @@ extern "C" int pmc_init_energy(pmc_system *h, double *e)
 extern "C" int pmc_energy_particle(pmc_system *h, int64_t i, double *e)
 {
     if (!h || !e || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_energy_particle: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
         int rb = pmc_build_cells(h);
         if (rb) return rb;
@@ -800,6 +807,7 @@ extern "C" int pmc_displacement_perform(pmc_system *h, int64_t i, const double *
                                         double *de)
 {
     if (!h || !delta || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_displacement_perform: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
         int rb = pmc_build_cells(h);
         if (rb) return rb;
@@ -825,6 +833,7 @@ extern "C" int pmc_displacement_perform(pmc_system *h, int64_t i, const double *
 extern "C" int pmc_displacement_revert(pmc_system *h, int64_t i, const double *minus_delta, double de)
 {
     if (!h || !minus_delta || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_displacement_revert: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
         int rb = pmc_build_cells(h);
         if (rb) return rb;
@@ -843,6 +852,7 @@ extern "C" int pmc_displacement_revert(pmc_system *h, int64_t i, const double *m
 extern "C" int pmc_swap_perform(pmc_system *h, int64_t i, int64_t j, double *e1, double *e2, double *de)
 {
     if (!h || i < 1 || i > h->N || j < 1 || j > h->N) return fail(h, PMC_ERR_BADARG, "pmc_swap_perform: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
         int rb = pmc_build_cells(h);
         if (rb) return rb;
@@ -868,6 +878,7 @@ extern "C" int pmc_swap_perform(pmc_system *h, int64_t i, int64_t j, double *e1,
 extern "C" int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de)
 {
     if (!h || i < 1 || i > h->N || j < 1 || j > h->N) return fail(h, PMC_ERR_BADARG, "pmc_swap_revert: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
         int rb = pmc_build_cells(h);
         if (rb) return rb;
@@ -1035,6 +1046,7 @@ extern "C" int pmc_grid(pmc_system *h, int64_t *n_mc, double *w)
 extern "C" int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_total_energy: null handle");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->mc_ok) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_total_energy: box too small for the cell grid (need >= 4 cells per side)");
     int rc = set_device(h);
     if (rc) return rc;
@@ -1096,6 +1108,7 @@ extern "C" int pmc_energy_particles_exact(pmc_system *h, double *e)
 extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const double *delta, double *e1, double *e2)
 {
     if (!h || n < 0 || (n > 0 && (!i || !delta || !e1 || !e2))) return fail(h, PMC_ERR_BADARG, "pmc_delta_e: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     if (!h->mc_ok) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_delta_e: box too small for the cell grid");
     if (n == 0) return PMC_OK;
     int rc = set_device(h);
@@ -1341,21 +1354,10 @@ extern "C" int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int3
                          pmc_stats *out)
 {
     if (h && h->pending) return fail(h, PMC_ERR_STATE, "pmc_sweep: a sweep is in flight on this handle (pmc_sweep_end first)");
-    if (!h || !pool || npool < 1 || npool > PMC_MAX_MOVES || nsweeps < 0)
-        return fail(h, PMC_ERR_BADARG, "pmc_sweep: bad argument");
-    for (int m = 0; m < npool; m++) {
-        if (pool[m].kind == PMC_MOVE_DISPLACEMENT) {
-            if (!(pool[m].sigma > 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_sweep: Displacement needs sigma > 0");
-        } else if (pool[m].kind == PMC_MOVE_SWAP) {
-            if (pool[m].species[0] < 1 || pool[m].species[0] > h->S || pool[m].species[1] < 1 || pool[m].species[1] > h->S)
-                return fail(h, PMC_ERR_BADARG, "pmc_sweep: DiscreteSwap species out of range");
-        } else {
-            return fail(h, PMC_ERR_BADARG, "pmc_sweep: unsupported action");
-        }
-        if (!(pool[m].probability >= 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_sweep: negative probability");
-    }
+    int rc = validate_pool(h, pool, npool, nsweeps);
+    if (rc) return rc;
     if (out) memset(out, 0, sizeof *out);
-    int rc = set_device(h);
+    rc = set_device(h);
     if (rc) return rc;
     if (mode == PMC_SEQUENTIAL) return sweep_sequential(h, pool, npool, nsweeps, out);
     if (mode == PMC_CHECKERBOARD) return sweep_checkerboard(h, pool, npool, nsweeps, out);
