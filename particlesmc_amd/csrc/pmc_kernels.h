@@ -695,6 +695,7 @@ struct WaveNbh {
     double lo[3], hi[3];
     double *part;  // [8] per-wavefront partial sums (workgroups of several wavefronts)
     int *flag;     // [4] workgroup flags
+    int *cnt;      // [16] per-move attempted / accepted counters of this cell visit
 };
 
 // thread index / stride of the NW wavefronts that share one cell
@@ -1157,7 +1158,7 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
 
 __host__ __device__ inline size_t pmc_lds_wave_bytes(int cap)
 {
-    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + 4 * 4 + 2 * 32 * 4 + cap;
+    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + 4 * 4 + 16 * 4 + 2 * 32 * 4 + cap;
 }
 
 template <int D, bool MULTI>
@@ -1170,7 +1171,8 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cfl = h.cz + h.cap;
     h.part = h.cfl + 3 * PMC_CFL;
     h.flag = reinterpret_cast<int *>(h.part + 8);
-    h.segoff = h.flag + 4;
+    h.cnt = h.flag + 4;
+    h.segoff = h.cnt + 16;
     h.segsrc = h.segoff + 32;
     h.csp = reinterpret_cast<unsigned char *>(h.segsrc + 32);
     DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap) + 15) & ~(size_t)15));
@@ -1292,7 +1294,13 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
     if (tid == 0) { atomicAdd(&a.stats[20], (unsigned long long)h.ncand); atomicAdd(&a.stats[21], 1ull); atomicAdd(&a.stats[22], (unsigned long long)h.nowrap); atomicAdd(&a.stats[23], (unsigned long long)h.bounds); atomicAdd(&a.stats[24], (unsigned long long)h.nseg); }
 #endif
 
-    unsigned long long att[8] = {0}, acc[8] = {0};
+    // multi-move pools count per move in LDS (cnt[0..7] attempted, cnt[8..15] accepted); a
+    // single-Displacement pool counts in two scalars
+    int *cnt = h.cnt;
+    if (!ONE) {
+        if (tid < 16) cnt[tid] = 0;
+        __syncthreads();
+    }
     unsigned long long att1 = 0, acc1 = 0;
     long long efix = 0;
     bool dirty = false;
@@ -1436,10 +1444,9 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                 att1 += 1;
                 acc1 += ok ? 1 : 0;
             } else {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    att[q] += (q == m);
-                    acc[q] += (q == m && ok);
+                if (tid == 0) {
+                    cnt[m] += 1;
+                    if (ok) cnt[8 + m] += 1;
                 }
             }
         }
@@ -1468,8 +1475,8 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
             if (acc1) atomicAdd(&a.stats[8], acc1);
         } else {
             for (int q = 0; q < a.pool.npool; q++) {
-                if (att[q]) atomicAdd(&a.stats[q], att[q]);
-                if (acc[q]) atomicAdd(&a.stats[8 + q], acc[q]);
+                if (cnt[q]) atomicAdd(&a.stats[q], (unsigned long long)cnt[q]);
+                if (cnt[8 + q]) atomicAdd(&a.stats[8 + q], (unsigned long long)cnt[8 + q]);
             }
         }
         if (efix) atomicAdd(&a.stats[16], (unsigned long long)efix);
