@@ -187,3 +187,24 @@ def test_bench_line_contract(gpu):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e3 and "sample" in c
     assert d["value"] > 1e6 and d["running_energy_equals_recomputed"] is True
     assert abs(d["value"] - 32768 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+
+
+def test_long_run_bookkeeping_is_exact(gpu):
+    """20 000 sweeps of the N = 32768 system (6.5 * 10^8 attempted moves): the running energy still
+    equals a recomputation bit for bit, the chain has equilibrated to the liquid (energy below the
+    lattice start, acceptance settled) and particles have diffused away from their lattice sites."""
+    pmc = gpu
+    pos, sp, rho = lj_lattice(32, jitter=0.05, seed=42)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+    e0, _ = g.total_energy()
+    pool = [_pool(pmc)[0]]
+    st = pmc.mc_sweep(g, pool, nsweeps=10000)
+    st2 = pmc.mc_sweep(g, pool, nsweeps=10000)
+    assert st2.attempted[0] == 10000 * len(pos)
+    _, fix = g.total_energy()
+    assert fix == st2.energy_fix
+    assert st2.energy / len(pos) < e0 / len(pos) - 1.0            # lattice -2.27 -> liquid about -5.3
+    assert abs(st2.energy - st.energy) < 0.02 * abs(st.energy)     # stationary over the second half
+    assert abs(st2.accepted[0] / st2.attempted[0] - st.accepted[0] / st.attempted[0]) < 0.02
+    assert np.sqrt(((g.position - pos) ** 2).sum(1).mean()) > 0.5  # root-mean-square displacement
+    assert g.get_counters()[1] == 20000
