@@ -36,7 +36,7 @@ typedef enum {
 typedef enum {
     PMC_MODEL_LJ = 0,
     PMC_MODEL_SOFT_INT = 1,    /* even n: (sigma2/r2)^(n/2) with an integer power */
-    PMC_MODEL_SOFT_FLOAT = 2,  /* odd n */
+    PMC_MODEL_SOFT_FLOAT = 2,  /* odd n: ndiv2_f = n/2 = k + 1/2, evaluated as sqrt((sigma2/r2)^n) -- see DESIGN.md section 3 */
     PMC_MODEL_SMOOTH_LJ = 3
 } pmc_model_kind;
 

@@ -104,7 +104,10 @@ static double inverse_power(double r2, double eps, double sigma2, const orc_mode
     double q = sigma2 / r2;
     if (m->kind == ORC_SOFT_INT)
         return eps * orc_pow_int(q, m->ndiv2_i);
-    return eps * pow(q, m->ndiv2_f); /* Float64^Float64: Julia's own pow, <= 1 ulp */
+    /* Float64^Float64 is Julia's own table-driven pow (< 1 ulp), which cannot be restated here without its
+     * tables; n odd => ndiv2 = k + 1/2, evaluated as sqrt(q^n) with the compensated integer power (<= 0.75 ulp
+     * from the true value). PARITY UNPINNED at the ulp level for this branch. */
+    return eps * sqrt(orc_pow_int(q, (int64_t)(2.0 * m->ndiv2_f)));
 }
 
 /* models.jl:110-119 */

@@ -82,6 +82,14 @@ __device__ __forceinline__ double dev_div_inrange(double n, double d)
     return __builtin_fma(r, y, q);
 }
 
+// x^(n/2) for odd n (src/models.jl:66 makes ndiv2 = n / 2 a Float64 and calls Julia's table-driven
+// Float64^Float64, < 1 ulp, not reproducible here). Evaluated as sqrt(x^n) with the compensated integer
+// power: <= 0.75 ulp from the true value and the same bits on the host, the device and in the oracle.
+__device__ __forceinline__ double dev_pow_half(double x, double ndiv2_f)
+{
+    return __builtin_sqrt(dev_pow_int(x, (long long)(2.0 * ndiv2_f)));
+}
+
 // throughput-engine variants of the pair potentials (same operations, guard-free division)
 template <int KIND>
 __device__ __forceinline__ double dev_potential_inrange(double r2, const DevModel &m);
@@ -95,7 +103,7 @@ __device__ __forceinline__ double dev_potential(double r2, const DevModel &m)
     } else if (KIND == K_SOFT_INT) {
         return m.eps * dev_pow_int(m.sigma2 / r2, m.ndiv2_i) - m.shift;
     } else if (KIND == K_SOFT_FLOAT) {
-        return m.eps * pow(m.sigma2 / r2, m.ndiv2_f) - m.shift;
+        return m.eps * dev_pow_half(m.sigma2 / r2, m.ndiv2_f) - m.shift;
     } else {
         double lj = dev_lennard_jones(r2, m.eps4, m.sigma2);
         double sh = m.eps4 * (m.C0 + r2 * __builtin_fma(r2, m.C4_s4, m.C2_s2));

@@ -38,6 +38,7 @@ struct pmc_system {
     bool cells_built = false;
     int *d_sp_off = nullptr, *d_sp_ids = nullptr, *d_sp_heads = nullptr;
     bool species_list_built = false;
+    bool species_list_stale = false;   // checkerboard swaps changed species[] behind the SpeciesList
     double *d_energy = nullptr;
     // binning scratch
     int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
@@ -155,7 +156,7 @@ static double h_potential(double r2, const pmc_pair_model &m)
     switch (m.kind) {
     case PMC_MODEL_LJ: return h_lennard_jones(r2, m.eps4, m.sigma2) - m.shift;
     case PMC_MODEL_SOFT_INT: return m.eps * h_pow_int(m.sigma2 / r2, m.ndiv2_i) - m.shift;
-    case PMC_MODEL_SOFT_FLOAT: return m.eps * pow(m.sigma2 / r2, m.ndiv2_f) - m.shift;
+    case PMC_MODEL_SOFT_FLOAT: return m.eps * std::sqrt(h_pow_int(m.sigma2 / r2, (int64_t)(2.0 * m.ndiv2_f))) - m.shift;
     default: {
         double lj = h_lennard_jones(r2, m.eps4, m.sigma2);
         double sh = m.eps4 * (m.C0 + r2 * std::fma(r2, m.C4_s4, m.C2_s2));
@@ -325,6 +326,13 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     for (auto &m : h->models) {
         if (m.kind != h->kind) h->kind = 4;
         if (m.kind < 0 || m.kind > 3) { delete h; return fail(nullptr, PMC_ERR_BADARG, "pmc_create: unknown model kind"); }
+        if (m.kind == PMC_MODEL_SOFT_FLOAT) {   // n odd: ndiv2 = k + 1/2 (src/models.jl:66); evaluated as sqrt(x^n)
+            const double n2 = 2.0 * m.ndiv2_f;
+            if (!(n2 >= 1.0 && n2 < 1e6) || n2 != std::floor(n2) || ((int64_t)n2 & 1) == 0) {
+                delete h;
+                return fail(nullptr, PMC_ERR_BADARG, "pmc_create: PMC_MODEL_SOFT_FLOAT needs ndiv2_f = n/2 with n odd");
+            }
+        }
         maxcut = std::max(maxcut, m.rcut);
     }
     h->maxcut = maxcut;
@@ -465,7 +473,19 @@ static int build_species_list(pmc_system *h, const std::vector<int> &sp0)
     HIPCHK(h, hipMemcpy(h->d_sp_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_sp_heads, heads.data(), heads.size() * sizeof(int), hipMemcpyHostToDevice));
     h->species_list_built = true;
+    h->species_list_stale = false;
     return PMC_OK;
+}
+
+// The throughput engine swaps species cell-locally and does not maintain the global SpeciesList; the next
+// consumer (sequential chain, swap verbs, pmc_get_species_ids) gets SpeciesList(species) of the current
+// state, i.e. what the reference constructor (src/utils.jl:36-49) would build from it.
+static int ensure_species_list(pmc_system *h)
+{
+    if (!h->species_list_stale) return PMC_OK;
+    std::vector<int> sp0(h->N);
+    HIPCHK(h, hipMemcpy(sp0.data(), h->d_species, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost));
+    return build_species_list(h, sp0);
 }
 
 extern "C" int pmc_upload(pmc_system *h, const double *pos, const int32_t *species)
@@ -589,6 +609,8 @@ extern "C" int pmc_build_cells(pmc_system *h)
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_build_cells: null handle");
     if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     int rc = set_device(h);
+    if (rc) return rc;
+    rc = ensure_species_list(h);
     if (rc) return rc;
     const int N = h->N;
     const pmc_params &p = h->p;
@@ -763,6 +785,9 @@ extern "C" int pmc_get_species_ids(pmc_system *h, int32_t sp, int64_t *ids)
 {
     if (!h || !ids || sp < 1 || sp > h->S) return fail(h, PMC_ERR_BADARG, "pmc_get_species_ids: bad argument");
     int rc = set_device(h);
+    if (rc) return rc;
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    rc = ensure_species_list(h);
     if (rc) return rc;
     int off[2];
     HIPCHK(h, hipMemcpy(off, h->d_sp_off + (sp - 1), 2 * sizeof(int), hipMemcpyDeviceToHost));
@@ -1191,9 +1216,11 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
         rc = pmc_total_energy(h, nullptr, nullptr);
         if (rc) return rc;
     }
-    for (int m = 0; m < npool; m++)
+    for (int m = 0; m < npool; m++) {
         if (pool[m].kind == PMC_MOVE_SWAP && h->S < 2)
             return fail(h, PMC_ERR_BADARG, "DiscreteSwap needs at least two species");
+        if (pool[m].kind == PMC_MOVE_SWAP && nsweeps > 0) h->species_list_stale = true;
+    }
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
     const MovePool mp = make_pool(pool, npool);
     const int ncol = 1 << h->D;

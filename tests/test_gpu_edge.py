@@ -318,24 +318,33 @@ def test_energy_bias_policy(gpu):
 
 
 def test_soft_spheres_odd_exponent(gpu):
-    """SoftSpheres with odd n takes the Float64 exponent branch (src/models.jl:66: ndiv2 = n / 2): the
-    device and the host libm `pow` agree to an ulp or so, so energies are compared to 1e-13 relative
-    (no bit-exact claim here) and a sweep must keep the exact bookkeeping consistent."""
+    """SoftSpheres with odd n takes the Float64 exponent branch (src/models.jl:66: ndiv2 = n / 2). Julia's own
+    Float64^Float64 cannot be restated without its tables (parity unpinned at the ulp level for this branch);
+    host, device and oracle all evaluate sqrt(x^n) with the compensated integer power, so they agree bit for
+    bit with each other, and with libm's pow to a couple of ulp."""
     from oracle import oracle as O
     pmc = gpu
     pos, sp, rho = binary_lattice(2197, frac_b=0.5, rho=0.8, jitter=0.05, seed=12)
     mm = [[pmc.SoftSpheres(1.0, s, 9) for s in row] for row in ([1.0, 1.1], [1.1, 1.2])]
     g = pmc.System(pos, sp, rho, 1.0, mm, seed=2)
-    o = O.System(pos, sp, rho, 1.0, O.model_matrix(lambda e, s: O.soft_spheres(e, s, 9), [[1.0, 1.0], [1.0, 1.0]],
-                                                    [[1.0, 1.1], [1.1, 1.2]]), O.LINKEDLIST)
+    mo = O.model_matrix(lambda e, s: O.soft_spheres(e, s, 9), [[1.0, 1.0], [1.0, 1.0]], [[1.0, 1.1], [1.1, 1.2]])
+    o = O.System(pos, sp, rho, 1.0, mo, O.LINKEDLIST)
     assert np.array_equal(g.get_cells(), o.cells())
-    assert np.allclose(pmc.compute_energy_particles(g), o.energy_particles(), rtol=1e-13, atol=1e-13)
-    assert abs(g.energy[0] - o.energy) <= 1e-12 * abs(o.energy)
+    assert np.array_equal(pmc.compute_energy_particles(g), o.energy_particles()) and g.energy[0] == o.energy
+    # against libm pow on the host: x^(9/2), a few ulp
+    r2 = np.linspace(0.7, 6.0, 1001)
+    mine = np.array([pmc.potential(x, mm[0][1]) for x in r2])
+    ref = 1.0 * (1.1 ** 2 / r2) ** 4.5 - mm[0][1].shift
+    assert np.allclose(mine, ref, rtol=1e-14, atol=1e-15)
     e, fix = g.total_energy()
     assert abs(e - o.energy) <= 1e-6 * abs(o.energy)
+    cb = O.Checkerboard(pos, sp, o.box, 1.0, mo, seed=2)
     st = pmc.mc_sweep(g, [_disp(pmc, 0.05)], nsweeps=4)
-    assert st.attempted[0] == 4 * len(pos) and 0.1 < st.accepted[0] / st.attempted[0] < 0.95
-    assert g.total_energy()[1] == st.energy_fix
+    att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 0, 4)
+    assert st.attempted[0] == att[0] == 4 * len(pos) and st.accepted[0] == acc[0]
+    assert 0.1 < st.accepted[0] / st.attempted[0] < 0.95
+    assert np.array_equal(g.position, cb.positions())
+    assert g.total_energy()[1] == st.energy_fix == cb.energy_fix
 
 
 def test_engines_interleave_without_manual_rebuilds(gpu):
