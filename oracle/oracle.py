@@ -312,6 +312,9 @@ class System:
         lib().orc_species_heads(self.h, _lp(h))
         return h
 
+    def set_temperature(self, T):
+        lib().orc_system_set_temperature(self.h, C.c_double(T))
+
     def mc_steps(self, pool, seed, chain, step0, nsteps):
         st = Stats()
         lib().orc_mc_steps_sequential(self.h, pool, len(pool), seed, chain, step0, nsteps, C.byref(st))

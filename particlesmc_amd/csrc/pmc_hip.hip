@@ -38,7 +38,7 @@ struct pmc_system {
     bool cells_built = false;
     int *d_sp_off = nullptr, *d_sp_ids = nullptr, *d_sp_heads = nullptr;
     bool species_list_built = false;
-    bool species_list_stale = false;   // checkerboard swaps changed species[] behind the SpeciesList
+    bool species_list_stale = false;   // throughput sweeps ran since the SpeciesList was built
     double *d_energy = nullptr;
     // binning scratch
     int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
@@ -1219,8 +1219,10 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
     for (int m = 0; m < npool; m++) {
         if (pool[m].kind == PMC_MOVE_SWAP && h->S < 2)
             return fail(h, PMC_ERR_BADARG, "DiscreteSwap needs at least two species");
-        if (pool[m].kind == PMC_MOVE_SWAP && nsweeps > 0) h->species_list_stale = true;
     }
+    // uniform hand-over rule: after throughput sweeps the next consumer of the SpeciesList sees SpeciesList(species)
+    // of the current state (swaps here are cell-local and do not maintain the global list)
+    if (h->S > 1 && nsweeps > 0) h->species_list_stale = true;
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
     const MovePool mp = make_pool(pool, npool);
     const int ncol = 1 << h->D;

@@ -128,6 +128,19 @@ class Atoms(Particles):
         pos = np.ascontiguousarray(value, dtype=np.float64)
         _lib.check(_lib.lib().pmc_upload(self._h, _dp(pos), None), self._h)
 
+    def upload(self, position, species=None):
+        """Replace positions (and, when given, species: the SpeciesList is then rebuilt as the reference
+        constructor builds it, src/utils.jl:36-49) on the device; the neighbour list is rebuilt on next use."""
+        pos = np.ascontiguousarray(position, dtype=np.float64)
+        if pos.shape != (self.N, self.d):
+            raise ValueError("position must be N x d")
+        sp = None
+        if species is not None:
+            sp = np.ascontiguousarray(species, dtype=np.int32)
+            if sp.shape != (self.N,):
+                raise AssertionError("length(position) == length(species)")
+        _lib.check(_lib.lib().pmc_upload(self._h, _dp(pos), None if sp is None else _ip(sp)), self._h)
+
     @property
     def species(self):
         sp = np.zeros(self.N, dtype=np.int32)

@@ -122,3 +122,145 @@ def test_random_configuration_both_engines(gpu, case, monkeypatch):
         assert np.array_equal(g.get_cells(), o2.cells())
         for s_ in range(1, S + 1):
             assert np.array_equal(g.species_ids(s_), o2.species_ids(s_))
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_operation_sequences(gpu, case):
+    """Random interleavings of throughput sweeps, reference-order sweeps, per-move verbs, temperature changes and
+    position/species round trips on ONE handle; after every operation the device state equals the oracle's."""
+    from oracle import oracle as O
+    pmc = gpu
+    rng = np.random.default_rng(5000 + case)
+    d = int(rng.choice([2, 3]))
+    n = int(rng.integers(26, 40)) if d == 2 else int(rng.integers(11, 14))
+    rho = float(rng.uniform(0.6, 1.2))
+    S = int(rng.choice([1, 2, 3]))
+    pos, sp, _ = lj_lattice(n, jitter=0.08 * rho ** (-1.0 / d), seed=100 + case, rho=rho, d=d)
+    N = len(pos)
+    if S > 1:
+        sp = rng.integers(1, S + 1, size=N).astype(np.int32)
+        sp[:S] = np.arange(1, S + 1)
+    T = float(rng.uniform(0.6, 1.8))
+    seed, chain = int(rng.integers(0, 2 ** 50)), int(rng.integers(0, 4))
+    mm, mo = _models(pmc, O, rng, S)
+    try:
+        g = pmc.System(pos, sp, rho, T, mm, seed=seed, chain=chain)
+    except (ValueError, RuntimeError) as e:
+        pytest.skip(f"case {case}: {e}")
+    pm, po = _pools(pmc, rng, S, g)
+    pool_o = O.make_pool(po)
+    o = O.System(pos, sp, rho, T, mo, O.LINKEDLIST)
+    assert g.energy[0] == o.energy
+
+    def same_state():
+        assert np.array_equal(g.position, o.positions()) and np.array_equal(g.species, o.species())
+        assert g.energy[0] == o.energy
+        assert np.array_equal(g.get_cells(), o.cells())
+        hg, lg = g.get_linked_list()
+        ho, lo = o.linked_list()
+        assert np.array_equal(hg, ho) and np.array_equal(lg, lo)
+        for s_ in range(1, S + 1):
+            assert np.array_equal(g.species_ids(s_), o.species_ids(s_))
+
+    for step in range(10):
+        op = rng.choice(["cb", "seq", "verbs", "temp", "roundtrip"], p=[0.3, 0.25, 0.25, 0.1, 0.1])
+        if op == "cb":
+            k = int(rng.integers(1, 3))
+            _, sweep0 = g.get_counters()
+            cb = O.Checkerboard(o.positions(), o.species(), o.box, T, mo, seed=seed, chain=chain)
+            st = pmc.mc_sweep(g, pm, nsweeps=k)
+            att, acc = cb.sweeps(pool_o, sweep0, k)
+            assert np.array_equal(st.attempted[: len(pm)], att) and np.array_equal(st.accepted[: len(pm)], acc)
+            assert np.array_equal(g.position, cb.positions()) and np.array_equal(g.species, cb.species())
+            assert st.energy_fix == cb.energy_fix == cb.total_energy_fix()
+            # hand-over to the reference-order side: a fresh System of the current state
+            o = O.System(cb.positions(), cb.species(), rho, T, mo, O.LINKEDLIST)
+            g.energy[0] = o.energy
+            same_state()
+        elif op == "seq":
+            step0, _ = g.get_counters()
+            st = pmc.mc_sweep(g, pm, nsweeps=1, mode="sequential")
+            att, acc = o.mc_steps(pool_o, seed, chain, step0, N)
+            assert np.array_equal(st.attempted[: len(pm)], att) and np.array_equal(st.accepted[: len(pm)], acc)
+            same_state()
+        elif op == "verbs":
+            for _ in range(6):
+                if S > 1 and rng.random() < 0.5:
+                    a, b = (int(x) for x in rng.choice(np.arange(1, S + 1), size=2, replace=False))
+                    ia, ib = int(rng.choice(g.species_ids(a))), int(rng.choice(g.species_ids(b)))
+                    act = pmc.DiscreteSwap(ia, ib, (a, b), (1, 1), 0.0)
+                    e = pmc.perform_action(g, act)
+                    r = o.swap_perform(ia, ib, a, b)
+                    assert (e[0], e[1], act.de) == r
+                    if rng.random() < 0.5:
+                        pmc.invert_action(act, g)
+                        pmc.revert_action(g, act)
+                        o.swap_revert(ib, ia, a, b, r[2])
+                else:
+                    i = int(rng.integers(1, N + 1))
+                    delta = rng.normal(0, 0.3, d)
+                    act = pmc.Displacement(i, delta, 0.0)
+                    e = pmc.perform_action(g, act)
+                    r = o.displacement_perform(i, delta)
+                    assert (e[0], e[1], act.de) == r
+                    if rng.random() < 0.5:
+                        pmc.invert_action(act, g)
+                        pmc.revert_action(g, act)
+                        o.displacement_revert(i, -delta, r[2])
+            same_state()
+        elif op == "temp":
+            T = float(rng.uniform(0.6, 1.8))
+            g.temperature = T
+            o.set_temperature(T)
+        else:
+            p_now, s_now = g.position, g.species           # download ... upload: a fresh list on both sides
+            g.upload(p_now, s_now)
+            o = O.System(p_now, s_now, rho, T, mo, O.LINKEDLIST)
+            g.build_neighbour_list()
+            g.energy[0] = o.energy
+            same_state()
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_dense_configurations(gpu, case, monkeypatch):
+    """Long cutoffs (3.4-4.2 sigma) at liquid density: 50-100 particles per cell (several proposal chunks per
+    cell), 1500-2500 candidates per neighbourhood (beyond the LDS capacity), 4-5 cells per side (wrapped
+    neighbourhoods everywhere), with every team width."""
+    from oracle import oracle as O
+    pmc = gpu
+    rng = np.random.default_rng(9000 + case)
+    n = int(rng.integers(17, 21))
+    rho = float(rng.uniform(0.9, 1.15))
+    S = int(rng.choice([1, 2]))
+    pos, sp, _ = lj_lattice(n, jitter=0.07, seed=300 + case, rho=rho)
+    N = len(pos)
+    if S > 1:
+        sp = rng.integers(1, 3, size=N).astype(np.int32)
+    L = (N / rho) ** (1.0 / 3.0)
+    rcut = float(min(rng.uniform(3.4, 4.2), L / 4.0 * 0.999))
+    T = float(rng.uniform(0.8, 1.6))
+    seed = int(rng.integers(0, 2 ** 60))
+    monkeypatch.setenv("PMC_TEAM", str([1, 2, 4][case % 3]))
+    arr = (O.Model * (S * S))()
+    mm = [[None] * S for _ in range(S)]
+    for i in range(S):
+        for j in range(i, S):
+            eps, sig = float(rng.uniform(0.7, 1.3)), float(rng.uniform(0.9, 1.0))
+            if case % 2:
+                p, o_ = pmc.SmoothLennardJones(eps, sig, rcut=rcut), O.smooth_lennard_jones(eps, sig, rcut)
+            else:
+                p, o_ = pmc.LennardJones(eps, sig, rcut=rcut), O.lennard_jones(eps, sig, rcut)
+            mm[i][j] = mm[j][i] = p
+            arr[i * S + j] = arr[j * S + i] = o_
+    mo = (arr, S)
+    g = pmc.System(pos, sp, rho, T, mm, seed=seed)
+    pm, po = _pools(pmc, rng, S, g)
+    o = O.System(pos, sp, rho, T, mo, O.LINKEDLIST)
+    assert np.array_equal(pmc.compute_energy_particles(g), o.energy_particles()) and g.energy[0] == o.energy
+    cb = O.Checkerboard(pos, sp, o.box, T, mo, seed=seed)
+    assert max(g.grid()[0]) <= 5
+    st = pmc.mc_sweep(g, pm, nsweeps=2)
+    att, acc = cb.sweeps(O.make_pool(po), 0, 2)
+    assert np.array_equal(st.attempted[: len(pm)], att) and np.array_equal(st.accepted[: len(pm)], acc)
+    assert np.array_equal(g.position, cb.positions()) and np.array_equal(g.species, cb.species())
+    assert st.energy_fix == cb.energy_fix == cb.total_energy_fix() == g.total_energy()[1]
