@@ -141,6 +141,10 @@ int pmc_init_energy(pmc_system *h, double *e);                  /* build list + 
 
 int pmc_species_count(pmc_system *h, int32_t sp, int64_t *n);    /* length(species_list.sp_ids[sp]) src/utils.jl:31-34 */
 int pmc_get_species_ids(pmc_system *h, int32_t sp, int64_t *ids);/* species_list.sp_ids[sp], current order */
+/* Hand-over rule: the sequential chain and the swap verbs maintain sp_ids exactly as src/moves.jl:170-185 does
+ * (swap-and-overwrite). PMC_CHECKERBOARD sweeps swap cell-locally and do not; after them the next consumer sees
+ * SpeciesList(species) of the current state (src/utils.jl:36-49: ids ascending per species), just as the linked
+ * list it sees is build_neighbour_list! of the current positions. */
 
 /* -- per-move verbs (batch of one; reference semantics incl. system.energy) */
 int pmc_displacement_perform(pmc_system *h, int64_t i, const double *delta,
