@@ -44,6 +44,14 @@ struct pmc_system {
     int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
     int *d_arrival = nullptr, *d_tile_sum = nullptr, *d_order = nullptr, *d_hist = nullptr;
     bool use_order = true;
+    // fused sweep (all colours in one launch, per-cell completion flags): flags, ticket, epoch
+    bool use_fused = true;
+    int fused_lpt = -1;          // longest-first order inside a fused launch: -1 auto (measured: wins when a colour
+                                 // has more cells than ~1.6x the resident workgroups), 0 off, 1 on
+    unsigned int *d_done = nullptr;
+    unsigned long long *d_ticket = nullptr;
+    unsigned int epoch = 0;
+    unsigned long long ticket_next = 0;
     int team = 1;                // wavefronts that share one cell in k_cb_pass (1, 2 or 4)
     double maxcut = 0.0;
     bool use_filter = true;
@@ -51,6 +59,7 @@ struct pmc_system {
     bool pending = false;
     int pending_mode = 0;
     int64_t pending_nsweeps = 0, pending_timed = 0;
+    int pending_launches_per_sweep = 0;
     unsigned long long *h_stats = nullptr;   // pinned host copy of d_stats
     pmc_stats done_stats{};
     int *d_start_ref = nullptr, *d_ids_ref = nullptr;
@@ -428,6 +437,12 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         CR(hipMalloc(&h->d_sy, N * sizeof(double)));
         CR(hipMalloc(&h->d_sz, N * sizeof(double)));
         CR(hipMalloc(&h->d_ssp, N));
+        CR(hipMalloc(&h->d_done, (size_t)h->ncell_mc * sizeof(unsigned int)));
+        CR(hipMemset(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int)));
+        CR(hipMalloc(&h->d_ticket, 16));
+        CR(hipMemset(h->d_ticket, 0, 16));
+        if (const char *e = getenv("PMC_NO_FUSED")) h->use_fused = !(e[0] == '1');
+        if (const char *e = getenv("PMC_FUSED_LPT")) h->fused_lpt = (e[0] == '1') ? 1 : 0;
     }
     CR(hipMalloc(&h->d_stats, 32 * sizeof(unsigned long long)));
     CR(hipMemset(h->d_stats, 0, 32 * sizeof(unsigned long long)));
@@ -446,7 +461,7 @@ extern "C" int pmc_destroy(pmc_system *h)
     void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
-                    h->d_sz, h->d_ssp, h->d_stats, h->d_result};
+                    h->d_sz, h->d_ssp, h->d_stats, h->d_result, h->d_done, h->d_ticket};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
@@ -999,6 +1014,7 @@ static size_t cb_lds_bytes(const pmc_system *h)
 {
     size_t b = (pmc_lds_wave_bytes(cb_cap(h)) + 15) & ~(size_t)15;
     if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
+    if (const char *e = getenv("PMC_LDS_PAD")) b += (size_t)atoi(e);   // occupancy experiments
     return b;
 }
 
@@ -1054,6 +1070,8 @@ static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
 {
     if (st[17] & 1ull)
         return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity");
+    if (st[17] & 2ull)
+        return fail(h, PMC_ERR_STATE, "fused sweep: a cell's completion flag was never seen (state is invalid; upload again)");
     return PMC_OK;
 }
 
@@ -1240,12 +1258,17 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
         for (int q = 0; q < h->D; q++) shift[q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
         rc = mc_bin(h, shift);
         if (rc) return rc;
-        if (h->use_order) {
+        // fused launches stream the cells of every colour in the same spatial order, so that the cells a
+        // workgroup waits for were ticketed long before it (a pipeline with one tail per sweep); separate
+        // colour launches sort each colour longest-first to shorten their eight tails
+        const bool fused = h->use_fused;
+        const bool lpt = h->use_order && (!fused || h->fused_lpt == 1 || (h->fused_lpt < 0 && nactive > 4096));
+        if (lpt) {
             rc = mc_order(h, nactive);
             if (rc) return rc;
         }
         CbArgs a = cb_args(h);
-        a.order = h->use_order ? h->d_order : nullptr;
+        a.order = lpt ? h->d_order : nullptr;
         a.s_lo = s_lo; a.s_hi = s_hi;
         a.pool = mp;
         a.all_cells = 0;
@@ -1261,10 +1284,28 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
             }
             HIPCHK(h, hipEventRecord(h->pass_ev[2 * sw], h->stream));
         }
-        for (int col = 0; col < ncol; col++) {
-            a.colour = col;
-            DISPATCH_CB(h, nactive, lds, a);
+        if (fused) {
+            // one launch for all colours; cells wait on the completion flags of their lower-colour neighbours
+            if (h->epoch == 0xffffffffu) {
+                HIPCHK(h, hipMemsetAsync(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int), h->stream));
+                h->epoch = 0;
+            }
+            a.fused = 1;
+            a.epoch = ++h->epoch;
+            a.done = h->d_done;
+            a.ticket = h->d_ticket;
+            a.ticket_base = h->ticket_next;
+            a.colour = 0;
+            const int grid = ncol * nactive;
+            h->ticket_next += (unsigned long long)grid;
+            DISPATCH_CB(h, grid, lds, a);
             launches++;
+        } else {
+            for (int col = 0; col < ncol; col++) {
+                a.colour = col;
+                DISPATCH_CB(h, nactive, lds, a);
+                launches++;
+            }
         }
         if (timed) {
             HIPCHK(h, hipEventRecord(h->pass_ev[2 * sw + 1], h->stream));
@@ -1274,7 +1315,7 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    (void)launches;
+    h->pending_launches_per_sweep = nsweeps > 0 ? (int)(launches / nsweeps) : ncol;
     h->pending = true;
     h->pending_mode = PMC_CHECKERBOARD;
     h->pending_nsweeps = nsweeps;
@@ -1288,7 +1329,6 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
     h->pending = false;
     const unsigned long long *st = h->h_stats;
     const int64_t nsweeps = h->pending_nsweeps, timed_sweeps = h->pending_timed;
-    const int ncol = 1 << h->D;
     float pass_ms = 0.f;
     h->sweep_ctr += (uint64_t)nsweeps;
     h->cells_built = false;
@@ -1310,7 +1350,7 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
             pass_ms += t;
         }
         out->sweep_kernel_ms = pass_ms;
-        out->sweep_kernel_launches = timed_sweeps * ncol;
+        out->sweep_kernel_launches = timed_sweeps * h->pending_launches_per_sweep;
         out->energy = h->energy;
         out->energy_fix = h->e_fix;
     }

@@ -665,7 +665,33 @@ struct CbArgs {
     const int *order;          // per colour: cells sorted by population, descending (may be null)
     unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
     double *e_particle;        // optional per-particle energies (id order)
+    // fused sweep: all 2^d colours in ONE launch, ordered by per-cell completion flags
+    int fused;                 // 1: grid = 2^d * nactive workgroups, colour taken from the ticket
+    unsigned int epoch;        // value a cell's flag takes when its visit of this sweep is complete
+    unsigned int *done;        // [ncell] completion flags (agent-scope stores / polls)
+    unsigned long long *ticket;    // monotonic workgroup ticket; this launch owns [ticket_base, ticket_base + grid)
+    unsigned long long ticket_base;
 };
+
+// Agent-scope accesses of the data that workgroups of one fused launch hand to each other (the
+// cell-sorted coordinates and species): sc1 loads bypass the CU's L1, sc1 stores write through
+// (cdna_hip_programming.md Guideline 16, R1).  Outside a fused launch they are merely uncached in L1.
+__device__ __forceinline__ double ld_agent(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned char ld_agent(const unsigned char *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned char *p, unsigned char v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // bijective remap so that blocks sharing an XCD (b % 8) work on one contiguous slab of cells
 // (used by k_total_energy and when the longest-first order is switched off)
@@ -806,10 +832,10 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
             tx[r] = ty[r] = tz[r] = 0.0;
             ts[r] = 0;
             if ((r % NW) == wv && lane < c0) {
-                tx[r] = a.sx[s0 + lane];
-                ty[r] = a.sy[s0 + lane];
-                if (D == 3) tz[r] = a.sz[s0 + lane];
-                if (MULTI) ts[r] = a.ssp[s0 + lane];
+                tx[r] = ld_agent(a.sx + s0 + lane);
+                ty[r] = ld_agent(a.sy + s0 + lane);
+                if (D == 3) tz[r] = ld_agent(a.sz + s0 + lane);
+                if (MULTI) ts[r] = ld_agent(a.ssp + s0 + lane);
             }
         }
 #pragma unroll
@@ -828,10 +854,10 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
             const int o0 = __builtin_amdgcn_readlane(seg_off, r);
             for (int l = PMC_WAVE + lane; l < c0; l += PMC_WAVE) {
                 if ((r % NW) == wv && o0 + l < lim) {
-                    h.cx[o0 + l] = a.sx[s0 + l];
-                    h.cy[o0 + l] = a.sy[s0 + l];
-                    if (D == 3) h.cz[o0 + l] = a.sz[s0 + l];
-                    if (MULTI) h.csp[o0 + l] = a.ssp[s0 + l];
+                    h.cx[o0 + l] = ld_agent(a.sx + s0 + l);
+                    h.cy[o0 + l] = ld_agent(a.sy + s0 + l);
+                    if (D == 3) h.cz[o0 + l] = ld_agent(a.sz + s0 + l);
+                    if (MULTI) h.csp[o0 + l] = ld_agent(a.ssp + s0 + l);
                 }
             }
         }
@@ -841,10 +867,10 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
         __syncthreads();
         for (int k = tid; k < lim; k += TS) {
             int src = nbh_find(h, k);
-            h.cx[k] = a.sx[src];
-            h.cy[k] = a.sy[src];
-            if (D == 3) h.cz[k] = a.sz[src];
-            if (MULTI) h.csp[k] = a.ssp[src];
+            h.cx[k] = ld_agent(a.sx + src);
+            h.cy[k] = ld_agent(a.sy + src);
+            if (D == 3) h.cz[k] = ld_agent(a.sz + src);
+            if (MULTI) h.csp[k] = ld_agent(a.ssp + src);
         }
         __syncthreads();
     }
@@ -1014,10 +1040,10 @@ __device__ __forceinline__ void nbh_load(const CbArgs &a, const WaveNbh &h, int 
         sj = MULTI ? (int)h.csp[k] : 0;
     } else {
         int src = nbh_find(h, k);
-        xj = a.sx[src];
-        yj = a.sy[src];
-        zj = (D == 3) ? a.sz[src] : 0.0;
-        sj = MULTI ? (int)a.ssp[src] : 0;
+        xj = ld_agent(a.sx + src);
+        yj = ld_agent(a.sy + src);
+        zj = (D == 3) ? ld_agent(a.sz + src) : 0.0;
+        sj = MULTI ? (int)ld_agent(a.ssp + src) : 0;
     }
 }
 
@@ -1184,11 +1210,11 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
 }
 
 template <int D>
-__device__ __forceinline__ bool decode_cell(const CbArgs &a, int aidx, int cell[3], int &lin)
+__device__ __forceinline__ bool decode_cell(const CbArgs &a, int colour, int aidx, int cell[3], int &lin)
 {
     int r = aidx;
     if (!a.all_cells && a.order) {
-        lin = a.order[a.colour * a.nactive + aidx];
+        lin = a.order[colour * a.nactive + aidx];
         r = lin;
 #pragma unroll
         for (int q = D - 1; q >= 0; q--) { cell[q] = r % a.n[q]; r /= a.n[q]; }
@@ -1200,7 +1226,7 @@ __device__ __forceinline__ bool decode_cell(const CbArgs &a, int aidx, int cell[
     } else {
 #pragma unroll
         for (int q = D - 1; q >= 0; q--) {
-            cell[q] = 2 * (r % a.half[q]) + ((a.colour >> q) & 1);
+            cell[q] = 2 * (r % a.half[q]) + ((colour >> q) & 1);
             r /= a.half[q];
         }
     }
@@ -1221,7 +1247,7 @@ __global__ __launch_bounds__(64) void k_total_energy(CbArgs a)
     int aidx = xcd_remap(blockIdx.x, gridDim.x);
     if (aidx >= a.nactive) return;
     int cell[3] = {0, 0, 0}, lin;
-    decode_cell<D>(a, aidx, cell, lin);
+    decode_cell<D>(a, a.colour, aidx, cell, lin);
     h.lin = lin;
     stage_neighbourhood<D, MULTI>(a, cell, h);
     if (h.nc == 0) return;
@@ -1265,6 +1291,58 @@ __device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
     return n;
 }
 
+// Fused sweep: a cell of colour c may start once every neighbour cell of a LOWER colour has finished
+// its visit of this sweep (those are the only cells that wrote coordinates this cell stages; cells of a
+// higher colour start after this one has published).  Tickets are handed out in colour order, so a
+// workgroup only ever waits for workgroups that already hold a ticket, i.e. are resident or finished:
+// no deadlock whatever the dispatch order.  Wavefront 0 polls (relaxed agent-scope loads, one flag
+// per lane), the barrier releases the other wavefronts; the staged data is then read with sc1 loads.
+// A bounded spin turns a lost flag into an error code (stats[17] bit 1) instead of a hang.
+template <int D, int NW>
+__device__ __forceinline__ void wait_lower_colours(const CbArgs &a, int colour, const int cell[3])
+{
+    constexpr int NN = (D == 3) ? 27 : 9;
+    const int lane = wave_lane();
+    if (team_wave<NW>() == 0) {
+        bool need = false;
+        int lin2 = 0;
+        if (lane < NN) {
+            int r = lane, mask = 0;
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                const int o = (r % 3) - 1;
+                r /= 3;
+                int cq = cell[q] + o;
+                if (cq < 0) cq += a.n[q];
+                if (cq >= a.n[q]) cq -= a.n[q];
+                lin2 = lin2 * a.n[q] + cq;
+                if (o != 0) mask |= 1 << q;
+            }
+            need = (mask != 0) && ((colour ^ mask) < colour);
+        }
+        unsigned spins = 0;
+        for (;;) {
+            unsigned v = a.epoch;
+            if (need) v = __hip_atomic_load(a.done + lin2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(v != a.epoch) == 0ull) break;
+            if (++spins > (1u << 22)) {
+                if (lane == 0) atomicOr(&a.stats[17], 2ull);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+}
+
+// publish the end of a cell visit: every wavefront drains its stores, then one lane sets the flag
+__device__ __forceinline__ void publish_done(const CbArgs &a, int lin, bool leader)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (leader) __hip_atomic_store(a.done + lin, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One colour pass of the checkerboard sweep: one workgroup (NW wavefronts) per active cell.
 // The cell's n_c proposal slots run in order against the LDS-resident neighbourhood, the
 // wavefronts splitting every candidate loop; Displacement slots that would leave the cell are
@@ -1279,15 +1357,30 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
     const int lane = wave_lane();
     const int tid = team_tid<NW>(), wv = team_wave<NW>();
     constexpr int TS = NW * PMC_WAVE;
-    int aidx = a.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    if (aidx >= a.nactive) return;
+    int aidx, colour = a.colour;
+    if (a.fused) {
+        // ticket order = colour order (see wait_lower_colours)
+        if (tid == 0) h.flag[2] = (int)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
+        __syncthreads();
+        const int t = h.flag[2];
+        colour = t / a.nactive;
+        aidx = t - colour * a.nactive;
+    } else {
+        aidx = a.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+        if (aidx >= a.nactive) return;
+    }
     int cell[3] = {0, 0, 0}, lin;
-    decode_cell<D>(a, aidx, cell, lin);
+    decode_cell<D>(a, colour, aidx, cell, lin);
     h.lin = lin;
+    if (a.fused && colour > 0) wait_lower_colours<D, NW>(a, colour, cell);
     stage_neighbourhood<D, MULTI, NW>(a, cell, h);
     const int nc = h.nc;
-    if (nc == 0) return;
-    if (h.ctr + nc > h.cap) { if (tid == 0) atomicOr(&a.stats[17], 1ull); return; }
+    if (nc == 0) { if (a.fused) publish_done(a, lin, tid == 0); return; }
+    if (h.ctr + nc > h.cap) {
+        if (tid == 0) atomicOr(&a.stats[17], 1ull);
+        if (a.fused) publish_done(a, lin, tid == 0);
+        return;
+    }
     compact_candidates<D, MULTI, NW>(a, h);
     cell_bounds<D>(a, h);
 #ifdef PMC_DEBUG_COUNT   // profiling builds only
@@ -1371,7 +1464,9 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         const double r2n = NOWRAP ? dist2_nowrap<D>(xn, yn, zn, xj, yj, zj) : dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
                         if (k != pc) {
                             if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
+#ifndef PMC_DEBUG_NOOLD   // profiling builds only: price the old-position evaluation
                             if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+#endif
                         }
                     };
                     // LDS-resident candidates, two per lane and trip: both loads are issued before the first
@@ -1455,20 +1550,21 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
         for (int k = tid; k < nc; k += TS) {
             const int kc = h.ctr + k;
             int id = a.ids[h.k0 + k];
-            a.sx[h.k0 + k] = h.cx[kc];
-            a.sy[h.k0 + k] = h.cy[kc];
+            st_agent(a.sx + h.k0 + k, h.cx[kc]);
+            st_agent(a.sy + h.k0 + k, h.cy[kc]);
             a.pos[(size_t)id * D + 0] = h.cx[kc];
             a.pos[(size_t)id * D + 1] = h.cy[kc];
             if (D == 3) {
-                a.sz[h.k0 + k] = h.cz[kc];
+                st_agent(a.sz + h.k0 + k, h.cz[kc]);
                 a.pos[(size_t)id * D + 2] = h.cz[kc];
             }
             if (MULTI) {
-                a.ssp[h.k0 + k] = h.csp[kc];
+                st_agent(a.ssp + h.k0 + k, h.csp[kc]);
                 a.species[id] = (int)h.csp[kc];
             }
         }
     }
+    if (a.fused) publish_done(a, lin, tid == 0);
     if (tid == 0) {
         if (ONE) {
             atomicAdd(&a.stats[0], att1);
