@@ -421,11 +421,12 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     if (const char *e = getenv("PMC_NO_ORDER")) h->use_order = !(e[0] == '1');
     {
         // wavefronts per cell: small systems have too few cells per colour to fill 256 CUs with one
-        // wavefront each (measured: N=32768 +54 % with 4); from N=2.6e5 to 8e6 two wavefronts per cell
-        // beat one by 5-15 % (half the LDS per wavefront, half the latency of a cell visit)
+        // wavefront each; teams of 4 (speculative slot batches for single-Displacement pools) win up to
+        // ~1500 cells per colour (N=32768 +30 %, N=110592 +23 %, N=175616 +11 % over teams of 2), above
+        // that two wavefronts per cell (half the LDS per wavefront, half the latency of a cell visit)
         long long nact = 1;
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
-        h->team = (nact <= 512) ? 4 : 2;
+        h->team = (nact <= 1536) ? 4 : 2;
         if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4) h->team = t; }
     }
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
@@ -1021,7 +1022,8 @@ static size_t cb_lds_bytes(const pmc_system *h)
 // k_cb_pass additionally carries the team size NW (wavefronts per cell)
 #define DISPATCH_CB_ONE(DD, KK, NWV, h, grid, lds, args)                                                        \
     if (!done_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV) {                                        \
-        if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
         else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
         else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
         done_ = true;                                                                                           \

@@ -18,6 +18,7 @@
 #endif
 #define PMC_REF_IDS 2048     // neighbourhood size (ids) the ordered-energy LDS buffer holds (8 KB: 20 wavefronts per CU)
 #define PMC_MAXNN 27
+#define PMC_REC 10           // doubles per slot record: old xyz, new xyz, dE, T ln u, LDS slot, inside
 
 // ------------------------------------------------------------------------------
 // binning: cell index -> CSR (cell_start, ids ascending inside each cell)
@@ -720,6 +721,7 @@ struct WaveNbh {
     bool bounds;   // lo/hi below are valid: "stays in the cell" is  lo_a <= x_a < hi_a
     double lo[3], hi[3];
     double *part;  // [8] per-wavefront partial sums (workgroups of several wavefronts)
+    double *rec;   // [4][PMC_REC] records of the speculatively evaluated slots of one batch
     int *flag;     // [4] workgroup flags
     int *cnt;      // [16] per-move attempted / accepted counters of this cell visit
 };
@@ -1184,7 +1186,7 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
 
 __host__ __device__ inline size_t pmc_lds_wave_bytes(int cap)
 {
-    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + 4 * 4 + 16 * 4 + 2 * 32 * 4 + cap;
+    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + PMC_REC * 4 * 8 + 4 * 4 + 16 * 4 + 2 * 32 * 4 + cap;
 }
 
 template <int D, bool MULTI>
@@ -1196,7 +1198,8 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cz = h.cy + h.cap;
     h.cfl = h.cz + h.cap;
     h.part = h.cfl + 3 * PMC_CFL;
-    h.flag = reinterpret_cast<int *>(h.part + 8);
+    h.rec = h.part + 8;
+    h.flag = reinterpret_cast<int *>(h.rec + PMC_REC * 4);
     h.cnt = h.flag + 4;
     h.segoff = h.cnt + 16;
     h.segsrc = h.segoff + 32;
@@ -1357,6 +1360,9 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
     const int lane = wave_lane();
     const int tid = team_tid<NW>(), wv = team_wave<NW>();
     constexpr int TS = NW * PMC_WAVE;
+    // speculative batches pay off where a cell visit is latency-bound (few cells per colour, teams of 4:
+    // N=32768 +22 %); with teams of 2 the chip is VALU-bound and the shared candidate loop is as fast
+    constexpr bool BATCH = ONE && (NW == 4);
     int aidx, colour = a.colour;
     if (a.fused) {
         // ticket order = colour order (see wait_lower_colours)
@@ -1427,6 +1433,171 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
 #ifdef PMC_DEBUG_NOSLOTS   // profiling builds only: price the staging alone
         nslots = 0;
 #endif
+        if constexpr (BATCH) {
+            // Speculative batches (single-Displacement pools, NW > 1): wavefront w evaluates slot s0 + w
+            // ALONE over all candidates against the state before the batch; wavefront 0 then resolves the
+            // batch in slot order.  An earlier accepted move i changes one candidate of slot j, so
+            //   dE_j' = dE_j - [q(new_j,old_i) - q(old_j,old_i)] + [q(new_j,new_i) - q(old_j,new_i)]
+            // (four pair terms, every term and sum exact, hence bit-identical to the sequential
+            // evaluation); a slot that re-selects an already moved particle ends the batch and is
+            // evaluated again in the next one.  Two barriers per NW slots, no shared reduction.
+            int s0 = 0;
+            while (s0 < nslots) {
+                const int K = min(NW, nslots - s0);
+                if (wv < K) {
+                    const int my = __builtin_amdgcn_readfirstlane(s0 + wv);
+                    const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, my);
+                    const int pc = h.ctr + (int)mulhi32(w1, (uint32_t)nc);
+                    const double xo = h.cx[pc], yo = h.cy[pc], zo = (D == 3) ? h.cz[pc] : 0.0;
+                    const double xn = xo + readlane_double(g_dx, my);
+                    const double yn = yo + readlane_double(g_dy, my);
+                    const double zn = (D == 3) ? zo + readlane_double(g_dz, my) : 0.0;
+                    bool inside;
+                    if (h.bounds) {
+                        inside = (xn >= h.lo[0]) && (xn < h.hi[0]) && (yn >= h.lo[1]) && (yn < h.hi[1]);
+                        if (D == 3) inside = inside && (zn >= h.lo[2]) && (zn < h.hi[2]);
+                    } else {
+                        bool bad = false;
+                        if (lane < D) {
+                            const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
+                            const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
+                            bad = mc_coord<D>(xs_n, my_shift, my_w) != mc_coord<D>(xs_o, my_shift, my_w);
+                        }
+                        inside = (__ballot(bad) == 0ull);
+                    }
+                    double de = 0.0;
+                    if (inside) {
+                        const int si = MULTI ? (int)h.csp[pc] : 0;
+                        double dsum = 0.0;
+                        auto term = [&](int k, double xj, double yj, double zj, int sj, auto nowrap_tag) {
+                            constexpr bool NOWRAP = decltype(nowrap_tag)::value;
+                            const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
+                            const double r2o = NOWRAP ? dist2_nowrap<D>(xo, yo, zo, xj, yj, zj) : dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
+                            const double r2n = NOWRAP ? dist2_nowrap<D>(xn, yn, zn, xj, yj, zj) : dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
+                            if (k != pc) {
+                                if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
+                                if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                            }
+                        };
+                        auto sweep_lds = [&](auto nowrap_tag) {
+                            int k = lane;
+                            for (; k + PMC_WAVE < lim; k += 2 * PMC_WAVE) {
+                                const int k2 = k + PMC_WAVE;
+                                const double xa = h.cx[k], ya = h.cy[k], za = (D == 3) ? h.cz[k] : 0.0;
+                                const double xb = h.cx[k2], yb = h.cy[k2], zb = (D == 3) ? h.cz[k2] : 0.0;
+                                const int sa_ = MULTI ? (int)h.csp[k] : 0, sb_ = MULTI ? (int)h.csp[k2] : 0;
+                                term(k, xa, ya, za, sa_, nowrap_tag);
+                                term(k2, xb, yb, zb, sb_, nowrap_tag);
+                            }
+                            if (k < lim) term(k, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0, MULTI ? (int)h.csp[k] : 0, nowrap_tag);
+                        };
+                        if (h.nowrap) sweep_lds(std::true_type{}); else sweep_lds(std::false_type{});
+                        for (int k = lim + lane; k < h.ncand; k += PMC_WAVE) {
+                            double xj, yj, zj;
+                            int sj;
+                            nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
+                            term(k, xj, yj, zj, sj, std::false_type{});
+                        }
+                        de = wave_sum_exact(dsum);
+                    }
+                    if (lane == 0) {
+                        double *r = h.rec + wv * PMC_REC;
+                        r[0] = xo; r[1] = yo; r[2] = zo;
+                        r[3] = xn; r[4] = yn; r[5] = zn;
+                        r[6] = de;
+                        r[7] = readlane_double(g_tlnu, my);
+                        r[8] = (double)pc;
+                        r[9] = inside ? 1.0 : 0.0;
+                    }
+                }
+                __syncthreads();           // every evaluation has read the pre-batch state; records are posted
+                if (wv == 0) {
+                    // pair terms, lane-parallel: lane = 4 * pair(i,j) + t,  pair(i,j) = j (j - 1) / 2 + i,  i < j < K
+                    double c01 = 0, c02 = 0, c12 = 0, c03 = 0, c13 = 0, c23 = 0;
+                    if (K > 1) {
+                        const int pr = lane >> 2, tt = lane & 3;
+                        const int pj = (pr >= 3) ? 3 : ((pr >= 1) ? 2 : 1);
+                        const int pi = pr - ((pj * (pj - 1)) >> 1);
+                        double v = 0.0;
+                        if (lane < 24 && pj < K) {
+                            const double *ri = h.rec + pi * PMC_REC, *rj = h.rec + pj * PMC_REC;
+                            const int oi = (tt & 2) ? 0 : 3, oj = (tt & 1) ? 0 : 3;   // old or new coordinates
+                            const double xi_ = ri[oi], yi_ = ri[oi + 1], zi_ = ri[oi + 2];
+                            const double xj_ = rj[oj], yj_ = rj[oj + 1], zj_ = rj[oj + 2];
+                            const int sci = MULTI ? (int)h.csp[(int)ri[8]] : 0, scj = MULTI ? (int)h.csp[(int)rj[8]] : 0;
+                            const DevModel &mm = MULTI ? tab[scj * a.S + sci] : a.m0;
+                            const double r2 = h.nowrap ? dist2_nowrap<D>(xj_, yj_, zj_, xi_, yi_, zi_) : dist2_fast<D>(a, xj_, yj_, zj_, xi_, yi_, zi_);
+                            if (!(r2 > mm.rcut2)) v = dev_quant(pot_kind<KIND>(r2, mm));
+                            if (tt == 1 || tt == 2) v = -v;
+                        }
+                        v = dpp_add<0xB1>(v);
+                        v = dpp_add<0x4E>(v);      // every lane of a quad holds the quad's (exact) sum
+                        c01 = readlane_double(v, 0);
+                        if (NW > 2) {
+                            c02 = readlane_double(v, 4);
+                            c12 = readlane_double(v, 8);
+                            c03 = readlane_double(v, 12);
+                            c13 = readlane_double(v, 16);
+                            c23 = readlane_double(v, 20);
+                        }
+                    }
+                    // this lane's record (lanes 0..K-1), then the decisions in slot order
+                    const int jl = min(lane, NW - 1);
+                    const double *rl = h.rec + jl * PMC_REC;
+                    const double l_de = rl[6], l_tlnu = rl[7];
+                    const int l_pc = (int)rl[8];
+                    const bool l_in = rl[9] != 0.0;
+                    bool acc_[4] = {false, false, false, false};
+                    double dec_[4] = {0, 0, 0, 0};
+                    int nres = 0;
+                    bool stop = false;
+#pragma unroll
+                    for (int j = 0; j < NW; j++) {
+                        if (j < K && !stop) {
+                            const int pcj = __builtin_amdgcn_readlane(l_pc, j);
+                            double dej = readlane_double(l_de, j);
+                            bool conflict = false;
+#pragma unroll
+                            for (int i = 0; i < j; i++) {
+                                if (acc_[i]) {
+                                    conflict = conflict || (__builtin_amdgcn_readlane(l_pc, i) == pcj);
+                                    const double cij = (j == 1) ? c01 : ((j == 2) ? (i == 0 ? c02 : c12) : (i == 0 ? c03 : (i == 1 ? c13 : c23)));
+                                    dej += cij;
+                                }
+                            }
+                            if (conflict) {
+                                stop = true;
+                            } else {
+                                const bool inj = (__ballot(l_in && lane == j) != 0ull);
+                                const bool okj = inj && (readlane_double(l_tlnu, j) < -dej);
+                                acc_[j] = okj;
+                                dec_[j] = dej;
+                                nres = j + 1;
+                            }
+                        }
+                    }
+                    unsigned accmask = 0;
+#pragma unroll
+                    for (int j = 0; j < NW; j++) {
+                        if (acc_[j]) {
+                            accmask |= 1u << j;
+                            acc1 += 1;
+                            efix += (long long)(dec_[j] * PMC_FIX);
+                        }
+                    }
+                    att1 += (unsigned long long)nres;
+                    if (lane < NW && ((accmask >> lane) & 1u)) {
+                        h.cx[l_pc] = rl[3];
+                        h.cy[l_pc] = rl[4];
+                        if (D == 3) h.cz[l_pc] = rl[5];
+                    }
+                    if (lane == 0) h.flag[3] = nres;
+                }
+                __syncthreads();           // accepted moves and the number of resolved slots are visible
+                s0 += h.flag[3];
+            }
+            dirty = true;
+        } else
         for (int s = 0; s < nslots; s++) {
             const int m = ONE ? 0 : __builtin_amdgcn_readlane(g_m, s);
             const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, s);
