@@ -44,6 +44,10 @@ struct pmc_system {
     int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
     int *d_arrival = nullptr, *d_tile_sum = nullptr, *d_order = nullptr, *d_hist = nullptr;
     bool use_order = true;
+    // proposal slots of the current sweep (k_mc_slots)
+    double *d_slot_f = nullptr;          // [4][N]: T ln u, dx, dy, dz
+    uint32_t *d_slot_w = nullptr;        // [2][N]: particle word, second swap word
+    unsigned char *d_slot_m = nullptr;   // [N]: move index
     // fused sweep (all colours in one launch, per-cell completion flags): flags, ticket, epoch
     bool use_fused = true;
     int fused_lpt = -1;          // longest-first order inside a fused launch: -1 auto (measured: wins when a colour
@@ -438,6 +442,9 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         CR(hipMalloc(&h->d_sy, N * sizeof(double)));
         CR(hipMalloc(&h->d_sz, N * sizeof(double)));
         CR(hipMalloc(&h->d_ssp, N));
+        CR(hipMalloc(&h->d_slot_f, 4 * N * sizeof(double)));
+        CR(hipMalloc(&h->d_slot_w, 2 * N * sizeof(uint32_t)));
+        CR(hipMalloc(&h->d_slot_m, N));
         CR(hipMalloc(&h->d_done, (size_t)h->ncell_mc * sizeof(unsigned int)));
         CR(hipMemset(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int)));
         CR(hipMalloc(&h->d_ticket, 16));
@@ -462,7 +469,7 @@ extern "C" int pmc_destroy(pmc_system *h)
     void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
-                    h->d_sz, h->d_ssp, h->d_stats, h->d_result, h->d_done, h->d_ticket};
+                    h->d_sz, h->d_ssp, h->d_stats, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
@@ -1271,6 +1278,15 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
         }
         CbArgs a = cb_args(h);
         a.order = lpt ? h->d_order : nullptr;
+        {
+            const size_t Ns = (size_t)h->N;
+            SlotOut so{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
+            const int nbs = nblk(h->N, 256);
+            if (h->D == 3) hipLaunchKernelGGL(k_mc_slots<3>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, s_lo, s_hi, h->key[0], h->key[1], h->p.temperature, mp, so);
+            else hipLaunchKernelGGL(k_mc_slots<2>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, s_lo, s_hi, h->key[0], h->key[1], h->p.temperature, mp, so);
+            a.slot_tlnu = so.tlnu; a.slot_dx = so.dx; a.slot_dy = so.dy; a.slot_dz = so.dz;
+            a.slot_w1 = so.w1; a.slot_w2 = so.w2; a.slot_m = so.m;
+        }
         a.s_lo = s_lo; a.s_hi = s_hi;
         a.pool = mp;
         a.all_cells = 0;

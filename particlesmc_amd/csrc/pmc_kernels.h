@@ -641,6 +641,41 @@ __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
 // throughput engine
 // ------------------------------------------------------------------------------
 
+// The random numbers of every proposal slot of one sweep: slot t of cell c is the
+// cell-sorted index k = start[c] + t, so one thread per k generates all N slots with every lane busy
+// (inside k_cb_pass the same arithmetic ran on ~18 of 64 lanes, once per wavefront of the team).
+struct SlotOut {
+    double *tlnu, *dx, *dy, *dz;
+    uint32_t *w1, *w2;
+    unsigned char *m;
+};
+template <int D>
+__global__ __launch_bounds__(256) void k_mc_slots(int N, const int *__restrict__ ids, const int *__restrict__ cell_of,
+                                                  const int *__restrict__ start, uint32_t s_lo, uint32_t s_hi,
+                                                  uint32_t key0, uint32_t key1, double temperature, MovePool pool,
+                                                  SlotOut o)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const int lin = cell_of[ids[k]];
+    const int t = k - start[lin];
+    uint32_t R[4], Q[4];
+    philox4x32((uint32_t)lin, (uint32_t)t, s_lo, s_hi | ((uint32_t)TAG_SLOT0 << 24), key0, key1, R);
+    philox4x32((uint32_t)lin, (uint32_t)t, s_lo, s_hi | ((uint32_t)TAG_SLOT1 << 24), key0, key1, Q);
+    const int m = (pool.npool == 1) ? 0 : select_move(pool, R[0]);
+    double z[4];
+    box_muller(Q[0], Q[1], &z[0], &z[1]);
+    box_muller(Q[2], Q[3], &z[2], &z[3]);
+    const double sg = pool.sigma[m];
+    o.tlnu[k] = temperature * det_log(uniform53(R[2], R[3]));
+    o.dx[k] = sg * z[0];
+    o.dy[k] = sg * z[1];
+    if (D == 3) o.dz[k] = sg * z[2];
+    o.w1[k] = R[1];
+    o.w2[k] = Q[0];
+    o.m[k] = (unsigned char)m;
+}
+
 struct CbArgs {
     int n[3];
     int half[3];
@@ -666,6 +701,10 @@ struct CbArgs {
     const int *order;          // per colour: cells sorted by population, descending (may be null)
     unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
     double *e_particle;        // optional per-particle energies (id order)
+    // proposal slots of this sweep, generated lane-dense by k_mc_slots (index = cell-sorted slot start[cell] + t)
+    const double *slot_tlnu, *slot_dx, *slot_dy, *slot_dz;
+    const uint32_t *slot_w1, *slot_w2;
+    const unsigned char *slot_m;
     // fused sweep: all 2^d colours in ONE launch, ordered by per-cell completion flags
     int fused;                 // 1: grid = 2^d * nactive workgroups, colour taken from the ticket
     unsigned int epoch;        // value a cell's flag takes when its visit of this sweep is complete
@@ -1414,20 +1453,14 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
         uint32_t g_w1 = 0, g_w2 = 0;
         double g_dx = 0, g_dy = 0, g_dz = 0, g_tlnu = 0;
         if (t < nc) {
-            uint32_t R[4], Q[4];
-            philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT0 << 24), a.key0, a.key1, R);
-            philox4x32((uint32_t)lin, (uint32_t)t, a.s_lo, a.s_hi | ((uint32_t)TAG_SLOT1 << 24), a.key0, a.key1, Q);
-            g_m = ONE ? 0 : select_move(a.pool, R[0]);
-            g_tlnu = a.temperature * det_log(uniform53(R[2], R[3]));
-            g_w1 = R[1];
-            g_w2 = Q[0];
-            double z[4];
-            box_muller(Q[0], Q[1], &z[0], &z[1]);
-            box_muller(Q[2], Q[3], &z[2], &z[3]);
-            double sg = ONE ? a.pool.sigma[0] : a.pool.sigma[g_m];
-            g_dx = sg * z[0];
-            g_dy = sg * z[1];
-            g_dz = sg * z[2];
+            const int ks = h.k0 + t;
+            g_m = ONE ? 0 : (int)a.slot_m[ks];
+            g_tlnu = a.slot_tlnu[ks];
+            g_w1 = a.slot_w1[ks];
+            if (!ONE) g_w2 = a.slot_w2[ks];
+            g_dx = a.slot_dx[ks];
+            g_dy = a.slot_dy[ks];
+            if (D == 3) g_dz = a.slot_dz[ks];
         }
         int nslots = min(PMC_WAVE, nc - chunk);
 #ifdef PMC_DEBUG_NOSLOTS   // profiling builds only: price the staging alone
