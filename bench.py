@@ -177,21 +177,21 @@ def main():
             moves_per_launch = N / 8.0
         achieved = b_alg * moves_per_launch / avg_launch_s / 1e9
         traffic = None
+        tinfo = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_cb_pass_hbm_bytes_per_launch")
+                tinfo = json.load(open(tpath))
+                # PMC bytes of the profiled launch, rescaled to the moves of a launch of this run
+                traffic = tinfo.get("k_cb_pass_hbm_bytes_per_launch") * moves_per_launch / float(tinfo.get("moves_per_launch", 125000))
             except Exception:
                 traffic = None
         # second, honest roofline: the kernel's real limiter is FP64 VALU issue.  Instructions per
         # launch come from the committed PMC summary of the same command (profiles/), the rate from this run.
         valu = None
-        ppath = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(ppath) and args.lattice == 100:
+        if tinfo.get("SQ_INSTS_VALU_per_launch") and args.lattice == 100:
             try:
-                pmcs = json.load(open(ppath))
-                k = next(v for name, v in pmcs.items() if name.startswith("void k_cb_pass<3, 0, false") and "SQ_INSTS_VALU" in v)
-                per_move = k["SQ_INSTS_VALU"]["mean"] / 125000.0
+                per_move = tinfo["SQ_INSTS_VALU_per_launch"] / float(tinfo["moves_per_launch"])
                 peak = 256 * 4 * 2.4e9 / 4.0          # FP64 wave-instructions/s: 256 CUs x 4 SIMDs, 4 cycles each
                 ach = per_move * moves_per_launch / avg_launch_s
                 valu = {"bound": "fp64-valu-issue", "wave_instructions_per_move": per_move, "achieved": ach,
@@ -216,9 +216,9 @@ def main():
                          "kernel": "k_cb_pass<3,LJ,single-species>", "algorithmic_bytes_per_move": b_alg,
                          "moves_per_launch": moves_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "reference_traversal_bytes_per_move": 2 * 27 * (N / float(np.prod(ncell_ref))) * 40.0,
-                         "note": "contract figure (algorithmic bytes / measured launch time); the kernel is FP64-VALU-"
-                                 "bound (SQ_ACTIVE_INST_VALU ~82 % of SIMD cycles, profiles/r01_pmc.json), its real HBM "
-                                 "traffic is `traffic` bytes per launch"},
+                         "note": "contract figure (algorithmic bytes / measured launch time; one launch = one fused "
+                                 "sweep of all colours); the kernel is FP64-VALU-bound (SQ_ACTIVE_INST_VALU ~88 % of SIMD "
+                                 "cycles, profiles/r01_pmc.json), its real HBM traffic is `traffic` bytes per launch"},
         }
         out["roofline_valu"] = valu
         if ngpus == 1 and not args.no_cpu:

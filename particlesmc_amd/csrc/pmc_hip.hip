@@ -50,8 +50,8 @@ struct pmc_system {
     unsigned char *d_slot_m = nullptr;   // [N]: move index
     // fused sweep (all colours in one launch, per-cell completion flags): flags, ticket, epoch
     bool use_fused = true;
-    int fused_lpt = -1;          // longest-first order inside a fused launch: -1 auto (measured: wins when a colour
-                                 // has more cells than ~1.6x the resident workgroups), 0 off, 1 on
+    int fused_lpt = 0;           // longest-first order inside a fused launch (PMC_FUSED_LPT=1): measured equal pass
+                                 // time at N=1e6 and slower below, and it costs the three ordering kernels
     unsigned int *d_done = nullptr;
     unsigned long long *d_ticket = nullptr;
     unsigned int epoch = 0;
@@ -1018,9 +1018,9 @@ static int cb_cap(const pmc_system *h)
     return std::min(std::max(cap, 128), PMC_CAP_MAX);
 }
 
-static size_t cb_lds_bytes(const pmc_system *h)
+static size_t cb_lds_bytes(const pmc_system *h, bool batch = false)
 {
-    size_t b = (pmc_lds_wave_bytes(cb_cap(h)) + 15) & ~(size_t)15;
+    size_t b = (pmc_lds_wave_bytes(cb_cap(h), h->S > 1, batch) + 15) & ~(size_t)15;
     if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
     if (const char *e = getenv("PMC_LDS_PAD")) b += (size_t)atoi(e);   // occupancy experiments
     return b;
@@ -1255,7 +1255,8 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
     const int ncol = 1 << h->D;
     int nactive = 1;
     for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
-    const size_t lds = cb_lds_bytes(h);
+    const bool batch = (h->team == 4) && mp.npool == 1 && mp.kind[0] == 0;   // k_cb_pass<..., NW = 4, ONE>
+    const size_t lds = cb_lds_bytes(h, batch);
     int64_t launches = 0, timed_sweeps = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     for (int64_t sw = 0; sw < nsweeps; sw++) {
@@ -1271,7 +1272,7 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
         // workgroup waits for were ticketed long before it (a pipeline with one tail per sweep); separate
         // colour launches sort each colour longest-first to shorten their eight tails
         const bool fused = h->use_fused;
-        const bool lpt = h->use_order && (!fused || h->fused_lpt == 1 || (h->fused_lpt < 0 && nactive > 4096));
+        const bool lpt = h->use_order && (!fused || h->fused_lpt == 1);
         if (lpt) {
             rc = mc_order(h, nactive);
             if (rc) return rc;

@@ -12,7 +12,7 @@
 #include <type_traits>
 
 #define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
-#define PMC_CFL 64           // centre-cell particles whose cell coordinates are cached
+#define PMC_CFL 16           // centre-cell particles whose cell coordinates are cached (cells without exact bounds)
 #ifndef PMC_CB_MINWAVES
 #define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget)
 #endif
@@ -1223,12 +1223,16 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
     return team_sum_exact<NW>(h, d);
 }
 
-__host__ __device__ inline size_t pmc_lds_wave_bytes(int cap)
+// LDS bytes of one workgroup: coordinates, cached cell coordinates, partial sums, [batch records],
+// flags, counters, segment tables, [species].  Kept small on purpose: at N = 10^6 (cap 512) a team of
+// two wavefronts needs <= 13 312 B for twelve workgroups (six wavefronts per SIMD) per CU.
+__host__ __device__ inline size_t pmc_lds_wave_bytes(int cap, bool multi, bool batch)
 {
-    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + PMC_REC * 4 * 8 + 4 * 4 + 16 * 4 + 2 * 32 * 4 + cap;
+    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (batch ? PMC_REC * 4 * 8 : 0) + 4 * 4 + 16 * 4 + 2 * 32 * 4 +
+           (multi ? cap : 0);
 }
 
-template <int D, bool MULTI>
+template <int D, bool MULTI, bool BATCH = false>
 __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned char *smem, WaveNbh &h)
 {
     h.cap = a.cap;
@@ -1238,12 +1242,12 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cfl = h.cz + h.cap;
     h.part = h.cfl + 3 * PMC_CFL;
     h.rec = h.part + 8;
-    h.flag = reinterpret_cast<int *>(h.rec + PMC_REC * 4);
+    h.flag = reinterpret_cast<int *>(h.rec + (BATCH ? PMC_REC * 4 : 0));
     h.cnt = h.flag + 4;
     h.segoff = h.cnt + 16;
     h.segsrc = h.segoff + 32;
     h.csp = reinterpret_cast<unsigned char *>(h.segsrc + 32);
-    DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap) + 15) & ~(size_t)15));
+    DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap, MULTI, BATCH) + 15) & ~(size_t)15));
     if (MULTI) {
         for (int k = threadIdx.x; k < a.S * a.S; k += blockDim.x) tab[k] = a.models[k];
         __syncthreads();
@@ -1395,7 +1399,7 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;
-    const DevModel *tab = setup_lds<D, MULTI>(a, smem, h);
+    const DevModel *tab = setup_lds<D, MULTI, ONE && (NW == 4)>(a, smem, h);
     const int lane = wave_lane();
     const int tid = team_tid<NW>(), wv = team_wave<NW>();
     constexpr int TS = NW * PMC_WAVE;

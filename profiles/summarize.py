@@ -45,8 +45,11 @@ for k, v in summary.items():
             "kernel": k, "round": tag,
             "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
             "k_cb_pass_hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
-            "note": "2 x FETCH_SIZE + WRITE_SIZE; the factor 2 is calibrated for this access width "
-                    "(8 B per lane, profiles/calib/RESULT.md); ~13x below the algorithmic bytes",
+            "moves_per_launch": 1000000,
+            "SQ_INSTS_VALU_per_launch": v.get("SQ_INSTS_VALU", {}).get("mean"),
+            "note": "one launch = one fused sweep of the N = 10^6 bench system (all 8 colours); "
+                    "2 x FETCH_SIZE + WRITE_SIZE; the factor 2 is calibrated for this access width "
+                    "(8 B per lane, profiles/calib/RESULT.md); ~14x below the algorithmic bytes",
         }
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
         print(traffic)
