@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libpmc_oracle.so")
 
 LJ, SOFT_INT, SOFT_FLOAT, SMOOTH_LJ = 0, 1, 2, 3
-EMPTYLIST, LINKEDLIST = 0, 1
+EMPTYLIST, LINKEDLIST, CELLLIST, VERLETLIST = 0, 1, 2, 3
 MOVE_DISPLACEMENT, MOVE_SWAP = 0, 1
 
 
@@ -72,6 +72,11 @@ def lib():
     L.orc_system_create.restype = vp
     L.orc_system_create.argtypes = [C.c_int64, C.c_int32, dp, ip, C.c_double, C.c_double, C.c_int32,
                                     C.POINTER(Model), C.c_int32, ip]
+    L.orc_system_create_list.restype = vp
+    L.orc_system_create_list.argtypes = [C.c_int64, C.c_int32, dp, ip, C.c_double, C.c_double, C.c_int32,
+                                         C.POINTER(Model), C.c_int32, C.c_double, C.POINTER(C.c_int32)]
+    L.orc_system_cell_members.restype = C.c_int64
+    L.orc_system_cell_members.argtypes = [vp, C.c_int64, lp, C.c_int64]
     L.orc_system_destroy.argtypes = [vp]
     L.orc_system_energy.restype = C.c_double
     L.orc_system_energy.argtypes = [vp]
@@ -204,14 +209,14 @@ def make_pool(moves):
 class System:
     """orc_system wrapper: the reference-faithful sequential path."""
 
-    def __init__(self, position, species, density, temperature, models, list_type=LINKEDLIST):
+    def __init__(self, position, species, density, temperature, models, list_type=LINKEDLIST, dr=0.0):
         marr, S = models
         self.pos0 = np.ascontiguousarray(position, dtype=np.float64)
         self.N, self.d = self.pos0.shape
         sp = np.ascontiguousarray(species, dtype=np.int32)
         err = C.c_int32(0)
-        self.h = lib().orc_system_create(self.N, self.d, _dp(self.pos0), _ip(sp), density, temperature,
-                                         S, marr, list_type, C.byref(err))
+        self.h = lib().orc_system_create_list(self.N, self.d, _dp(self.pos0), _ip(sp), density, temperature,
+                                              S, marr, list_type, dr, C.byref(err))
         self.err = err.value
         if not self.h:
             raise ValueError({1: "Initial configuration has infinite or NaN energy.",
@@ -223,6 +228,12 @@ class System:
         if getattr(self, "h", None):
             lib().orc_system_destroy(self.h)
             self.h = None
+
+    def cell_members(self, c):
+        """cells[c] of a CellList / VerletList (1-based c), in the reference's vector order."""
+        out = np.zeros(4096, dtype=np.int64)
+        n = lib().orc_system_cell_members(self.h, c, out.ctypes.data_as(C.POINTER(C.c_int64)), len(out))
+        return out[:n].copy()
 
     @property
     def energy(self):

@@ -230,7 +230,32 @@ struct orc_system {
     int64_t **sp_ids;
     int64_t *sp_n;
     int64_t *sp_heads;
+    /* CellList / VerletList, neighbours.jl:61-217, 387-543: per-cell vectors of ids */
+    int64_t **cells;
+    int64_t *cells_n, *cells_cap;
+    /* VerletList: per-particle vectors of neighbour ids, positions at the last update */
+    double maxcut, dr, dr2o4, rcutoff2;
+    int64_t **vnb;
+    int64_t *vnb_n, *vnb_cap;
+    double *last;
 };
+
+static void vec_push(int64_t **v, int64_t *n, int64_t *cap, int64_t x)   /* push! */
+{
+    if (*n == *cap) {
+        *cap = *cap ? 2 * *cap : 8;
+        *v = (int64_t *)realloc(*v, sizeof(int64_t) * (size_t)*cap);
+    }
+    (*v)[(*n)++] = x;
+}
+
+static void vec_remove_all(int64_t *v, int64_t *n, int64_t x)   /* filter!(y -> y != x, v) == deleteat!(v, v .== x) */
+{
+    int64_t w = 0;
+    for (int64_t r = 0; r < *n; r++)
+        if (v[r] != x) v[w++] = v[r];
+    *n = w;
+}
 
 /* cell_index, neighbours.jl:79-88 (fold_back utils.jl:12; last dim fastest) */
 static int64_t cell_index(const int64_t *ncells, const int64_t *mc, int d)
@@ -309,9 +334,94 @@ static void build_linked_list(orc_system *s)
     }
 }
 
+/* build_neighbour_list!(::CellList), neighbours.jl:145-156 (cells are not emptied: called once by System) */
+static void build_cell_vectors(orc_system *s)
+{
+    for (int64_t i = 1; i <= s->N; i++) {
+        int64_t c = position_cell_index(s, s->pos + (size_t)(i - 1) * s->d);
+        s->cs[i - 1] = c;
+        vec_push(&s->cells[c - 1], &s->cells_n[c - 1], &s->cells_cap[c - 1], i);
+    }
+}
+
+/* update_neighbour_list!(i, c, c2, ::CellList) 162-170 / update_cell_list!(::VerletList) 468-476 */
+static void update_cell_vectors(orc_system *s, int64_t i)
+{
+    int64_t c = s->cs[i - 1];
+    int64_t c2 = position_cell_index(s, s->pos + (size_t)(i - 1) * s->d);
+    if (c == c2)
+        return;
+    vec_remove_all(s->cells[c - 1], &s->cells_n[c - 1], i);
+    vec_push(&s->cells[c2 - 1], &s->cells_n[c2 - 1], &s->cells_cap[c2 - 1], i);
+    s->cs[i - 1] = c2;
+}
+
+/* build_neighbour_list!(::VerletList), neighbours.jl:429-462 */
+static void build_verlet(orc_system *s)
+{
+    build_cell_vectors(s);
+    for (int64_t i = 1; i <= s->N; i++) {
+        const double *xi = s->pos + (size_t)(i - 1) * s->d;
+        int64_t c = position_cell_index(s, xi);
+        const int64_t *nb = s->nbr + (size_t)(c - 1) * s->nbr_cap;
+        for (int k = 0; k < s->nbr_cnt[c - 1]; k++) {
+            int64_t c2 = nb[k];
+            for (int64_t q = 0; q < s->cells_n[c2 - 1]; q++) {
+                int64_t j = s->cells[c2 - 1][q];
+                if (j <= i)
+                    continue;
+                double r2 = nearest_image_distance_squared(xi, s->pos + (size_t)(j - 1) * s->d, s->box, s->d);
+                if (r2 < s->rcutoff2) {
+                    vec_push(&s->vnb[i - 1], &s->vnb_n[i - 1], &s->vnb_cap[i - 1], j);
+                    vec_push(&s->vnb[j - 1], &s->vnb_n[j - 1], &s->vnb_cap[j - 1], i);
+                }
+            }
+        }
+        memcpy(s->last + (size_t)(i - 1) * s->d, xi, sizeof(double) * (size_t)s->d);
+    }
+}
+
+/* update_neighbour_list!(::VerletList), neighbours.jl:494-543 */
+static void update_verlet(orc_system *s, int64_t i)
+{
+    const double *xi = s->pos + (size_t)(i - 1) * s->d;
+    const double *li = s->last + (size_t)(i - 1) * s->d;
+    double d2 = 0.0;                       /* sum(abs2, dx) */
+    for (int a = 0; a < s->d; a++) {
+        double dx = xi[a] - li[a];
+        d2 = (a == 0) ? dx * dx : d2 + dx * dx;
+    }
+    if (d2 < s->dr2o4)
+        return;
+    for (int64_t q = 0; q < s->vnb_n[i - 1]; q++) {
+        int64_t j = s->vnb[i - 1][q];
+        vec_remove_all(s->vnb[j - 1], &s->vnb_n[j - 1], i);
+    }
+    s->vnb_n[i - 1] = 0;
+    update_cell_vectors(s, i);
+    int64_t c = position_cell_index(s, xi);
+    const int64_t *nb = s->nbr + (size_t)(c - 1) * s->nbr_cap;
+    for (int k = 0; k < s->nbr_cnt[c - 1]; k++) {
+        int64_t c2 = nb[k];
+        for (int64_t q = 0; q < s->cells_n[c2 - 1]; q++) {
+            int64_t j = s->cells[c2 - 1][q];
+            if (i == j)
+                continue;
+            double r2 = nearest_image_distance_squared(xi, s->pos + (size_t)(j - 1) * s->d, s->box, s->d);
+            if (r2 < s->rcutoff2) {
+                vec_push(&s->vnb[i - 1], &s->vnb_n[i - 1], &s->vnb_cap[i - 1], j);
+                vec_push(&s->vnb[j - 1], &s->vnb_n[j - 1], &s->vnb_cap[j - 1], i);
+            }
+        }
+    }
+    memcpy(s->last + (size_t)(i - 1) * s->d, xi, sizeof(double) * (size_t)s->d);
+}
+
 /* update_neighbour_list!, neighbours.jl:276-302; old_new_cell 306-312 */
 static void update_linked_list(orc_system *s, int64_t i)
 {
+    if (s->list_type == ORC_CELLLIST) { update_cell_vectors(s, i); return; }
+    if (s->list_type == ORC_VERLETLIST) { update_verlet(s, i); return; }
     if (s->list_type != ORC_LINKEDLIST)
         return;
     int64_t c = s->cs[i - 1];
@@ -361,9 +471,20 @@ double orc_energy_particle(const orc_system *s, int64_t i)
             e += energy_ij(s, i, j, xi);
         return e;
     }
+    if (s->list_type == ORC_VERLETLIST) {       /* (verlet_list)(system, i), neighbours.jl:422-424 */
+        for (int64_t q = 0; q < s->vnb_n[i - 1]; q++)
+            e += energy_ij(s, i, s->vnb[i - 1][q], xi);
+        return e;
+    }
     int64_t c = position_cell_index(s, xi);
     const int64_t *nb = s->nbr + (size_t)(c - 1) * s->nbr_cap;
     int cnt = s->nbr_cnt[c - 1];
+    if (s->list_type == ORC_CELLLIST) {         /* (cell_list)(system, i), neighbours.jl:209-217 */
+        for (int k = 0; k < cnt; k++)
+            for (int64_t q = 0; q < s->cells_n[nb[k] - 1]; q++)
+                e += energy_ij(s, i, s->cells[nb[k] - 1][q], xi);
+        return e;
+    }
     for (int k = 0; k < cnt; k++) {
         int64_t j = s->head[nb[k] - 1];
         while (j != -1) {
@@ -383,8 +504,20 @@ int64_t orc_neighbours_of(const orc_system *s, int64_t i, int64_t *out, int64_t 
             out[n++] = j;
         return n;
     }
+    if (s->list_type == ORC_VERLETLIST) {
+        for (int64_t q = 0; q < s->vnb_n[i - 1] && n < cap; q++)
+            out[n++] = s->vnb[i - 1][q];
+        return n;
+    }
     int64_t c = position_cell_index(s, xi);
     const int64_t *nb = s->nbr + (size_t)(c - 1) * s->nbr_cap;
+    if (s->list_type == ORC_CELLLIST) {
+        for (int k = 0; k < s->nbr_cnt[c - 1]; k++)
+            for (int64_t q = 0; q < s->cells_n[nb[k] - 1]; q++)
+                if (n < cap)
+                    out[n++] = s->cells[nb[k] - 1][q];
+        return n;
+    }
     for (int k = 0; k < s->nbr_cnt[c - 1]; k++)
         for (int64_t j = s->head[nb[k] - 1]; j != -1; j = s->list[j - 1])
             if (n < cap)
@@ -448,6 +581,13 @@ orc_system *orc_system_create(int64_t N, int32_t d, const double *pos, const int
                               double density, double temperature, int32_t nspecies,
                               const orc_model *models, int32_t list_type, int32_t *err)
 {
+    return orc_system_create_list(N, d, pos, species, density, temperature, nspecies, models, list_type, 0.0, err);
+}
+
+orc_system *orc_system_create_list(int64_t N, int32_t d, const double *pos, const int32_t *species,
+                                   double density, double temperature, int32_t nspecies,
+                                   const orc_model *models, int32_t list_type, double dr, int32_t *err)
+{
     *err = 0;
     if (N < 1 || d < 1 || d > 3 || nspecies < 1) { *err = 2; return NULL; }
     orc_system *s = (orc_system *)calloc(1, sizeof(*s));
@@ -488,9 +628,51 @@ orc_system *orc_system_create(int64_t N, int32_t d, const double *pos, const int
         s->cs = (int64_t *)calloc((size_t)N, sizeof(int64_t));
         build_neighbour_cells(s);
     }
+    s->maxcut = maxcut;
+    if (list_type == ORC_CELLLIST || list_type == ORC_VERLETLIST) {
+        s->ncell_total = 1;
+        if (list_type == ORC_VERLETLIST) {
+            if (!(dr > 0.0)) { *err = 2; orc_system_destroy(s); return NULL; }   /* "Verlet list must have dr as a parameter" */
+            s->dr = dr;
+            s->dr2o4 = (dr * dr) / 4;                           /* (dr^2)/4, neighbours.jl:415 */
+            s->rcutoff2 = (maxcut + dr) * (maxcut + dr);        /* (rcut + dr)^2 */
+        }
+        for (int a = 0; a < d; a++) {
+            if (list_type == ORC_CELLLIST) {
+                /* CellList(box, rcut, N), neighbours.jl:126-133: box / floor(Int, box / rcut); max(1, floor(Int, box / cell)) */
+                double nf = floor(s->box[a] / maxcut);
+                if (!(nf >= 1.0)) { *err = 2; orc_system_destroy(s); return NULL; }
+                s->cell[a] = s->box[a] / (double)(int64_t)nf;
+                double q = floor(s->box[a] / s->cell[a]);
+                s->ncells[a] = q >= 1.0 ? (int64_t)q : 1;
+            } else {
+                /* VerletList(box, rcut, N), neighbours.jl:405-406 */
+                s->cell[a] = s->box[a] / orc_jl_fld(s->box[a], maxcut + dr);
+                double q = s->box[a] / s->cell[a];
+                if (!(q >= 1.0) || q != rint(q)) { *err = 2; orc_system_destroy(s); return NULL; }
+                s->ncells[a] = (int64_t)q;
+            }
+            s->ncell_total *= s->ncells[a];
+        }
+        s->cs = (int64_t *)calloc((size_t)N, sizeof(int64_t));
+        s->cells = (int64_t **)calloc((size_t)s->ncell_total, sizeof(int64_t *));
+        s->cells_n = (int64_t *)calloc((size_t)s->ncell_total, sizeof(int64_t));
+        s->cells_cap = (int64_t *)calloc((size_t)s->ncell_total, sizeof(int64_t));
+        build_neighbour_cells(s);
+        if (list_type == ORC_VERLETLIST) {
+            s->vnb = (int64_t **)calloc((size_t)N, sizeof(int64_t *));
+            s->vnb_n = (int64_t *)calloc((size_t)N, sizeof(int64_t));
+            s->vnb_cap = (int64_t *)calloc((size_t)N, sizeof(int64_t));
+            s->last = (double *)calloc((size_t)N * d, sizeof(double));
+        }
+    }
     build_species_list(s);           /* atoms.jl:48 */
     if (list_type == ORC_LINKEDLIST)
         build_linked_list(s);        /* atoms.jl:50 */
+    if (list_type == ORC_CELLLIST)
+        build_cell_vectors(s);
+    if (list_type == ORC_VERLETLIST)
+        build_verlet(s);
     double e = orc_total_energy(s);  /* atoms.jl:51-52 */
     if (isinf(e) || isnan(e)) {      /* atoms.jl:53-55 */
         *err = 1;
@@ -509,6 +691,12 @@ void orc_system_destroy(orc_system *s)
     if (s->sp_ids)
         for (int k = 0; k < s->nspecies; k++) free(s->sp_ids[k]);
     free(s->sp_ids); free(s->sp_n); free(s->sp_heads);
+    if (s->cells)
+        for (int64_t c = 0; c < s->ncell_total; c++) free(s->cells[c]);
+    free(s->cells); free(s->cells_n); free(s->cells_cap);
+    if (s->vnb)
+        for (int64_t i = 0; i < s->N; i++) free(s->vnb[i]);
+    free(s->vnb); free(s->vnb_n); free(s->vnb_cap); free(s->last);
     free(s);
 }
 
@@ -521,6 +709,13 @@ void orc_system_cell_geometry(const orc_system *s, double *cell, int64_t *ncells
     for (int a = 0; a < s->d; a++) { cell[a] = s->cell[a]; ncells[a] = s->ncells[a]; }
 }
 void orc_system_get_cells(const orc_system *s, int64_t *cs) { memcpy(cs, s->cs, sizeof(int64_t) * (size_t)s->N); }
+int64_t orc_system_cell_members(const orc_system *s, int64_t c, int64_t *out, int64_t cap)   /* cells[c], c 1-based */
+{
+    if (!s->cells) return -1;
+    int64_t n = s->cells_n[c - 1];
+    for (int64_t q = 0; q < n && q < cap; q++) out[q] = s->cells[c - 1][q];
+    return n;
+}
 void orc_system_get_linked_list(const orc_system *s, int64_t *head, int64_t *list)
 {
     memcpy(head, s->head, sizeof(int64_t) * (size_t)s->ncell_total);

@@ -48,7 +48,7 @@ double orc_jl_fld(double x, double y);
 int64_t orc_jl_fld_i(int64_t a, int64_t b);
 
 /* ---- system (src/atoms.jl, src/neighbours.jl, src/utils.jl) --------------- */
-enum { ORC_EMPTYLIST = 0, ORC_LINKEDLIST = 1 };
+enum { ORC_EMPTYLIST = 0, ORC_LINKEDLIST = 1, ORC_CELLLIST = 2, ORC_VERLETLIST = 3 };
 typedef struct orc_system orc_system;
 
 /* System(...) atoms.jl:40-58.  species are 1-based (reference convention).
@@ -57,6 +57,11 @@ typedef struct orc_system orc_system;
 orc_system *orc_system_create(int64_t N, int32_t d, const double *pos, const int32_t *species,
                               double density, double temperature, int32_t nspecies,
                               const orc_model *models, int32_t list_type, int32_t *err);
+/* the same with the list parameter of VerletList (list_parameters["dr"], neighbours.jl:401-404) */
+orc_system *orc_system_create_list(int64_t N, int32_t d, const double *pos, const int32_t *species,
+                                   double density, double temperature, int32_t nspecies,
+                                   const orc_model *models, int32_t list_type, double dr, int32_t *err);
+int64_t orc_system_cell_members(const orc_system *s, int64_t c, int64_t *out, int64_t cap); /* CellList/VerletList cells[c] */
 void orc_system_destroy(orc_system *s);
 double orc_system_energy(const orc_system *s);            /* system.energy[1] */
 void orc_system_set_energy(orc_system *s, double e);

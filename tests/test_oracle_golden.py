@@ -68,10 +68,10 @@ def test_lists_agree_on_initial_state(O):
     assert np.allclose(e1, e2, rtol=0, atol=1e-11)
 
 
-def _trace(O, lt, pool, sweeps, seed=10):
+def _trace(O, lt, pool, sweeps, seed=10, dr=0.0):
     pos, sp, box = _load("config_0.xyz")
     rho = len(pos) / np.prod(box)
-    s = O.System(_fold(O, pos, box), sp, rho, 0.231, O.jbb(), lt)
+    s = O.System(_fold(O, pos, box), sp, rho, 0.231, O.jbb(), lt, dr)
     out = [s.energy / s.N]
     att = acc = 0
     for t in range(sweeps):
@@ -88,6 +88,50 @@ def test_same_seed_traces_equal_across_list_types_displacement(O):
     ll, att_l, acc_l, _ = _trace(O, O.LINKEDLIST, pool, 8)
     assert np.allclose(el, ll, rtol=0, atol=1e-6)
     assert np.array_equal(acc_e, acc_l) and acc_e[0] > 0
+    # the Verlet leg of the same reference test (list_parameters dr = 0.2) and the CellList
+    vl, _, acc_v, sv = _trace(O, O.VERLETLIST, pool, 8, dr=0.2)
+    cl, _, acc_c, sc = _trace(O, O.CELLLIST, pool, 8)
+    assert np.allclose(ll, vl, rtol=0, atol=1e-6) and np.allclose(ll, cl, rtol=0, atol=1e-6)
+    assert np.array_equal(acc_l, acc_v) and np.array_equal(acc_l, acc_c)
+    assert abs(sv.energy - sv.total_energy()) < 1e-8 * abs(sv.energy)
+
+
+def test_verlet_and_cell_list_goldens_and_invariants(O):
+    """test/runtests.jl:24,38: energy/N = -2.676832 +- 1e-6 with VerletList(dr = 0.2); the same for the
+    CellList.  Invariants after moves: every Verlet list holds exactly the particles within rcut + dr
+    of the positions of the last update or closer than rcut now (no in-range pair is ever missed), lists are
+    symmetric and duplicate-free, cells[] partitions the particles and agrees with cs."""
+    pos, sp, box = _load("config_0.xyz")
+    rho = len(pos) / np.prod(box)
+    p = _fold(O, pos, box)
+    vl = O.System(p, sp, rho, 0.231, O.jbb(), O.VERLETLIST, 0.2)
+    cl = O.System(p, sp, rho, 0.231, O.jbb(), O.CELLLIST)
+    assert abs(vl.energy / vl.N - (-2.676832)) < 1e-6
+    assert abs(cl.energy / cl.N - (-2.676832)) < 1e-6
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.15}])       # large steps: many list updates
+    for s in (vl, cl):
+        s.mc_steps(pool, 3, 0, 0, 4 * s.N)
+        cs = s.cells()
+        _, ncells = s.cell_geometry()
+        seen = []
+        for c in range(1, int(np.prod(ncells)) + 1):
+            m = s.cell_members(c)
+            assert np.all(cs[m - 1] == c)
+            seen.extend(m.tolist())
+        assert sorted(seen) == list(range(1, s.N + 1))
+    x = vl.positions()
+    L = np.array(vl.box)
+    nbs = [set(vl.neighbours_of(i).tolist()) for i in range(1, vl.N + 1)]
+    assert all(len(vl.neighbours_of(i)) == len(nbs[i - 1]) for i in range(1, vl.N + 1))     # no duplicates
+    rc = 2.5 * 1.0                                                                                   # largest JBB cutoff is below this
+    for i in range(0, vl.N, 7):
+        d = x - x[i]
+        d -= np.round(d / L) * L
+        r = np.sqrt((d * d).sum(axis=1))
+        close = set((np.nonzero(r < 1.5)[0] + 1).tolist()) - {i + 1}
+        assert close <= nbs[i]                                    # nobody inside the interaction range is missing
+        assert all((i + 1) in nbs[j - 1] for j in nbs[i])         # symmetry
+    assert abs(vl.energy - vl.total_energy()) < 1e-8 * abs(vl.energy)
 
 
 def test_same_seed_traces_equal_across_list_types_swaps(O):
