@@ -119,6 +119,10 @@ int pmc_potential(double r2, const pmc_pair_model *m, double *u); /* potential(r
 int pmc_box_from_density(int64_t N, double density, int32_t d, double *box);   /* src/atoms.jl:45 */
 int pmc_linked_list_geometry(int32_t d, const double *box, double rcut,
                              double *cell, int64_t *ncells);      /* LinkedList(box, rcut, N) src/neighbours.jl:237-238 */
+int pmc_cell_list_geometry(int32_t d, const double *box, double rcut,
+                           double *cell, int64_t *ncells);        /* CellList(box, rcut, N) src/neighbours.jl:126-133 */
+int pmc_verlet_list_geometry(int32_t d, const double *box, double rcut, double dr,
+                             double *cell, int64_t *ncells);      /* VerletList(box, rcut, N; dr) src/neighbours.jl:405-406 */
 
 /* -- state ---------------------------------------------------------------- */
 int pmc_upload(pmc_system *h, const double *pos, const int32_t *species);   /* system.position / .species */
@@ -129,6 +133,16 @@ int pmc_set_energy(pmc_system *h, double e);                    /* system.energy
 int pmc_get_energy(pmc_system *h, double *e);
 int pmc_set_counters(pmc_system *h, uint64_t step, uint64_t sweep);  /* RNG stream position */
 int pmc_get_counters(pmc_system *h, uint64_t *step, uint64_t *sweep);
+
+/* -- the reference's other list types (reference-order engine only; the throughput engine's results do not
+ *    depend on the list).  Call after pmc_create (whose cell / ncells then hold THAT list's geometry) and before
+ *    the first build.  list_type: 0 EmptyList (src/neighbours.jl:13-44), 1 LinkedList (default, :224-377),
+ *    2 CellList (:61-217), 3 VerletList with list_parameters["dr"] (:387-543).  Per-particle energies are summed
+ *    in the order that list's iterator yields; moves maintain it exactly as update_neighbour_list! does.  After
+ *    throughput sweeps the list is rebuilt from the current state (build_neighbour_list!). */
+int pmc_set_list_type(pmc_system *h, int32_t list_type, double dr);
+int pmc_get_cell_members(pmc_system *h, int64_t c, int64_t *out, int64_t cap, int64_t *n);      /* CellList/VerletList .cells[c] */
+int pmc_get_verlet_neighbours(pmc_system *h, int64_t i, int64_t *out, int64_t cap, int64_t *n); /* VerletList .neighbours[i] */
 
 /* -- LinkedList (reference-order engine) ---------------------------------- */
 int pmc_build_cells(pmc_system *h);                             /* build_neighbour_list! src/neighbours.jl:251-270 */

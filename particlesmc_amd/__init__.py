@@ -7,7 +7,7 @@ package is the host-side mirror of the reference interface (src/ParticlesMC.jl:1
 from ._lib import PMCError, device_count, lib  # noqa: F401
 from .models import (BHHP, JBB, KobAndersen, LennardJones, Model, SmoothLennardJones,  # noqa: F401
                      SoftSpheres, cutoff, cutoff2, potential)
-from .neighbours import EmptyList, LinkedList, NeighbourList  # noqa: F401
+from .neighbours import CellList, EmptyList, LinkedList, NeighbourList, VerletList  # noqa: F401
 from .system import (Atoms, System, compute_energy_particle, compute_energy_particles,
                      compute_energy_particles_exact, fold_back,  # noqa: F401
                      get_box, get_model, get_neighbour_list, get_position, get_species)

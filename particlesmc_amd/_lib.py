@@ -66,6 +66,11 @@ SYMBOLS = {
     "pmc_potential": (C.c_int, [C.c_double, C.POINTER(PairModel), _dp]),
     "pmc_box_from_density": (C.c_int, [C.c_int64, C.c_double, C.c_int32, _dp]),
     "pmc_linked_list_geometry": (C.c_int, [C.c_int32, _dp, C.c_double, _dp, _lp]),
+    "pmc_cell_list_geometry": (C.c_int, [C.c_int32, _dp, C.c_double, _dp, _lp]),
+    "pmc_verlet_list_geometry": (C.c_int, [C.c_int32, _dp, C.c_double, C.c_double, _dp, _lp]),
+    "pmc_set_list_type": (C.c_int, [_h, C.c_int32, C.c_double]),
+    "pmc_get_cell_members": (C.c_int, [_h, C.c_int64, _lp, C.c_int64, _lp]),
+    "pmc_get_verlet_neighbours": (C.c_int, [_h, C.c_int64, _lp, C.c_int64, _lp]),
     "pmc_upload": (C.c_int, [_h, _dp, _ip]),
     "pmc_download": (C.c_int, [_h, _dp, _ip]),
     "pmc_set_temperature": (C.c_int, [_h, C.c_double]),

@@ -44,6 +44,12 @@ struct pmc_system {
     int *d_cell_of = nullptr, *d_count = nullptr, *d_fill = nullptr, *d_tmp_ids = nullptr;
     int *d_arrival = nullptr, *d_tile_sum = nullptr, *d_order = nullptr, *d_hist = nullptr;
     bool use_order = true;
+    // alternative reference list types (pmc_set_list_type): 0 EmptyList, 1 LinkedList, 2 CellList, 3 VerletList
+    int list_type = 1;
+    double list_dr = 0.0;
+    int *d_cl_items = nullptr, *d_vl_nb = nullptr, *d_vl_cnt = nullptr, *d_ref_err = nullptr;
+    double *d_vl_last = nullptr;
+    int cl_cap = 0, vl_cap = 0;
     // proposal slots of the current sweep (k_mc_slots)
     double *d_slot_f = nullptr;          // [4][N]: T ln u, dx, dy, dz
     uint32_t *d_slot_w = nullptr;        // [2][N]: particle word, second swap word
@@ -469,7 +475,8 @@ extern "C" int pmc_destroy(pmc_system *h)
     void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
-                    h->d_sz, h->d_ssp, h->d_stats, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m};
+                    h->d_sz, h->d_ssp, h->d_stats, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m,
+                    h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
@@ -595,6 +602,114 @@ extern "C" int pmc_get_counters(pmc_system *h, uint64_t *step, uint64_t *sweep)
     return PMC_OK;
 }
 
+// ---- alternative list types of the reference -----------------------------------------------
+
+extern "C" int pmc_cell_list_geometry(int32_t d, const double *box, double rcut, double *cell, int64_t *ncells)
+{
+    // CellList(box, rcut, N), src/neighbours.jl:126-133: box / floor(Int, box / rcut); max(1, floor(Int, box / cell))
+    if (!box || !cell || !ncells || d < 1 || d > 3 || !(rcut > 0.0)) return fail(nullptr, PMC_ERR_BADARG, "pmc_cell_list_geometry: bad argument");
+    for (int a = 0; a < d; a++) {
+        const double nf = std::floor(box[a] / rcut);
+        if (!(nf >= 1.0)) return fail(nullptr, PMC_ERR_BADARG, "CellList: rcut larger than the box (division by zero cells)");
+        cell[a] = box[a] / (double)(int64_t)nf;
+        const double q = std::floor(box[a] / cell[a]);
+        ncells[a] = q >= 1.0 ? (int64_t)q : 1;
+    }
+    return PMC_OK;
+}
+
+extern "C" int pmc_verlet_list_geometry(int32_t d, const double *box, double rcut, double dr, double *cell, int64_t *ncells)
+{
+    // VerletList(box, rcut, N; dr), src/neighbours.jl:405-406: the LinkedList formula with rcut + dr
+    if (!(dr > 0.0)) return fail(nullptr, PMC_ERR_BADARG, "Verlet list must have dr as a parameter");
+    return pmc_linked_list_geometry(d, box, rcut + dr, cell, ncells);
+}
+
+extern "C" int pmc_set_list_type(pmc_system *h, int32_t list_type, double dr)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_list_type: null handle");
+    if (list_type < 0 || list_type > 3) return fail(h, PMC_ERR_BADARG, "pmc_set_list_type: 0 EmptyList, 1 LinkedList, 2 CellList, 3 VerletList");
+    if (list_type == 3 && !(dr > 0.0)) return fail(h, PMC_ERR_BADARG, "Verlet list must have dr as a parameter");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    h->list_type = list_type;
+    h->list_dr = dr;
+    h->cells_built = false;
+    const size_t N = (size_t)h->N;
+    if (!h->d_ref_err) {
+        HIPCHK(h, hipMalloc(&h->d_ref_err, 16));
+        HIPCHK(h, hipMemset(h->d_ref_err, 0, 16));
+    }
+    if (list_type >= 2 && !h->d_cl_items) {
+        const double mean = (double)h->N / (double)h->ncell_ref;
+        h->cl_cap = std::max(32, (int)(3.0 * mean) + 32);
+        HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * h->cl_cap * sizeof(int)));
+    }
+    if (list_type == 3) {
+        double vol = 1.0;
+        for (int a = 0; a < h->D; a++) vol *= h->p.box[a];
+        const double r = h->maxcut + dr;
+        const double sphere = (h->D == 3) ? 4.18879020478639 * r * r * r : 3.14159265358979 * r * r;
+        const int cap = std::max(64, (int)(2.5 * sphere * (double)h->N / vol) + 32);
+        if (cap != h->vl_cap) {
+            if (h->d_vl_nb) (void)hipFree(h->d_vl_nb);
+            h->d_vl_nb = nullptr;
+            h->vl_cap = cap;
+        }
+        if (!h->d_vl_nb) HIPCHK(h, hipMalloc(&h->d_vl_nb, N * (size_t)h->vl_cap * sizeof(int)));
+        if (!h->d_vl_cnt) HIPCHK(h, hipMalloc(&h->d_vl_cnt, N * sizeof(int)));
+        if (!h->d_vl_last) HIPCHK(h, hipMalloc(&h->d_vl_last, N * h->D * sizeof(double)));
+    }
+    return PMC_OK;
+}
+
+static int ref_list_errors(pmc_system *h)
+{
+    if (!h->d_ref_err) return PMC_OK;
+    int e = 0;
+    HIPCHK(h, hipMemcpy(&e, h->d_ref_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(h->d_ref_err, 0, sizeof(int));
+        h->cells_built = false;
+        return fail(h, PMC_ERR_UNSUPPORTED, (e & 2) ? "VerletList: a neighbour vector exceeded its device capacity"
+                                                   : "CellList: a cell vector exceeded its device capacity");
+    }
+    return PMC_OK;
+}
+
+extern "C" int pmc_get_cell_members(pmc_system *h, int64_t c, int64_t *out, int64_t cap, int64_t *n)
+{
+    if (!h || !out || !n || c < 1 || c > h->ncell_ref) return fail(h, PMC_ERR_BADARG, "pmc_get_cell_members: bad argument");
+    if (h->list_type < 2) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_get_cell_members: only CellList and VerletList keep cells[c]");
+    if (!h->cells_built) { int rb = pmc_build_cells(h); if (rb) return rb; }
+    int rc = set_device(h);
+    if (rc) return rc;
+    int cnt = 0;
+    HIPCHK(h, hipMemcpy(&cnt, h->d_ccount + (c - 1), sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> t((size_t)std::max(cnt, 1));
+    if (cnt) HIPCHK(h, hipMemcpy(t.data(), h->d_cl_items + (size_t)(c - 1) * h->cl_cap, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost));
+    for (int k = 0; k < cnt && k < cap; k++) out[k] = (int64_t)t[k] + 1;
+    *n = cnt;
+    return PMC_OK;
+}
+
+extern "C" int pmc_get_verlet_neighbours(pmc_system *h, int64_t i, int64_t *out, int64_t cap, int64_t *n)
+{
+    if (!h || !out || !n || i < 1 || i > h->N) return fail(h, PMC_ERR_BADARG, "pmc_get_verlet_neighbours: bad argument");
+    if (h->list_type != 3) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_get_verlet_neighbours: the list type is not VerletList");
+    if (!h->cells_built) { int rb = pmc_build_cells(h); if (rb) return rb; }
+    int rc = set_device(h);
+    if (rc) return rc;
+    int cnt = 0;
+    HIPCHK(h, hipMemcpy(&cnt, h->d_vl_cnt + (i - 1), sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> t((size_t)std::max(cnt, 1));
+    if (cnt) HIPCHK(h, hipMemcpy(t.data(), h->d_vl_nb + (size_t)(i - 1) * h->vl_cap, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost));
+    for (int k = 0; k < cnt && k < cap; k++) out[k] = (int64_t)t[k] + 1;
+    *n = cnt;
+    return PMC_OK;
+}
+
 // ---- binning ------------------------------------------------------------------------
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
@@ -627,6 +742,8 @@ static int bin_by_cell(pmc_system *h, int ncell, int *d_start, int *d_ids)
     return PMC_OK;
 }
 
+static RefArgs ref_args(pmc_system *h);
+
 extern "C" int pmc_build_cells(pmc_system *h)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_build_cells: null handle");
@@ -649,10 +766,20 @@ extern "C" int pmc_build_cells(pmc_system *h)
     int tot = std::max(N, h->ncell_ref);
     hipLaunchKernelGGL(k_ref_links, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, h->d_start_ref,
                        h->d_ids_ref, h->ncell_ref, h->d_head, h->d_list, h->d_ccount);
+    if (h->list_type >= 2) {
+        // CellList / VerletList: cells[c] vectors in ascending id (build_neighbour_list!, src/neighbours.jl:145-156, 431-435)
+        hipLaunchKernelGGL(k_ref_cellvec, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, N, h->d_cell_of, h->d_start_ref,
+                           h->d_ids_ref, h->ncell_ref, h->d_cl_items, h->cl_cap, h->d_ccount, h->d_ref_err);
+    }
+    if (h->list_type == 3) {
+        RefArgs a = ref_args(h);
+        if (h->D == 3) hipLaunchKernelGGL(k_ref_verlet_build<3>, dim3(nblk(N, 64)), dim3(64), 0, h->stream, a);
+        else hipLaunchKernelGGL(k_ref_verlet_build<2>, dim3(nblk(N, 64)), dim3(64), 0, h->stream, a);
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->cells_built = true;
-    return PMC_OK;
+    return ref_list_errors(h);
 }
 
 extern "C" int pmc_get_cells(pmc_system *h, int64_t *cs)
@@ -673,6 +800,7 @@ extern "C" int pmc_get_cells(pmc_system *h, int64_t *cs)
 extern "C" int pmc_get_linked_list(pmc_system *h, int64_t *head, int64_t *list)
 {
     if (!h || !head || !list) return fail(h, PMC_ERR_BADARG, "pmc_get_linked_list: null argument");
+    if (h->list_type != 1) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_get_linked_list: the list type is not LinkedList");
     if (!h->cells_built) {   // e.g. after checkerboard sweeps: the reference's list is always current
         int rb = pmc_build_cells(h);
         if (rb) return rb;
@@ -713,6 +841,12 @@ static RefArgs ref_args(pmc_system *h)
     a.sp_off = h->d_sp_off; a.sp_ids = h->d_sp_ids; a.sp_heads = h->d_sp_heads;
     a.energy = h->d_energy;
     a.temperature = h->p.temperature;
+    a.list_type = h->list_type;
+    a.cl_items = h->d_cl_items; a.cl_cap = h->cl_cap;
+    a.vl_nb = h->d_vl_nb; a.vl_cnt = h->d_vl_cnt; a.vl_cap = h->vl_cap; a.vl_last = h->d_vl_last;
+    a.dr2o4 = (h->list_dr * h->list_dr) / 4;                                   // src/neighbours.jl:415
+    a.rcutoff2 = (h->maxcut + h->list_dr) * (h->maxcut + h->list_dr);          // (rcut + dr)^2, :438
+    a.err = h->d_ref_err;
     return a;
 }
 
@@ -848,7 +982,7 @@ static int ref_op_launch(pmc_system *h, RefOp &o)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->mc_binned = false;
     h->e_fix_valid = false;
-    return PMC_OK;
+    return h->list_type >= 2 ? ref_list_errors(h) : PMC_OK;
 }
 
 extern "C" int pmc_displacement_perform(pmc_system *h, int64_t i, const double *delta, double *e1, double *e2,

@@ -312,6 +312,15 @@ struct RefArgs {
     int *sp_off, *sp_ids, *sp_heads; // SpeciesList (utils.jl:31-49), 0-based
     double *energy;            // system.energy[1]
     double temperature;
+    // alternative list types of the reference (src/neighbours.jl): 0 EmptyList, 1 LinkedList, 2 CellList, 3 VerletList
+    int list_type;
+    int *cl_items;             // cells[c] vectors (CellList / VerletList): [ncell][cl_cap], lengths in ccount
+    int cl_cap;
+    int *vl_nb, *vl_cnt;       // neighbours[i] vectors (VerletList): [N][vl_cap]
+    int vl_cap;
+    double *vl_last;           // positions_at_last_update
+    double dr2o4, rcutoff2;
+    int *err;                  // bit 0: a cell vector overflowed, bit 1: a Verlet vector overflowed
 };
 
 template <int D>
@@ -345,6 +354,20 @@ __device__ __forceinline__ double ref_energy_ij(const RefArgs &a, int i, int j, 
     return dev_potential_dyn(r2, m);
 }
 
+// nearest_image_distance_squared, src/utils.jl:21-28 (division form)
+template <int D>
+__device__ __forceinline__ double ref_dist2(const RefArgs &a, const double *xi, int j)
+{
+    double v = dev_vector_1d(xi[0], a.pos[(size_t)j * D + 0], a.box[0]);
+    double r2 = v * v;
+#pragma unroll
+    for (int q = 1; q < D; q++) {
+        v = dev_vector_1d(xi[q], a.pos[(size_t)j * D + q], a.box[q]);
+        r2 = r2 + v * v;
+    }
+    return r2;
+}
+
 __device__ __forceinline__ double readlane_double(double v, int l)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -361,6 +384,21 @@ template <int D>
 __device__ double wave_ordered_energy(const RefArgs &a, int i, const double *xi, int spi, int *lds_ids)
 {
     const int lane = wave_lane();
+    if (a.list_type == 0 || a.list_type == 3) {
+        // EmptyList: j in 1:N (src/neighbours.jl:42-44); VerletList: j in neighbours[i] (:422-424)
+        const int total = (a.list_type == 0) ? a.N : a.vl_cnt[i];
+        double acc = 0.0;
+        for (int base = 0; base < total; base += PMC_WAVE) {
+            const int n = min(PMC_WAVE, total - base);
+            double u = 0.0;
+            if (lane < n) {
+                const int j = (a.list_type == 0) ? base + lane : a.vl_nb[(size_t)i * a.vl_cap + base + lane];
+                u = ref_energy_ij<D>(a, i, j, xi, spi);
+            }
+            for (int k = 0; k < n; k++) acc += readlane_double(u, k);
+        }
+        return acc;
+    }
     int c = ref_cell_of<D>(a, xi);
     int cnt = a.nbrcnt[c];
     int c2 = (lane < cnt) ? a.nbr[(size_t)c * a.nnmax + lane] : 0;
@@ -378,11 +416,15 @@ __device__ double wave_ordered_energy(const RefArgs &a, int i, const double *xi,
     __syncthreads();
     if (fits) {
         if (lane < cnt) {
-            int j = a.head[c2], k = 0;
-            while (j != -1 && k < len) {
-                lds_ids[off + k] = j;
-                k++;
-                j = a.list[j];
+            if (a.list_type == 2) {                 // CellList: cells[c2] in vector order (src/neighbours.jl:209-217)
+                for (int k = 0; k < len; k++) lds_ids[off + k] = a.cl_items[(size_t)c2 * a.cl_cap + k];
+            } else {
+                int j = a.head[c2], k = 0;
+                while (j != -1 && k < len) {
+                    lds_ids[off + k] = j;
+                    k++;
+                    j = a.list[j];
+                }
             }
         }
         __syncthreads();
@@ -391,6 +433,12 @@ __device__ double wave_ordered_energy(const RefArgs &a, int i, const double *xi,
             double u = 0.0;
             if (lane < n) u = ref_energy_ij<D>(a, i, lds_ids[base + lane], xi, spi);
             for (int k = 0; k < n; k++) acc += readlane_double(u, k);
+        }
+    } else if (a.list_type == 2) {
+        for (int l = 0; l < cnt; l++) {
+            const int cc = a.nbr[(size_t)c * a.nnmax + l];
+            const int n = a.ccount[cc];
+            for (int k = 0; k < n; k++) acc += ref_energy_ij<D>(a, i, a.cl_items[(size_t)cc * a.cl_cap + k], xi, spi);
         }
     } else {
         for (int l = 0; l < cnt; l++) {
@@ -440,6 +488,169 @@ __device__ void ref_relink(const RefArgs &a, int i, const double *x)
     a.cs[i] = c2;
     a.ccount[c]--;
     a.ccount[c2]++;
+}
+
+// update_neighbour_list!(i, c, c2, ::CellList) / update_cell_list!(::VerletList): filter! keeps the order of
+// the old cell's vector, push! appends to the new one (src/neighbours.jl:162-170, 468-476).  Lane 0.
+template <int D>
+__device__ void ref_cellvec_update(const RefArgs &a, int i, const double *x)
+{
+    const int c = a.cs[i];
+    const int c2 = ref_cell_of<D>(a, x);
+    if (c == c2) return;
+    int *v = a.cl_items + (size_t)c * a.cl_cap;
+    const int n = a.ccount[c];
+    int w = 0;
+    for (int r = 0; r < n; r++) {
+        const int t = v[r];
+        if (t != i) v[w++] = t;
+    }
+    a.ccount[c] = w;
+    const int n2 = a.ccount[c2];
+    if (n2 >= a.cl_cap) { atomicOr(a.err, 1); return; }
+    a.cl_items[(size_t)c2 * a.cl_cap + n2] = i;
+    a.ccount[c2] = n2 + 1;
+    a.cs[i] = c2;
+}
+
+// update_neighbour_list!(system, i, ::VerletList), src/neighbours.jl:494-543: nothing unless the particle moved
+// dr/2 since its last update; then i leaves every list it is in (order kept), its cell vector is updated, and
+// its own list is rebuilt by scanning the neighbourhood in cell / vector order.  Whole wavefront.
+template <int D>
+__device__ void ref_verlet_update(const RefArgs &a, int i, const double *x, int *lds_ids)
+{
+    const int lane = wave_lane();
+    double d2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; q++) {
+        const double dx = x[q] - a.vl_last[(size_t)i * D + q];
+        d2 = (q == 0) ? dx * dx : d2 + dx * dx;
+    }
+    if (d2 < a.dr2o4) return;
+    const int ni = a.vl_cnt[i];
+    for (int q = lane; q < ni; q += PMC_WAVE) {           // lists are duplicate-free: distinct lanes, distinct j
+        const int j = a.vl_nb[(size_t)i * a.vl_cap + q];
+        int *v = a.vl_nb + (size_t)j * a.vl_cap;
+        const int n = a.vl_cnt[j];
+        int w = 0;
+        for (int r = 0; r < n; r++) {
+            const int t = v[r];
+            if (t != i) v[w++] = t;
+        }
+        a.vl_cnt[j] = w;
+    }
+    if (lane == 0) ref_cellvec_update<D>(a, i, x);
+    __threadfence();
+    __syncthreads();
+    const int c = ref_cell_of<D>(a, x);
+    const int cnt = a.nbrcnt[c];
+    int fill = 0;                                           // uniform: entries of neighbours[i] so far
+    for (int l = 0; l < cnt; l++) {
+        const int cc = a.nbr[(size_t)c * a.nnmax + l];
+        const int n = a.ccount[cc];
+        for (int base = 0; base < n; base += PMC_WAVE) {
+            const int k = base + lane;
+            int j = -1;
+            bool in = false;
+            if (k < n) {
+                j = a.cl_items[(size_t)cc * a.cl_cap + k];
+                in = (j != i) && (ref_dist2<D>(a, x, j) < a.rcutoff2);
+            }
+            const unsigned long long mk = __ballot(in);
+            if (in) {
+                const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                const int nj = a.vl_cnt[j];
+                if (pos < a.vl_cap && nj < a.vl_cap) {
+                    a.vl_nb[(size_t)i * a.vl_cap + pos] = j;
+                    a.vl_nb[(size_t)j * a.vl_cap + nj] = i;
+                    a.vl_cnt[j] = nj + 1;
+                } else {
+                    atomicOr(a.err, 2);
+                }
+            }
+            fill += __popcll(mk);
+        }
+    }
+    if (lane == 0) {
+        a.vl_cnt[i] = min(fill, a.vl_cap);
+#pragma unroll
+        for (int q = 0; q < D; q++) a.vl_last[(size_t)i * D + q] = x[q];
+    }
+    (void)lds_ids;
+}
+
+// update_neighbour_list!(system, i) for the active list type; called by the whole wavefront
+template <int D>
+__device__ void ref_update_list(const RefArgs &a, int i, const double *x, int *lds_ids)
+{
+    if (a.list_type == 1) { if (wave_lane() == 0) ref_relink<D>(a, i, x); }
+    else if (a.list_type == 2) { if (wave_lane() == 0) ref_cellvec_update<D>(a, i, x); }
+    else if (a.list_type == 3) ref_verlet_update<D>(a, i, x, lds_ids);
+}
+
+// build_neighbour_list!(::CellList): cells[c] = ids in ascending order (push! in the loop over i)
+__global__ void k_ref_cellvec(int N, const int *__restrict__ cell_of, const int *__restrict__ start,
+                              const int *__restrict__ ids, int ncell, int *__restrict__ items, int cap,
+                              int *__restrict__ ccount, int *__restrict__ err)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncell) {
+        const int n = start[k + 1] - start[k];
+        ccount[k] = min(n, cap);
+        if (n > cap) atomicOr(err, 1);
+    }
+    if (k < N) {
+        const int i = ids[k];
+        const int c = cell_of[i];
+        const int q = k - start[c];
+        if (q < cap) items[(size_t)c * cap + q] = i;
+    }
+}
+
+// build_neighbour_list!(::VerletList), src/neighbours.jl:429-462.  The serial loop over i pushes, for every
+// pair within rcut + dr, j into neighbours[i] and i into neighbours[j] while scanning the cells around i for
+// j > i; neighbours[k] therefore is [the i < k in ascending i] followed by [the j > k in k's own scan order].
+template <int D>
+__global__ void k_ref_verlet_build(RefArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.N) return;
+    double x[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < D; q++) x[q] = a.pos[(size_t)k * D + q];
+    const int c = a.cs[k];
+    const int cnt = a.nbrcnt[c];
+    int *v = a.vl_nb + (size_t)k * a.vl_cap;
+    int n = 0;
+    bool over = false;
+    for (int l = 0; l < cnt; l++) {
+        const int cc = a.nbr[(size_t)c * a.nnmax + l];
+        const int m = a.ccount[cc];
+        for (int q = 0; q < m; q++) {
+            const int j = a.cl_items[(size_t)cc * a.cl_cap + q];
+            if (j < k && ref_dist2<D>(a, x, j) < a.rcutoff2) {
+                if (n < a.vl_cap) {
+                    int w = n++;                              // insertion into the ascending prefix
+                    while (w > 0 && v[w - 1] > j) { v[w] = v[w - 1]; w--; }
+                    v[w] = j;
+                } else over = true;
+            }
+        }
+    }
+    for (int l = 0; l < cnt; l++) {
+        const int cc = a.nbr[(size_t)c * a.nnmax + l];
+        const int m = a.ccount[cc];
+        for (int q = 0; q < m; q++) {
+            const int j = a.cl_items[(size_t)cc * a.cl_cap + q];
+            if (j > k && ref_dist2<D>(a, x, j) < a.rcutoff2) {
+                if (n < a.vl_cap) v[n++] = j; else over = true;
+            }
+        }
+    }
+    a.vl_cnt[k] = n;
+    if (over) atomicOr(a.err, 2);
+#pragma unroll
+    for (int q = 0; q < D; q++) a.vl_last[(size_t)k * D + q] = x[q];
 }
 
 enum { OP_DISP_PERFORM = 0, OP_DISP_REVERT = 1, OP_SWAP_PERFORM = 2, OP_SWAP_REVERT = 3, OP_STEPS = 4 };
@@ -494,8 +705,10 @@ __device__ void ref_disp_perform(const RefArgs &a, int i, const double *delta, i
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = x[q];
-        ref_relink<D>(a, i, x);
     }
+    __threadfence();
+    __syncthreads();
+    ref_update_list<D>(a, i, x, lds_ids);                 // update_neighbour_list!, src/moves.jl:47
     __threadfence();
     __syncthreads();
     double eb = wave_ordered_energy<D>(a, i, x, sp, lds_ids);
@@ -508,18 +721,20 @@ __device__ void ref_disp_perform(const RefArgs &a, int i, const double *delta, i
 }
 
 template <int D>
-__device__ void ref_disp_revert(const RefArgs &a, int i, const double *mdelta, double de)
+__device__ void ref_disp_revert(const RefArgs &a, int i, const double *mdelta, double de, int *lds_ids)
 {
-    if (wave_lane() == 0) {
-        double x[3] = {0, 0, 0};
+    double x[3] = {0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < D; q++) {
-            x[q] = a.pos[(size_t)i * D + q] + mdelta[q];
-            a.pos[(size_t)i * D + q] = x[q];
-        }
+    for (int q = 0; q < D; q++) x[q] = a.pos[(size_t)i * D + q] + mdelta[q];
+    __syncthreads();
+    if (wave_lane() == 0) {
+#pragma unroll
+        for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = x[q];
         *a.energy -= de;                                  // src/moves.jl:79
-        ref_relink<D>(a, i, x);
     }
+    __threadfence();
+    __syncthreads();
+    ref_update_list<D>(a, i, x, lds_ids);
     __threadfence();
     __syncthreads();
 }
@@ -587,7 +802,7 @@ __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
     if (o.op == OP_DISP_PERFORM) {
         ref_disp_perform<D>(a, o.i, o.delta, lds_ids, &e1, &e2, &de);
     } else if (o.op == OP_DISP_REVERT) {
-        ref_disp_revert<D>(a, o.i, o.delta, o.de_in);
+        ref_disp_revert<D>(a, o.i, o.delta, o.de_in, lds_ids);
     } else if (o.op == OP_SWAP_PERFORM) {
         ref_swap_perform<D>(a, o.i, o.j, a.species[o.i], a.species[o.j], lds_ids, &e1, &e2, &de);
     } else if (o.op == OP_SWAP_REVERT) {
@@ -612,7 +827,7 @@ __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
                 for (int q = 0; q < D; q++) { delta[q] = o.pool.sigma[m] * z[q]; md[q] = -delta[q]; }
                 ref_disp_perform<D>(a, i, delta, lds_ids, &e1, &e2, &de);
                 ok = lnu < -(e2 - e1) / a.temperature;
-                if (!ok) ref_disp_revert<D>(a, i, md, de);
+                if (!ok) ref_disp_revert<D>(a, i, md, de, lds_ids);
             } else {
                 int sa = o.pool.sp0[m], sb = o.pool.sp1[m];
                 int na = a.sp_off[sa + 1] - a.sp_off[sa], nb = a.sp_off[sb + 1] - a.sp_off[sb];

@@ -203,7 +203,7 @@ def load_chains(init_path, args=None, filename="", verbose=False, seed=0, device
         list_name = args["list_type"]
     list_type = LIST_TYPES.get(list_name)
     if list_type is None:
-        raise NotImplementedError(f"{list_name} has no HIP implementation (LinkedList only)")
+        raise NotImplementedError(f"unknown list_type {list_name} (LinkedList, CellList, VerletList, EmptyList)")
     chains = [System(positions[k], species[k], densities[k], temps[k], model_matrix, list_type=list_type,
                      list_parameters=args.get("list_parameters"), seed=seed, chain=k, device=device)
               for k in range(len(positions))]

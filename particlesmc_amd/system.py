@@ -101,6 +101,8 @@ class Atoms(Particles):
         h = C.c_void_p()
         _lib.check(_lib.lib().pmc_create(C.byref(p), C.byref(h)))
         self._h = h
+        if getattr(neighbour_list, "LIST_TYPE", 1) != 1:
+            _lib.check(_lib.lib().pmc_set_list_type(self._h, int(neighbour_list.LIST_TYPE), float(getattr(neighbour_list, "dr", 0.0))), self._h)
         _lib.check(_lib.lib().pmc_upload(self._h, _dp(pos), _ip(sp)), self._h)
         self.energy = _EnergyRef(self)
 
@@ -171,6 +173,20 @@ class Atoms(Particles):
         lst = np.zeros(self.N, dtype=np.int64)
         _lib.check(_lib.lib().pmc_get_linked_list(self._h, _lp(head), _lp(lst)), self._h)
         return head, lst
+
+    def get_cell_members(self, c):
+        """cells[c] of a CellList / VerletList, in the reference's vector order (1-based ids)."""
+        out = np.zeros(4096, dtype=np.int64)
+        n = C.c_int64()
+        _lib.check(_lib.lib().pmc_get_cell_members(self._h, int(c), _lp(out), len(out), C.byref(n)), self._h)
+        return out[: n.value].copy()
+
+    def get_verlet_neighbours(self, i):
+        """neighbours[i] of a VerletList (1-based ids, vector order)."""
+        out = np.zeros(4096, dtype=np.int64)
+        n = C.c_int64()
+        _lib.check(_lib.lib().pmc_get_verlet_neighbours(self._h, int(i), _lp(out), len(out), C.byref(n)), self._h)
+        return out[: n.value].copy()
 
     def get_neighbour_cells(self, c):
         out = np.zeros(27, dtype=np.int64)
