@@ -1389,7 +1389,7 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
     const int ncol = 1 << h->D;
     int nactive = 1;
     for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
-    const bool batch = (h->team == 4) && mp.npool == 1 && mp.kind[0] == 0;   // k_cb_pass<..., NW = 4, ONE>
+    const bool batch = (h->team == 4);                       // k_cb_pass<..., NW = 4, ...> keeps slot records in LDS
     const size_t lds = cb_lds_bytes(h, batch);
     int64_t launches = 0, timed_sweeps = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));

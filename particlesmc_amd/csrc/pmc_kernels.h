@@ -18,7 +18,7 @@
 #endif
 #define PMC_REF_IDS 2048     // neighbourhood size (ids) the ordered-energy LDS buffer holds (8 KB: 20 wavefronts per CU)
 #define PMC_MAXNN 27
-#define PMC_REC 10           // doubles per slot record: old xyz, new xyz, dE, T ln u, LDS slot, inside
+#define PMC_REC 12           // doubles per slot record: old xyz, new xyz, dE, T ln u, LDS slot i, valid, LDS slot j, move
 
 // ------------------------------------------------------------------------------
 // binning: cell index -> CSR (cell_start, ids ascending inside each cell)
@@ -1614,13 +1614,13 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;
-    const DevModel *tab = setup_lds<D, MULTI, ONE && (NW == 4)>(a, smem, h);
+    const DevModel *tab = setup_lds<D, MULTI, (NW == 4)>(a, smem, h);
     const int lane = wave_lane();
     const int tid = team_tid<NW>(), wv = team_wave<NW>();
     constexpr int TS = NW * PMC_WAVE;
     // speculative batches pay off where a cell visit is latency-bound (few cells per colour, teams of 4:
     // N=32768 +22 %); with teams of 2 the chip is VALU-bound and the shared candidate loop is as fast
-    constexpr bool BATCH = ONE && (NW == 4);
+    constexpr bool BATCH = (NW == 4);
     int aidx, colour = a.colour;
     if (a.fused) {
         // ticket order = colour order (see wait_lower_colours)
@@ -1699,6 +1699,30 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                 if (wv < K) {
                     const int my = __builtin_amdgcn_readfirstlane(s0 + wv);
                     const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, my);
+                    const int mm_ = ONE ? 0 : __builtin_amdgcn_readlane(g_m, my);
+                    if (MULTI && !ONE && a.pool.kind[mm_] != 0) {
+                        // DiscreteSwap slot: both particles and the fused four-energy difference by this wavefront alone
+                        const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)g_w2, my);
+                        const int sa = a.pool.sp0[mm_], sb = a.pool.sp1[mm_];
+                        const int na = count_species(h, sa), nb = count_species(h, sb);
+                        const bool valid = (na > 0 && nb > 0 && sa != sb);
+                        int pi = 0, pj = 0;
+                        double de = 0.0;
+                        if (valid) {
+                            pi = h.ctr + kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
+                            pj = h.ctr + kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
+                            de = swap_delta<D, KIND, MULTI, 1>(a, h, tab, pi, pj, sa, sb);
+                        }
+                        if (lane == 0) {
+                            double *r = h.rec + wv * PMC_REC;
+                            r[6] = de;
+                            r[7] = readlane_double(g_tlnu, my);
+                            r[8] = (double)pi;
+                            r[9] = valid ? 1.0 : 0.0;
+                            r[10] = (double)pj;
+                            r[11] = (double)mm_;
+                        }
+                    } else {
                     const int pc = h.ctr + (int)mulhi32(w1, (uint32_t)nc);
                     const double xo = h.cx[pc], yo = h.cy[pc], zo = (D == 3) ? h.cz[pc] : 0.0;
                     const double xn = xo + readlane_double(g_dx, my);
@@ -1760,6 +1784,9 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         r[7] = readlane_double(g_tlnu, my);
                         r[8] = (double)pc;
                         r[9] = inside ? 1.0 : 0.0;
+                        r[10] = -1.0;
+                        r[11] = (double)mm_;
+                    }
                     }
                 }
                 __syncthreads();           // every evaluation has read the pre-batch state; records are posted
@@ -1771,7 +1798,9 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         const int pj = (pr >= 3) ? 3 : ((pr >= 1) ? 2 : 1);
                         const int pi = pr - ((pj * (pj - 1)) >> 1);
                         double v = 0.0;
-                        if (lane < 24 && pj < K) {
+                        // record[10] >= 0 marks a DiscreteSwap slot (its second particle); pair terms exist between Displacement slots only
+                        const bool both_disp = ONE || (h.rec[pi * PMC_REC + 10] < 0.0 && h.rec[min(pj, NW - 1) * PMC_REC + 10] < 0.0);
+                        if (lane < 24 && pj < K && both_disp) {
                             const double *ri = h.rec + pi * PMC_REC, *rj = h.rec + pj * PMC_REC;
                             const int oi = (tt & 2) ? 0 : 3, oj = (tt & 1) ? 0 : 3;   // old or new coordinates
                             const double xi_ = ri[oi], yi_ = ri[oi + 1], zi_ = ri[oi + 2];
@@ -1799,6 +1828,10 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                     const double l_de = rl[6], l_tlnu = rl[7];
                     const int l_pc = (int)rl[8];
                     const bool l_in = rl[9] != 0.0;
+                    const int l_pj = (int)rl[10];
+                    const int l_m = ONE ? 0 : (int)rl[11];
+                    const bool l_swap = !ONE && MULTI && (l_pj >= 0);
+                    bool any_acc = false;
                     bool acc_[4] = {false, false, false, false};
                     double dec_[4] = {0, 0, 0, 0};
                     int nres = 0;
@@ -1808,7 +1841,9 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         if (j < K && !stop) {
                             const int pcj = __builtin_amdgcn_readlane(l_pc, j);
                             double dej = readlane_double(l_de, j);
-                            bool conflict = false;
+                            const bool swapj = (__ballot(l_swap && lane == j) != 0ull);
+                            // a swap slot was evaluated against species that any earlier accepted move may have touched
+                            bool conflict = swapj && any_acc;
 #pragma unroll
                             for (int i = 0; i < j; i++) {
                                 if (acc_[i]) {
@@ -1825,6 +1860,8 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                                 acc_[j] = okj;
                                 dec_[j] = dej;
                                 nres = j + 1;
+                                any_acc = any_acc || okj;
+                                if (swapj && okj) stop = true;      // later slots saw the old species: next batch
                             }
                         }
                     }
@@ -1838,10 +1875,20 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         }
                     }
                     att1 += (unsigned long long)nres;
+                    if (!ONE && lane < nres) {              // per-move counters of multi-move pools (this wavefront only)
+                        atomicAdd(&cnt[l_m], 1);
+                        if ((accmask >> lane) & 1u) atomicAdd(&cnt[8 + l_m], 1);
+                    }
                     if (lane < NW && ((accmask >> lane) & 1u)) {
-                        h.cx[l_pc] = rl[3];
-                        h.cy[l_pc] = rl[4];
-                        if (D == 3) h.cz[l_pc] = rl[5];
+                        if (l_swap) {
+                            const unsigned char si_ = h.csp[l_pc], sj_ = h.csp[l_pj];
+                            h.csp[l_pc] = sj_;
+                            h.csp[l_pj] = si_;
+                        } else {
+                            h.cx[l_pc] = rl[3];
+                            h.cy[l_pc] = rl[4];
+                            if (D == 3) h.cz[l_pc] = rl[5];
+                        }
                     }
                     if (lane == 0) h.flag[3] = nres;
                 }
