@@ -147,3 +147,44 @@ def test_pt_decide_is_deterministic_and_respects_detailed_balance(pmc):
     e2 = np.array([-1.0, 0.0])                         # (1 - 0.5) * (-1 - 0) = -0.5
     acc = sum(pt_decide(99, 2 * r, e2, ladder2, np.arange(2, dtype=np.int32))[1] for r in range(4000))
     assert abs(acc / 4000 - np.exp(-0.5)) < 0.03
+
+
+def test_cell_and_verlet_list_geometry_match_oracle(pmc):
+    """CellList / VerletList constructors (src/neighbours.jl:126-133, 405-406): the host geometry handed to the
+    device equals the oracle's for a sweep of boxes and cutoffs, and the host classes carry the reference's fields."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    checked = 0
+    for _ in range(200):
+        d = int(rng.integers(2, 4))
+        N = int(rng.integers(50, 400))
+        rho = float(rng.uniform(0.3, 1.3))
+        rcut = float(rng.uniform(1.0, 2.6))
+        dr = float(rng.uniform(0.05, 0.5))
+        box = pmc.system.box_from_density(N, rho, d)
+        if box[0] < 3.2 * (rcut + dr):
+            continue
+        pos = rng.uniform(0, box[0], (N, d))
+        for dx in (0.0, 1.0):
+            pos[0] = dx
+        sp = np.ones(N, dtype=np.int32)
+        m = O.single(O.lennard_jones(1.0, 1.0, rcut))                # random points never coincide: finite energy
+        cl = pmc.CellList(box, rcut, N)
+        ocl = O.System(pos, sp, rho, 1.0, m, O.CELLLIST)
+        pairs = [(cl, ocl)]
+        try:
+            vl = pmc.VerletList(box, rcut, N, list_parameters={"dr": dr})
+        except pmc.PMCError:
+            # Int(box / cell) is inexact for this box (src/neighbours.jl:406 throws InexactError): the oracle refuses too
+            with pytest.raises(ValueError):
+                O.System(pos, sp, rho, 1.0, m, O.VERLETLIST, dr)
+        else:
+            pairs.append((vl, O.System(pos, sp, rho, 1.0, m, O.VERLETLIST, dr)))
+            assert vl.dr == dr and vl.dr2o4 == (dr * dr) / 4
+            checked += 1
+        for host, orc in pairs:
+            cell, nc = orc.cell_geometry()
+            assert np.array_equal(host.box, np.asarray(cell)[:d]) and tuple(host.ncells) == tuple(int(v) for v in nc[:d])
+    assert checked > 50
+    with pytest.raises(ValueError):
+        pmc.VerletList(np.array([10.0, 10.0]), 2.5, 10)              # "Verlet list must have dr as a parameter"
