@@ -81,6 +81,7 @@ struct pmc_system {
     double *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr;
     unsigned char *d_ssp = nullptr;
     bool mc_binned = false;      // CSR + SoA consistent with d_pos
+    bool count_is_zero = false;  // d_count[0..ncell_mc] is all zero (left so by the last throughput scan)
     unsigned long long *d_stats = nullptr;
     double *d_result = nullptr;
     int max_count = 0;
@@ -714,14 +715,20 @@ extern "C" int pmc_get_verlet_neighbours(pmc_system *h, int64_t i, int64_t *out,
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
-static int scan_counts(pmc_system *h, int ncell, int *d_start)
+// exclusive scan of d_count into d_start; zero != 0 also clears d_count for the next binning pass
+static int scan_counts(pmc_system *h, int ncell, int *d_start, int zero = 0)
 {
+    if (ncell <= PMC_SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, h->stream, h->d_count, ncell, d_start, zero);
+        HIPCHK(h, hipGetLastError());
+        return PMC_OK;
+    }
     const int ntiles = nblk(ncell, PMC_SCAN_TILE);
     int *d_total = h->d_hist + 8 * 256;
     hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, h->stream, h->d_count, ncell, h->d_tile_sum);
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, h->stream, h->d_tile_sum, ntiles, d_total);
     hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(1024), 0, h->stream, h->d_count, ncell, h->d_tile_sum, d_total,
-                       d_start);
+                       d_start, zero);
     HIPCHK(h, hipGetLastError());
     return PMC_OK;
 }
@@ -732,6 +739,7 @@ static int bin_by_cell(pmc_system *h, int ncell, int *d_start, int *d_ids)
     const int N = h->N;
     HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)ncell + 1) * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_fill, 0, ((size_t)ncell + 1) * sizeof(int), h->stream));
+    h->count_is_zero = false;
     hipLaunchKernelGGL(k_count, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, h->d_count);
     if (int rc = scan_counts(h, ncell, d_start)) return rc;
     hipLaunchKernelGGL(k_scatter, dim3(nblk(N, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, d_start, h->d_fill,
@@ -1078,22 +1086,27 @@ extern "C" int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de)
 
 // ---- throughput engine -----------------------------------------------------------------
 
-static int mc_bin(pmc_system *h, const double shift[3])
+static int mc_bin(pmc_system *h, const double shift[3], const SlotGen *slots = nullptr)
 {
     const int N = h->N;
     const int nb = nblk(N, 256);
     for (int q = 0; q < 3; q++) h->grid.shift[q] = q < h->D ? shift[q] : 0.0;
-    HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)h->ncell_mc + 1) * sizeof(int), h->stream));
+    SlotGen gen;
+    memset(&gen, 0, sizeof gen);
+    if (slots) gen = *slots;
+    // the scan of the previous throughput binning left the counters zeroed (k_scan_*: zero = 1)
+    if (!h->count_is_zero) HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)h->ncell_mc + 1) * sizeof(int), h->stream));
     if (h->D == 3) hipLaunchKernelGGL(k_mc_bin_a<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival);
     else hipLaunchKernelGGL(k_mc_bin_a<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival);
-    if (int rc = scan_counts(h, h->ncell_mc, h->d_start)) return rc;
+    if (int rc = scan_counts(h, h->ncell_mc, h->d_start, 1)) return rc;
+    h->count_is_zero = true;
     hipLaunchKernelGGL(k_mc_bin_b, dim3(nb), dim3(256), 0, h->stream, h->d_cell_of, h->d_arrival, N, h->d_start, h->d_tmp_ids);
     if (h->D == 3)
         hipLaunchKernelGGL(k_mc_bin_c<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->d_species, h->d_cell_of, N, h->d_start,
-                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
+                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp, gen);
     else
         hipLaunchKernelGGL(k_mc_bin_c<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->d_species, h->d_cell_of, N, h->d_start,
-                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp);
+                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp, gen);
     HIPCHK(h, hipGetLastError());
     h->mc_binned = true;
     return PMC_OK;
@@ -1400,8 +1413,25 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
         philox4x32(0, 0, s_lo, s_hi | ((uint32_t)TAG_SHIFT << 24), h->key[0], h->key[1], W);
         double shift[3] = {0, 0, 0};
         for (int q = 0; q < h->D; q++) shift[q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
-        rc = mc_bin(h, shift);
+        SlotGen sg;
+        memset(&sg, 0, sizeof sg);
+        {
+            const size_t Ns = (size_t)h->N;
+            sg.enabled = 1;
+            sg.s_lo = s_lo; sg.s_hi = s_hi; sg.key0 = h->key[0]; sg.key1 = h->key[1];
+            sg.temperature = h->p.temperature;
+            sg.pool = mp;
+            sg.out = SlotOut{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
+        }
+        // small systems: generated inside pass C of the binning (one launch fewer); large ones: own launch (coalesced stores)
+        const bool fuse_slots = h->N < 500000;
+        rc = mc_bin(h, shift, fuse_slots ? &sg : nullptr);
         if (rc) return rc;
+        if (!fuse_slots) {
+            const int nbs = nblk(h->N, 256);
+            if (h->D == 3) hipLaunchKernelGGL(k_mc_slots<3>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
+            else hipLaunchKernelGGL(k_mc_slots<2>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
+        }
         // fused launches stream the cells of every colour in the same spatial order, so that the cells a
         // workgroup waits for were ticketed long before it (a pipeline with one tail per sweep); separate
         // colour launches sort each colour longest-first to shorten their eight tails
@@ -1413,15 +1443,8 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
         }
         CbArgs a = cb_args(h);
         a.order = lpt ? h->d_order : nullptr;
-        {
-            const size_t Ns = (size_t)h->N;
-            SlotOut so{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
-            const int nbs = nblk(h->N, 256);
-            if (h->D == 3) hipLaunchKernelGGL(k_mc_slots<3>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, s_lo, s_hi, h->key[0], h->key[1], h->p.temperature, mp, so);
-            else hipLaunchKernelGGL(k_mc_slots<2>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, s_lo, s_hi, h->key[0], h->key[1], h->p.temperature, mp, so);
-            a.slot_tlnu = so.tlnu; a.slot_dx = so.dx; a.slot_dy = so.dy; a.slot_dz = so.dz;
-            a.slot_w1 = so.w1; a.slot_w2 = so.w2; a.slot_m = so.m;
-        }
+        a.slot_tlnu = sg.out.tlnu; a.slot_dx = sg.out.dx; a.slot_dy = sg.out.dy; a.slot_dz = sg.out.dz;
+        a.slot_w1 = sg.out.w1; a.slot_w2 = sg.out.w2; a.slot_m = sg.out.m;
         a.s_lo = s_lo; a.s_hi = s_hi;
         a.pool = mp;
         a.all_cells = 0;

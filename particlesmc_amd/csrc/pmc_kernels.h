@@ -84,11 +84,34 @@ __global__ void k_mc_bin_b(const int *__restrict__ cell_of, const int *__restric
 }
 
 // pass C: rank by id inside the cell (deterministic order) and gather the cell-sorted SoA copy
+// optional second job of pass C: the random numbers of proposal slot (cell c, t = rank r), see k_mc_slots
+struct SlotOut {
+    double *tlnu, *dx, *dy, *dz;
+    uint32_t *w1, *w2;
+    unsigned char *m;
+};
+struct MovePool {
+    int npool;
+    int kind[8];
+    int sp0[8], sp1[8];       // 0-based species
+    double prob[8];
+    double sigma[8];
+};
+struct SlotGen {
+    int enabled;
+    uint32_t s_lo, s_hi, key0, key1;
+    double temperature;
+    MovePool pool;
+    SlotOut out;
+};
+template <int D>
+__device__ __forceinline__ void generate_slot(const SlotGen &g, int lin, int t, int k);
+
 template <int D>
 __global__ void k_mc_bin_c(const double *__restrict__ pos, const int *__restrict__ species,
                            const int *__restrict__ cell_of, int N, const int *__restrict__ start,
                            const int *__restrict__ tmp_ids, int *__restrict__ ids, double *__restrict__ sx,
-                           double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp)
+                           double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp, SlotGen gen)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -102,6 +125,7 @@ __global__ void k_mc_bin_c(const double *__restrict__ pos, const int *__restrict
     sy[dst] = pos[(size_t)i * D + 1];
     if (D == 3) sz[dst] = pos[(size_t)i * D + 2];
     ssp[dst] = (unsigned char)species[i];
+    if (gen.enabled) generate_slot<D>(gen, c, r, dst);
 }
 
 // three-launch exclusive scan: tile sums, scan of the tile sums, tile scan + base
@@ -159,8 +183,8 @@ __global__ __launch_bounds__(1024) void k_scan_tops(int *__restrict__ tile_sum, 
     if (threadIdx.x == 0) *total = carry;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_apply(const int *__restrict__ count, int n, const int *__restrict__ tile_sum,
-                                                     const int *__restrict__ total, int *__restrict__ start)
+__global__ __launch_bounds__(1024) void k_scan_apply(int *__restrict__ count, int n, const int *__restrict__ tile_sum,
+                                                     const int *__restrict__ total, int *__restrict__ start, int zero)
 {
     __shared__ int wsum[16];
     int i = blockIdx.x * PMC_SCAN_TILE + threadIdx.x;
@@ -168,7 +192,33 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const int *__restrict__ cou
     int incl = block_inclusive_scan_1024(v, wsum);
     if (i < n) start[i] = tile_sum[blockIdx.x] + incl - v;
     if (i == n - 1) start[n] = *total;
+    if (zero && i < n) count[i] = 0;        // leaves the counters ready for the next binning pass (no memset launch)
 }
+
+// the whole exclusive scan in one launch for small grids: one block walks the counts tile by tile (coalesced),
+// carrying the running total; larger grids take the three-launch scan (one block would serialise them)
+#define PMC_SCAN_SMALL_MAX 8192
+__global__ __launch_bounds__(1024) void k_scan_small(int *__restrict__ count, int n, int *__restrict__ start, int zero)
+{
+    __shared__ int wsum[16];
+    __shared__ int last;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < n) ? count[i] : 0;
+        const int incl = block_inclusive_scan_1024(v, wsum);
+        if (i < n) {
+            start[i] = carry + incl - v;
+            if (zero) count[i] = 0;
+        }
+        if (threadIdx.x == 1023) last = incl;
+        __syncthreads();
+        carry += last;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[n] = carry;
+}
+
 
 // longest-first ordering of the cells of each colour (counting sort by population, descending):
 // the tail of a colour pass then consists of its cheapest cells.
@@ -655,14 +705,6 @@ __global__ void k_ref_verlet_build(RefArgs a)
 
 enum { OP_DISP_PERFORM = 0, OP_DISP_REVERT = 1, OP_SWAP_PERFORM = 2, OP_SWAP_REVERT = 3, OP_STEPS = 4 };
 
-struct MovePool {
-    int npool;
-    int kind[8];
-    int sp0[8], sp1[8];       // 0-based species
-    double prob[8];
-    double sigma[8];
-};
-
 __device__ __host__ __forceinline__ int select_move(const MovePool &p, uint32_t w)
 {
     if (p.npool == 1) return 0;
@@ -857,38 +899,42 @@ __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
 // ------------------------------------------------------------------------------
 
 // The random numbers of every proposal slot of one sweep: slot t of cell c is the
-// cell-sorted index k = start[c] + t, so one thread per k generates all N slots with every lane busy
-// (inside k_cb_pass the same arithmetic ran on ~18 of 64 lanes, once per wavefront of the team).
-struct SlotOut {
-    double *tlnu, *dx, *dy, *dz;
-    uint32_t *w1, *w2;
-    unsigned char *m;
-};
+// cell-sorted index k = start[c] + t, so one thread per particle (pass C of the binning, which knows its
+// cell and rank) generates all N slots with every lane busy; inside k_cb_pass the same arithmetic ran on
+// ~18 of 64 lanes, once per wavefront of the team.
+template <int D>
+__device__ __forceinline__ void generate_slot(const SlotGen &g, int lin, int t, int k)
+{
+    uint32_t R[4], Q[4];
+    philox4x32((uint32_t)lin, (uint32_t)t, g.s_lo, g.s_hi | ((uint32_t)TAG_SLOT0 << 24), g.key0, g.key1, R);
+    philox4x32((uint32_t)lin, (uint32_t)t, g.s_lo, g.s_hi | ((uint32_t)TAG_SLOT1 << 24), g.key0, g.key1, Q);
+    const int m = (g.pool.npool == 1) ? 0 : select_move(g.pool, R[0]);
+    double z[4];
+    box_muller(Q[0], Q[1], &z[0], &z[1]);
+    box_muller(Q[2], Q[3], &z[2], &z[3]);
+    // per-move sigma without a dynamically indexed kernel argument (select chain)
+    double sg = g.pool.sigma[0];
+#pragma unroll
+    for (int q = 1; q < 8; q++) sg = (m == q) ? g.pool.sigma[q] : sg;
+    g.out.tlnu[k] = g.temperature * det_log(uniform53(R[2], R[3]));
+    g.out.dx[k] = sg * z[0];
+    g.out.dy[k] = sg * z[1];
+    if (D == 3) g.out.dz[k] = sg * z[2];
+    g.out.w1[k] = R[1];
+    g.out.w2[k] = Q[0];
+    g.out.m[k] = (unsigned char)m;
+}
+
+// the same as its own launch, one thread per cell-sorted slot: coalesced stores, which beats the scattered
+// stores of the fused form once the slot arrays outgrow the caches (N >~ 5e5)
 template <int D>
 __global__ __launch_bounds__(256) void k_mc_slots(int N, const int *__restrict__ ids, const int *__restrict__ cell_of,
-                                                  const int *__restrict__ start, uint32_t s_lo, uint32_t s_hi,
-                                                  uint32_t key0, uint32_t key1, double temperature, MovePool pool,
-                                                  SlotOut o)
+                                                  const int *__restrict__ start, SlotGen g)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     const int lin = cell_of[ids[k]];
-    const int t = k - start[lin];
-    uint32_t R[4], Q[4];
-    philox4x32((uint32_t)lin, (uint32_t)t, s_lo, s_hi | ((uint32_t)TAG_SLOT0 << 24), key0, key1, R);
-    philox4x32((uint32_t)lin, (uint32_t)t, s_lo, s_hi | ((uint32_t)TAG_SLOT1 << 24), key0, key1, Q);
-    const int m = (pool.npool == 1) ? 0 : select_move(pool, R[0]);
-    double z[4];
-    box_muller(Q[0], Q[1], &z[0], &z[1]);
-    box_muller(Q[2], Q[3], &z[2], &z[3]);
-    const double sg = pool.sigma[m];
-    o.tlnu[k] = temperature * det_log(uniform53(R[2], R[3]));
-    o.dx[k] = sg * z[0];
-    o.dy[k] = sg * z[1];
-    if (D == 3) o.dz[k] = sg * z[2];
-    o.w1[k] = R[1];
-    o.w2[k] = Q[0];
-    o.m[k] = (unsigned char)m;
+    generate_slot<D>(g, lin, k - start[lin], k);
 }
 
 struct CbArgs {
