@@ -72,7 +72,23 @@ __global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, in
         lin = lin * g.n[a] + r;
     }
     cell_of[i] = (int)lin;
-    arrival[i] = atomicAdd(&count[(int)lin], 1);
+    // one returning atomic per RUN of consecutive lanes that share a cell (ids are usually spatially coherent:
+    // 2-3 particles per run for lattice-ordered ids), the run head adds the run length and hands out the tickets
+    const int lane = threadIdx.x & (PMC_WAVE - 1);
+    const int c = (int)lin;
+    const int prev = __shfl_up(c, 1, PMC_WAVE);
+    const bool head = (lane == 0) || (prev != c);
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long am = __ballot(true);
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int my_head = 63 - __builtin_clzll(hm & le);
+    const unsigned long long after = (lane == 63) ? 0ull : (hm >> (lane + 1));
+    const int last_active = 63 - __builtin_clzll(am);
+    const int run_end = after ? lane + __builtin_ctzll(after) : last_active;       // last lane of my run (heads only use it)
+    int base = 0;
+    if (head) base = atomicAdd(&count[c], run_end - lane + 1);
+    base = __shfl(base, my_head, PMC_WAVE);
+    arrival[i] = base + (lane - my_head);
 }
 
 // pass B: place ids by ticket (order inside a cell still depends on atomic arrival)
