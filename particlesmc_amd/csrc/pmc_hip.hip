@@ -434,11 +434,13 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         // wavefronts per cell: small systems have too few cells per colour to fill 256 CUs with one
         // wavefront each; teams of 4 (speculative slot batches for single-Displacement pools) win up to
         // ~1500 cells per colour (N=32768 +30 %, N=110592 +23 %, N=175616 +11 % over teams of 2), above
-        // that two wavefronts per cell (half the LDS per wavefront, half the latency of a cell visit)
+        // that two wavefronts per cell (half the LDS per wavefront, half the latency of a cell visit); up to ~500
+        // cells per colour (N <~ 9e4) teams of 8 resolve eight slots per batch (N=13824 +13 %, N=32768 +11 %,
+        // N=64000 +13 %, N=85184 +9 % over teams of 4; N=110592 -12 %)
         long long nact = 1;
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
-        h->team = (nact <= 1536) ? 4 : 2;
-        if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4) h->team = t; }
+        h->team = (nact <= 512) ? 8 : ((nact <= 1536) ? 4 : 2);
+        if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4 || t == 8) h->team = t; }
     }
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
     CR(hipMalloc(&h->d_ids_ref, N * sizeof(int)));
@@ -1165,9 +1167,9 @@ static int cb_cap(const pmc_system *h)
     return std::min(std::max(cap, 128), PMC_CAP_MAX);
 }
 
-static size_t cb_lds_bytes(const pmc_system *h, bool batch = false)
+static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
 {
-    size_t b = (pmc_lds_wave_bytes(cb_cap(h), h->S > 1, batch) + 15) & ~(size_t)15;
+    size_t b = (pmc_lds_wave_bytes(cb_cap(h), h->S > 1, batch_nw) + 15) & ~(size_t)15;
     if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
     if (const char *e = getenv("PMC_LDS_PAD")) b += (size_t)atoi(e);   // occupancy experiments
     return b;
@@ -1185,7 +1187,8 @@ static size_t cb_lds_bytes(const pmc_system *h, bool batch = false)
 #define DISPATCH_CB_KIND(DD, KK, h, grid, lds, args)                                                            \
     DISPATCH_CB_ONE(DD, KK, 1, h, grid, lds, args)                                                              \
     DISPATCH_CB_ONE(DD, KK, 2, h, grid, lds, args)                                                              \
-    DISPATCH_CB_ONE(DD, KK, 4, h, grid, lds, args)
+    DISPATCH_CB_ONE(DD, KK, 4, h, grid, lds, args)                                                              \
+    DISPATCH_CB_ONE(DD, KK, 8, h, grid, lds, args)
 #define DISPATCH_CB(h, grid, lds, args)                                                                         \
     do {                                                                                                        \
         bool done_ = false;                                                                                     \
@@ -1402,8 +1405,7 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
     const int ncol = 1 << h->D;
     int nactive = 1;
     for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
-    const bool batch = (h->team == 4);                       // k_cb_pass<..., NW = 4, ...> keeps slot records in LDS
-    const size_t lds = cb_lds_bytes(h, batch);
+    const size_t lds = cb_lds_bytes(h, h->team >= 4 ? h->team : 0);   // teams of >= 4 keep slot records in LDS
     int64_t launches = 0, timed_sweeps = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     for (int64_t sw = 0; sw < nsweeps; sw++) {

@@ -1037,7 +1037,8 @@ struct WaveNbh {
     bool bounds;   // lo/hi below are valid: "stays in the cell" is  lo_a <= x_a < hi_a
     double lo[3], hi[3];
     double *part;  // [8] per-wavefront partial sums (workgroups of several wavefronts)
-    double *rec;   // [4][PMC_REC] records of the speculatively evaluated slots of one batch
+    double *rec;   // [NW][PMC_REC] records of the speculatively evaluated slots of one batch
+    double *cmat;  // [NW][NW] pair corrections c(i,j) of one batch
     int *flag;     // [4] workgroup flags
     int *cnt;      // [16] per-move attempted / accepted counters of this cell visit
 };
@@ -1234,7 +1235,7 @@ __device__ void compact_candidates(const CbArgs &a, WaveNbh &h)
     constexpr int MAXC = 8;                       // chunks of 64 candidates per wavefront held in registers
     const int lane = wave_lane(), wv = team_wave<NW>();
     const int nchunk = (h.ncand + PMC_WAVE - 1) / PMC_WAVE;
-    if (!a.filter || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW) return;
+    if (!a.filter || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW || nchunk > 32) return;   // segoff holds 32 chunk counts
     // box centre (in the frame of the first centre particle) and padded half width; candidates in
     // another periodic image are brought to the box by the minimum image (|t| <= 2 w <= L/2)
     double bc[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
@@ -1503,13 +1504,13 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
 // LDS bytes of one workgroup: coordinates, cached cell coordinates, partial sums, [batch records],
 // flags, counters, segment tables, [species].  Kept small on purpose: at N = 10^6 (cap 512) a team of
 // two wavefronts needs <= 13 312 B for twelve workgroups (six wavefronts per SIMD) per CU.
-__host__ __device__ inline size_t pmc_lds_wave_bytes(int cap, bool multi, bool batch)
+__host__ __device__ inline size_t pmc_lds_wave_bytes(int cap, bool multi, int batch_nw)
 {
-    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (batch ? PMC_REC * 4 * 8 : 0) + 4 * 4 + 16 * 4 + 2 * 32 * 4 +
-           (multi ? cap : 0);
+    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (size_t)(PMC_REC * batch_nw + batch_nw * batch_nw) * 8 + 4 * 4 + 16 * 4 +
+           2 * 32 * 4 + (multi ? cap : 0);
 }
 
-template <int D, bool MULTI, bool BATCH = false>
+template <int D, bool MULTI, int BATCH = 0>   // BATCH: team size of the speculative slot batches (0: none)
 __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned char *smem, WaveNbh &h)
 {
     h.cap = a.cap;
@@ -1519,7 +1520,8 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cfl = h.cz + h.cap;
     h.part = h.cfl + 3 * PMC_CFL;
     h.rec = h.part + 8;
-    h.flag = reinterpret_cast<int *>(h.rec + (BATCH ? PMC_REC * 4 : 0));
+    h.cmat = h.rec + PMC_REC * BATCH;
+    h.flag = reinterpret_cast<int *>(h.cmat + BATCH * BATCH);
     h.cnt = h.flag + 4;
     h.segoff = h.cnt + 16;
     h.segsrc = h.segoff + 32;
@@ -1676,13 +1678,13 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;
-    const DevModel *tab = setup_lds<D, MULTI, (NW == 4)>(a, smem, h);
+    const DevModel *tab = setup_lds<D, MULTI, (NW >= 4 ? NW : 0)>(a, smem, h);
     const int lane = wave_lane();
     const int tid = team_tid<NW>(), wv = team_wave<NW>();
     constexpr int TS = NW * PMC_WAVE;
     // speculative batches pay off where a cell visit is latency-bound (few cells per colour, teams of 4:
     // N=32768 +22 %); with teams of 2 the chip is VALU-bound and the shared candidate loop is as fast
-    constexpr bool BATCH = (NW == 4);
+    constexpr bool BATCH = (NW >= 4);
     int aidx, colour = a.colour;
     if (a.fused) {
         // ticket order = colour order (see wait_lower_colours)
@@ -1853,16 +1855,28 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                 }
                 __syncthreads();           // every evaluation has read the pre-batch state; records are posted
                 if (wv == 0) {
-                    // pair terms, lane-parallel: lane = 4 * pair(i,j) + t,  pair(i,j) = j (j - 1) / 2 + i,  i < j < K
-                    double c01 = 0, c02 = 0, c12 = 0, c03 = 0, c13 = 0, c23 = 0;
-                    if (K > 1) {
-                        const int pr = lane >> 2, tt = lane & 3;
-                        const int pj = (pr >= 3) ? 3 : ((pr >= 1) ? 2 : 1);
+                    // this lane's record (lanes 0..K-1)
+                    const int jl = min(lane, NW - 1);
+                    const double *rl = h.rec + jl * PMC_REC;
+                    const double l_de = rl[6], l_tlnu = rl[7];
+                    const int l_pc = (int)rl[8];
+                    const bool l_in = rl[9] != 0.0;
+                    const int l_pj = (int)rl[10];
+                    const int l_m = ONE ? 0 : (int)rl[11];
+                    const bool l_swap = !ONE && MULTI && (l_pj >= 0);
+                    // pair terms, lane-parallel: lane-term = 4 * pair(i,j) + t,  pair(i,j) = j (j - 1) / 2 + i,  i < j < K;
+                    // 16 pairs per pass; the quad sums c(i,j) go to an NW x NW matrix in LDS
+                    constexpr int NP = NW * (NW - 1) / 2;
+#pragma unroll
+                    for (int p0 = 0; p0 < NP; p0 += 16) {
+                        const int pr = p0 + (lane >> 2), tt = lane & 3;
+                        const int pj = 1 + (pr >= 1) + (pr >= 3) + (pr >= 6) + (pr >= 10) + (pr >= 15) + (pr >= 21);
                         const int pi = pr - ((pj * (pj - 1)) >> 1);
+                        const int pjc = min(pj, NW - 1);
                         double v = 0.0;
                         // record[10] >= 0 marks a DiscreteSwap slot (its second particle); pair terms exist between Displacement slots only
-                        const bool both_disp = ONE || (h.rec[pi * PMC_REC + 10] < 0.0 && h.rec[min(pj, NW - 1) * PMC_REC + 10] < 0.0);
-                        if (lane < 24 && pj < K && both_disp) {
+                        const bool both_disp = ONE || (h.rec[pi * PMC_REC + 10] < 0.0 && h.rec[pjc * PMC_REC + 10] < 0.0);
+                        if (pr < NP && pj < K && both_disp) {
                             const double *ri = h.rec + pi * PMC_REC, *rj = h.rec + pj * PMC_REC;
                             const int oi = (tt & 2) ? 0 : 3, oj = (tt & 1) ? 0 : 3;   // old or new coordinates
                             const double xi_ = ri[oi], yi_ = ri[oi + 1], zi_ = ri[oi + 2];
@@ -1875,65 +1889,50 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         }
                         v = dpp_add<0xB1>(v);
                         v = dpp_add<0x4E>(v);      // every lane of a quad holds the quad's (exact) sum
-                        c01 = readlane_double(v, 0);
-                        if (NW > 2) {
-                            c02 = readlane_double(v, 4);
-                            c12 = readlane_double(v, 8);
-                            c03 = readlane_double(v, 12);
-                            c13 = readlane_double(v, 16);
-                            c23 = readlane_double(v, 20);
-                        }
+                        if (tt == 0 && pr < NP) h.cmat[pi * NW + pjc] = v;
                     }
-                    // this lane's record (lanes 0..K-1), then the decisions in slot order
-                    const int jl = min(lane, NW - 1);
-                    const double *rl = h.rec + jl * PMC_REC;
-                    const double l_de = rl[6], l_tlnu = rl[7];
-                    const int l_pc = (int)rl[8];
-                    const bool l_in = rl[9] != 0.0;
-                    const int l_pj = (int)rl[10];
-                    const int l_m = ONE ? 0 : (int)rl[11];
-                    const bool l_swap = !ONE && MULTI && (l_pj >= 0);
-                    bool any_acc = false;
-                    bool acc_[4] = {false, false, false, false};
-                    double dec_[4] = {0, 0, 0, 0};
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i
+                    double creg[NW - 1];
+#pragma unroll
+                    for (int i = 0; i < NW - 1; i++) creg[i] = h.cmat[i * NW + jl];
+                    // decisions in slot order; lanes > i accumulate what an accepted slot i does to them
+                    double corr = 0.0;
+                    bool conf = false, any_acc = false, stop = false;
                     int nres = 0;
-                    bool stop = false;
-#pragma unroll
-                    for (int j = 0; j < NW; j++) {
-                        if (j < K && !stop) {
-                            const int pcj = __builtin_amdgcn_readlane(l_pc, j);
-                            double dej = readlane_double(l_de, j);
-                            const bool swapj = (__ballot(l_swap && lane == j) != 0ull);
-                            // a swap slot was evaluated against species that any earlier accepted move may have touched
-                            bool conflict = swapj && any_acc;
-#pragma unroll
-                            for (int i = 0; i < j; i++) {
-                                if (acc_[i]) {
-                                    conflict = conflict || (__builtin_amdgcn_readlane(l_pc, i) == pcj);
-                                    const double cij = (j == 1) ? c01 : ((j == 2) ? (i == 0 ? c02 : c12) : (i == 0 ? c03 : (i == 1 ? c13 : c23)));
-                                    dej += cij;
-                                }
-                            }
-                            if (conflict) {
-                                stop = true;
-                            } else {
-                                const bool inj = (__ballot(l_in && lane == j) != 0ull);
-                                const bool okj = inj && (readlane_double(l_tlnu, j) < -dej);
-                                acc_[j] = okj;
-                                dec_[j] = dej;
-                                nres = j + 1;
-                                any_acc = any_acc || okj;
-                                if (swapj && okj) stop = true;      // later slots saw the old species: next batch
-                            }
-                        }
-                    }
                     unsigned accmask = 0;
 #pragma unroll
-                    for (int j = 0; j < NW; j++) {
-                        if (acc_[j]) {
-                            accmask |= 1u << j;
-                            acc1 += 1;
-                            efix += (long long)(dec_[j] * PMC_FIX);
+                    for (int i = 0; i < NW; i++) {
+                        if (i < K && !stop) {
+                            const double dei = readlane_double(l_de + corr, i);
+                            const bool swapi = (__ballot(l_swap && lane == i) != 0ull);
+                            const bool confi = (__ballot(conf && lane == i) != 0ull);
+                            // a slot that re-selects a moved particle, or a swap slot after any accepted move (it was evaluated
+                            // against the species of the state before the batch), ends the batch and is evaluated again
+                            if (confi || (swapi && any_acc)) {
+                                stop = true;
+                            } else {
+                                const bool ini = (__ballot(l_in && lane == i) != 0ull);
+                                const bool oki = ini && (readlane_double(l_tlnu, i) < -dei);
+                                nres = i + 1;
+                                if (oki) {
+                                    accmask |= 1u << i;
+                                    acc1 += 1;
+                                    efix += (long long)(dei * PMC_FIX);
+                                    any_acc = true;
+                                    if (swapi) {
+                                        stop = true;            // later slots saw the old species: next batch
+                                    } else if (i < NW - 1) {
+                                        const int pci = __builtin_amdgcn_readlane(l_pc, i);
+                                        if (lane > i) {
+                                            corr += creg[i < NW - 1 ? i : 0];
+                                            conf = conf || (l_pc == pci);
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                     att1 += (unsigned long long)nres;

@@ -210,7 +210,7 @@ def test_long_run_bookkeeping_is_exact(gpu):
     assert g.get_counters()[1] == 20000
 
 
-@pytest.mark.parametrize("team", ["2", "4"])
+@pytest.mark.parametrize("team", ["2", "4", "8"])
 def test_fused_launch_equals_colour_launches_under_uneven_load(gpu, monkeypatch, team):
     """The fused sweep (all colours in one launch, cells released by their lower-colour neighbours'
     completion flags) must leave exactly the state of 2^d separate colour launches.  Half of the box is

@@ -83,7 +83,7 @@ def test_random_configuration_both_engines(gpu, case, monkeypatch):
     for var, p in (("PMC_TEAM", 0.6), ("PMC_NO_FILTER", 0.25), ("PMC_NO_ORDER", 0.25)):
         monkeypatch.delenv(var, raising=False)
         if rng.random() < p:
-            monkeypatch.setenv(var, str(int(rng.choice([1, 2, 4]))) if var == "PMC_TEAM" else "1")
+            monkeypatch.setenv(var, str(int(rng.choice([1, 2, 4, 8]))) if var == "PMC_TEAM" else "1")
     mm, mo = _models(pmc, O, rng, S)
     try:
         g = pmc.System(pos, sp, rho, T, mm, seed=seed, chain=chain)
@@ -240,7 +240,7 @@ def test_random_dense_configurations(gpu, case, monkeypatch):
     rcut = float(min(rng.uniform(3.4, 4.2), L / 4.0 * 0.999))
     T = float(rng.uniform(0.8, 1.6))
     seed = int(rng.integers(0, 2 ** 60))
-    monkeypatch.setenv("PMC_TEAM", str([1, 2, 4][case % 3]))
+    monkeypatch.setenv("PMC_TEAM", str([1, 2, 4, 8, 8, 4][case % 6]))
     arr = (O.Model * (S * S))()
     mm = [[None] * S for _ in range(S)]
     for i in range(S):
