@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collects the per-round evidence on an MI355X box (run through gpurun from the repo root):
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh'
+# then, back in the build container:  python profiles/summarize.py rNN
+# --pmc passes are separate runs and never share a command line with a trace domain other than --kernel-trace.
+cd /tmp; export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/prof; rm -rf gpurun_out/prof/trace gpurun_out/prof/fetch gpurun_out/prof/write gpurun_out/prof/sq
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/prof/bench_full.json 2> gpurun_out/prof/bench_full.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu > gpurun_out/prof/trace_bench.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/write -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/prof/sq -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
+python3 examples/throughput_table.py > gpurun_out/throughput_table.jsonl 2>&1
+ls gpurun_out/prof
