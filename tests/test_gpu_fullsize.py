@@ -97,9 +97,12 @@ def test_c3_kob_andersen_100k_properties(gpu):
     assert abs(g.total_energy()[0] - pmc.compute_energy_particles(g).sum() / 2) <= 1e-9 * abs(e_ref)
 
 
-def test_cli_toml_surface_end_to_end(gpu, tmp_path):
+@pytest.mark.parametrize("list_toml", ['list_type = "LinkedList"', 'list_type = "CellList"',
+                                       'list_type = "VerletList"\nlist_parameters = {dr = 0.2}', 'list_type = "EmptyList"'])
+def test_cli_toml_surface_end_to_end(gpu, tmp_path, list_toml):
     """`particlesmc params.toml` with the keys of test/params.toml (config_0.xyz, JBB, LinkedList,
-    T = 0.231, seed 10, Displacement sigma = 0.05); success + outputs in the reference's layout."""
+    T = 0.231, seed 10, Displacement sigma = 0.05); success + outputs in the reference's layout.  The
+    reference's other list types (test/runtests.jl:22-24) go through the same surface."""
     import shutil
     from particlesmc_amd import cli
     shutil.copy(os.path.join(GOLD, "config_0.xyz"), tmp_path / "config_0.xyz")
@@ -109,7 +112,7 @@ config = "config_0.xyz"
 temperature = 0.231
 density = 1.192060351952634
 model = "JBB"
-list_type = "LinkedList"
+''' + list_toml + '''
 
 [simulation]
 type = "Metropolis"
@@ -145,6 +148,7 @@ scheduler_params = {linear_interval = 20}
 fmt = "XYZ"
 ''')
     sim = cli.particlesmc(str(tmp_path / "params.toml"))
+    assert type(sim.chains[0].neighbour_list).__name__ == list_toml.split('"')[1]
     out = tmp_path / "data" / "out"
     en = np.loadtxt(out / "chains" / "1" / "energy.dat")
     assert en.shape == (5, 2) and list(en[:, 0]) == [0, 5, 10, 15, 20]
