@@ -440,6 +440,9 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         long long nact = 1;
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
         h->team = (nact <= 512) ? 8 : ((nact <= 1536) ? 4 : 2);
+        // 2-d neighbourhoods hold ~70-100 candidates: a shared candidate loop leaves half of two wavefronts' lanes
+        // empty, one wavefront per slot does not (N=65536 soft spheres, one chain: 3.4e8 vs 3.2e8 moves/s)
+        if (h->D == 2 && nact > 512 && nact <= 2048) h->team = 4;
         if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4 || t == 8) h->team = t; }
     }
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
