@@ -95,7 +95,7 @@ typedef struct {
     int64_t energy_fix;   /* same, in units of 2^-32 (checkerboard mode; exact) */
     double kernel_ms;     /* HIP-event time of the sweep kernels on the handle's stream */
     double sweep_kernel_ms; /* of which: the dE/Metropolis kernel alone */
-    int64_t sweep_kernel_launches;
+    int64_t sweep_kernel_launches; /* its launches in the timed sweeps: one per sweep (all colours fused), 2^d with PMC_NO_FUSED=1 */
 } pmc_stats;
 
 typedef struct pmc_system pmc_system;
