@@ -1062,11 +1062,36 @@ __device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
 //    contiguous in the cell-sorted arrays, so the neighbourhood is 3^(D-1) runs; every run is
 //    loaded with one coalesced load per array and all loads are in flight together.
 //  * Generic path: 3^D segments, centre first, located per candidate by binary search.
+// wait_colour > 0 (fused sweep): before the first coordinate is loaded the workgroup waits for the completion flags
+// of its lower-colour neighbour cells; the first poll is issued at the very top so that it
+// travels together with the loads of the CSR offsets instead of after them.
 template <int D, bool MULTI, int NW = 1>
-__device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h)
+__device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h, int wait_colour = 0)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
     constexpr int NR = (D == 3) ? 9 : 3;
+    bool poll_need = false;
+    int poll_lin = 0;
+    unsigned poll_v = 0;
+    if (wait_colour > 0 && team_wave<NW>() == 0) {
+        const int pl = wave_lane();
+        if (pl < NN) {
+            int r = pl, mask = 0;
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                const int o = (r % 3) - 1;
+                r /= 3;
+                int cq = cell[q] + o;
+                if (cq < 0) cq += a.n[q];
+                if (cq >= a.n[q]) cq -= a.n[q];
+                poll_lin = poll_lin * a.n[q] + cq;
+                if (o != 0) mask |= 1 << q;
+            }
+            poll_need = (mask != 0) && ((wait_colour ^ mask) < wait_colour);
+        }
+        poll_v = a.epoch;
+        if (poll_need) poll_v = __hip_atomic_load(a.done + poll_lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     constexpr int LD = D - 1;
     constexpr int TS = NW * PMC_WAVE;             // team stride
     const int lane = wave_lane();
@@ -1140,6 +1165,23 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
     h.ncand = __shfl(incl, h.nseg - 1, PMC_WAVE);
     if (lane == 0) h.segoff[h.nseg] = h.ncand;
     const int lim = min(h.ncand, h.cap);
+    if (wait_colour > 0) {
+        // a workgroup only ever waits for workgroups that already hold a ticket (see k_cb_pass): no deadlock; a bounded
+        // spin turns a lost flag into an error code (stats[17] bit 1) instead of a hang
+        if (team_wave<NW>() == 0) {
+            unsigned spins = 0;
+            while (__ballot(poll_v != a.epoch) != 0ull) {
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) atomicOr(&a.stats[17], 2ull);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                poll_v = a.epoch;
+                if (poll_need) poll_v = __hip_atomic_load(a.done + poll_lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
     if (runs_ok) {
         // centre cell sits inside the middle run
         h.ctr = __shfl(seg_off, (NR - 1) / 2, PMC_WAVE) + (h.k0 - __shfl(seg_start, (NR - 1) / 2, PMC_WAVE));
@@ -1621,44 +1663,8 @@ __device__ __forceinline__ int count_species(const WaveNbh &h, int sp)
 // higher colour start after this one has published).  Tickets are handed out in colour order, so a
 // workgroup only ever waits for workgroups that already hold a ticket, i.e. are resident or finished:
 // no deadlock whatever the dispatch order.  Wavefront 0 polls (relaxed agent-scope loads, one flag
-// per lane), the barrier releases the other wavefronts; the staged data is then read with sc1 loads.
-// A bounded spin turns a lost flag into an error code (stats[17] bit 1) instead of a hang.
-template <int D, int NW>
-__device__ __forceinline__ void wait_lower_colours(const CbArgs &a, int colour, const int cell[3])
-{
-    constexpr int NN = (D == 3) ? 27 : 9;
-    const int lane = wave_lane();
-    if (team_wave<NW>() == 0) {
-        bool need = false;
-        int lin2 = 0;
-        if (lane < NN) {
-            int r = lane, mask = 0;
-#pragma unroll
-            for (int q = 0; q < D; q++) {
-                const int o = (r % 3) - 1;
-                r /= 3;
-                int cq = cell[q] + o;
-                if (cq < 0) cq += a.n[q];
-                if (cq >= a.n[q]) cq -= a.n[q];
-                lin2 = lin2 * a.n[q] + cq;
-                if (o != 0) mask |= 1 << q;
-            }
-            need = (mask != 0) && ((colour ^ mask) < colour);
-        }
-        unsigned spins = 0;
-        for (;;) {
-            unsigned v = a.epoch;
-            if (need) v = __hip_atomic_load(a.done + lin2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot(v != a.epoch) == 0ull) break;
-            if (++spins > (1u << 22)) {
-                if (lane == 0) atomicOr(&a.stats[17], 2ull);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-}
+// per lane; inside stage_neighbourhood, overlapped with the CSR loads), a barrier releases the other
+// wavefronts; the staged data is then read with sc1 loads.
 
 // publish the end of a cell visit: every wavefront drains its stores, then one lane sets the flag
 __device__ __forceinline__ void publish_done(const CbArgs &a, int lin, bool leader)
@@ -1687,7 +1693,7 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
     constexpr bool BATCH = (NW >= 4);
     int aidx, colour = a.colour;
     if (a.fused) {
-        // ticket order = colour order (see wait_lower_colours)
+        // ticket order = colour order (see the comment above publish_done)
         if (tid == 0) h.flag[2] = (int)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
         __syncthreads();
         const int t = h.flag[2];
@@ -1700,8 +1706,7 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
     int cell[3] = {0, 0, 0}, lin;
     decode_cell<D>(a, colour, aidx, cell, lin);
     h.lin = lin;
-    if (a.fused && colour > 0) wait_lower_colours<D, NW>(a, colour, cell);
-    stage_neighbourhood<D, MULTI, NW>(a, cell, h);
+    stage_neighbourhood<D, MULTI, NW>(a, cell, h, a.fused ? colour : 0);
     const int nc = h.nc;
     if (nc == 0) { if (a.fused) publish_done(a, lin, tid == 0); return; }
     if (h.ctr + nc > h.cap) {
