@@ -1037,6 +1037,10 @@ struct WaveNbh {
     bool bounds;   // lo/hi below are valid: "stays in the cell" is  lo_a <= x_a < hi_a
     double lo[3], hi[3];
     double *part;  // [8] per-wavefront partial sums (workgroups of several wavefronts)
+    // proposal-slot values of the first chunk, fetched together with the coordinates (latency-bound teams only)
+    double p_tlnu, p_dx, p_dy, p_dz;
+    uint32_t p_w1, p_w2;
+    int p_m;
     double *rec;   // [NW][PMC_REC] records of the speculatively evaluated slots of one batch
     double *cmat;  // [NW][NW] pair corrections c(i,j) of one batch
     int *flag;     // [4] workgroup flags
@@ -1181,6 +1185,23 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
             }
         }
         __syncthreads();
+    }
+    if (NW >= 4 && a.slot_tlnu && !a.all_cells) {
+        // small systems: a cell visit is one dependent chain, so the slot values ride along with the coordinate loads
+        const int t = lane;
+        h.p_tlnu = h.p_dx = h.p_dy = h.p_dz = 0.0;
+        h.p_w1 = h.p_w2 = 0u;
+        h.p_m = 0;
+        if (t < h.nc) {
+            const int ks = h.k0 + t;
+            h.p_m = (int)a.slot_m[ks];
+            h.p_tlnu = a.slot_tlnu[ks];
+            h.p_w1 = a.slot_w1[ks];
+            h.p_w2 = a.slot_w2[ks];
+            h.p_dx = a.slot_dx[ks];
+            h.p_dy = a.slot_dy[ks];
+            if (D == 3) h.p_dz = a.slot_dz[ks];
+        }
     }
     if (runs_ok) {
         // centre cell sits inside the middle run
@@ -1740,7 +1761,15 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
         int g_m = 0;
         uint32_t g_w1 = 0, g_w2 = 0;
         double g_dx = 0, g_dy = 0, g_dz = 0, g_tlnu = 0;
-        if (t < nc) {
+        if (NW >= 4 && chunk == 0) {
+            g_m = ONE ? 0 : h.p_m;
+            g_tlnu = h.p_tlnu;
+            g_w1 = h.p_w1;
+            g_w2 = h.p_w2;
+            g_dx = h.p_dx;
+            g_dy = h.p_dy;
+            g_dz = h.p_dz;
+        } else if (t < nc) {
             const int ks = h.k0 + t;
             g_m = ONE ? 0 : (int)a.slot_m[ks];
             g_tlnu = a.slot_tlnu[ks];
