@@ -1,19 +1,18 @@
-# INTEGRATION — binding `libpmc_hip.so` from ParticlesMC (Julia)
-
-The reference has no FFI on this path. The glue below is what a ParticlesMC maintainer adds to route the
-LinkedList + pair-energy + Metropolis path through `include/pmc.h`. **It could not be executed in the build image**
-(no `julia`, no network; SURVEY F3) — it is written against the header and the reference's own types and is the
-Julia twin of the tested Python host in `particlesmc_amd/` (same call order, same argument meaning).
-
-Build the library once: `make -C particlesmc_amd/csrc` (hipcc, gfx950) → `libpmc_hip.so`.
-The code blocks of sections 1–4, plus the remaining verbs (`revert_action!`, `DiscreteSwap`), `refresh!`, `set_list_type!` and
-`sweep_many!`, are collected in one includable file: `julia/PMCHip.jl` (same caveat: reviewed against the header, not executed).
-
-## 1. Mirror structs (`include/pmc.h`)
-
-```julia
+# PMCHip.jl -- ccall glue between ParticlesMC.jl and libpmc_hip.so (include/pmc.h).
+#
+# This file is the code of INTEGRATION.md sections 1-4 in one place, so that a ParticlesMC maintainer can
+# `include("PMCHip.jl")` it next to the built library.  It was written against include/pmc.h and the reference's own
+# types; it could NOT be executed in the build image (no `julia`, no Arianna / StaticArrays: SURVEY F2, F3), so treat
+# it as reviewed-but-untested glue.  The tested twin of every call sequence in here is the Python host in
+# particlesmc_amd/ (same call order, same argument meaning), which the GPU test-suite exercises.
+#
+#   using ParticlesMC, Arianna, StaticArrays
+#   include("PMCHip.jl"); using .PMCHip
+#   chains = load_chains("config.xyz", args=Dict("temperature" => [1.0], "model" => ["LJ"], "list_type" => "HIPLinkedList"))
+#
 module PMCHip
 using StaticArrays
+import ParticlesMC, Arianna
 const LIB = joinpath(@__DIR__, "libpmc_hip.so")
 
 struct PairModel            # pmc_pair_model
@@ -49,15 +48,7 @@ end
 
 check(rc, h=C_NULL) = rc == 0 || error(unsafe_string(ccall((:pmc_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
 pad3(v, fill) = ntuple(a -> a <= length(v) ? v[a] : fill, 3)
-```
 
-## 2. A neighbour-list type that owns the device handle
-
-The plug-in protocol of `src/neighbours.jl:9-11,236,251,297,371` is kept: the constructor receives
-`(box, rcut, N; list_parameters)`, `build_neighbour_list!(system, L)` uploads and builds on the device, and the fields
-`cs, box (= cell size), ncells` are served from the device on demand.
-
-```julia
 mutable struct HIPLinkedList{T<:AbstractFloat,d} <: ParticlesMC.NeighbourList
     box::SVector{d,T}          # cell size, as in LinkedList (src/neighbours.jl:226)
     ncells::NTuple{d,Int}
@@ -102,31 +93,13 @@ function Base.getproperty(L::HIPLinkedList, s::Symbol)              # neighbour_
     end
     return getfield(L, s)
 end
-```
 
-The reference's other list types map the same way: construct with the geometry of `CellList` / `VerletList`
-(`pmc_cell_list_geometry`, `pmc_verlet_list_geometry`) and call `pmc_set_list_type(h, 2 | 3, dr)` (0 = `EmptyList`) right after
-`pmc_create`; the device then keeps `cells[c]` / `neighbours[i]` as id vectors in the reference's order
-(`pmc_get_cell_members`, `pmc_get_verlet_neighbours`) and sums per-particle energies in that list's iterator order.
-
-`System(...)` (`src/atoms.jl:40-58`) then works unchanged with `list_type=HIPLinkedList`: line 47 constructs it,
-line 50 builds on the device; for line 51 (`compute_energy_particle` for all `i`) add the method
-
-```julia
 function ParticlesMC.compute_energy_particle(system::ParticlesMC.Atoms, i, L::HIPLinkedList)   # src/atoms.jl:81-88
     e = Ref{Float64}(0.0)
     check(ccall((:pmc_energy_particle, LIB), Cint, (Ptr{Cvoid}, Int64, Ref{Float64}), L.handle, i, e), L.handle)
     return e[]
 end
-```
 
-(or, one launch for all particles, `pmc_energy_particles`; `pmc_init_energy` does lines 50–56 in one call and returns
-`PMC_ERR_NONFINITE` = -3 where the reference `error`s). These return the sum **in LinkedIterator order**, i.e. the same
-bits as the Julia loop.
-
-## 3. Per-move verbs (batch of one) — `src/moves.jl`
-
-```julia
 function ParticlesMC.perform_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.Displacement) where {D,V}
     e1, e2, de = Ref(0.0), Ref(0.0), Ref(0.0)                        # replaces src/moves.jl:57-67 (+ wrapper :11-20 bookkeeping on the device)
     δ = collect(Float64, action.δ)
@@ -137,17 +110,7 @@ function ParticlesMC.perform_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedLi
 end
 # revert_action! -> pmc_displacement_revert(h, action.i, action.δ (already inverted), action.δe)      src/moves.jl:76-81
 # DiscreteSwap   -> pmc_swap_perform(h, i, j, e1, e2, de) / pmc_swap_revert(h, i, j, δe)               src/moves.jl:187-207
-```
 
-Because the device owns positions, species, `SpeciesList` and `energy[1]` while a handle is live, the Julia arrays are
-refreshed with `pmc_download` / `pmc_get_energy` when IO or callbacks read them (`src/IO/IO.jl:365-372`, `src/utils.jl:51-53`).
-
-## 4. The accelerated entry: an algorithm beside `Metropolis`
-
-`src/ParticlesMC.jl:246` pushes `(algorithm=Metropolis, pool, seed, parallel, sweepstep=N)`. The HIP path is selected
-by pushing `algorithm=HIPMetropolis` instead (TOML: `[simulation] type = "HIPMetropolis"`, optional `mode`):
-
-```julia
 struct HIPMetropolis <: Arianna.Algorithm
     pool::Vector{CMove}; mode::Int32            # 0 = sequential (reference chain), 1 = checkerboard (throughput)
 end
@@ -163,17 +126,72 @@ function Arianna.make_step!(sim::Arianna.Simulation, alg::HIPMetropolis)        
         # st[].attempted / .accepted feed StoreAcceptance
     end
 end
-```
 
-With `parallel = true` replace the loop body by `pmc_sweep_begin` for every chain followed by `pmc_sweep_end` for every
-chain: each handle owns a HIP stream, so the chains' kernels overlap on the GPU (no Julia threads needed).
+# ---- the remaining per-move verbs (src/moves.jl:76-90, 187-214) ---------------------------------------------------
 
-`benchmark/particles_benchmarks.jl:29`'s `mc_sweep!(system, pool, rng; mc_steps=N)` maps to the same call with
-`nsweeps = mc_steps ÷ N`. The device consumes its own Philox streams keyed by `(seed, chain)` (DESIGN.md §2); an
-`AbstractRNG` wrapper over `pmc_sequential_words` lets the *Julia* reference be driven by the same stream for
-move-for-move comparison with `mode = 0`.
+function Arianna.revert_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.Displacement) where {D,V}
+    h = system.neighbour_list.handle                                # action.δ was inverted by invert_action! (src/moves.jl:88-90)
+    δ = collect(Float64, action.δ)
+    check(ccall((:pmc_displacement_revert, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Float64), h, action.i, δ, action.δe), h)
+    return nothing
+end
 
-## 5. What the Python host does instead
+function ParticlesMC.perform_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.DiscreteSwap) where {D,V}
+    h = system.neighbour_list.handle
+    e1, e2, de = Ref(0.0), Ref(0.0), Ref(0.0)
+    check(ccall((:pmc_swap_perform, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Float64}, Ref{Float64}, Ref{Float64}),
+                h, action.i, action.j, e1, e2, de), h)
+    action.δe = de[]
+    return e1[], e2[]
+end
 
-`particlesmc_amd/` is this same glue in Python over `ctypes` (`_lib.py` ↔ §1, `neighbours.py`/`system.py` ↔ §2,
-`moves.py` ↔ §3, `simulation.py`/`cli.py` ↔ §4) and is what the test-suite exercises on the GPU.
+function Arianna.revert_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.DiscreteSwap) where {D,V}
+    h = system.neighbour_list.handle                                # called with the inverted action (src/moves.jl:212-214)
+    check(ccall((:pmc_swap_revert, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Float64), h, action.i, action.j, action.δe), h)
+    return nothing
+end
+
+# ---- keeping the Julia-side arrays current for IO and callbacks (src/IO/IO.jl:365-372, src/utils.jl:51-53) ---------
+
+function refresh!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}) where {D,V}
+    h = system.neighbour_list.handle
+    pos = reinterpret(Float64, system.position)
+    sp = Vector{Int32}(undef, system.N)
+    GC.@preserve pos sp begin
+        check(ccall((:pmc_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}), h, pos, sp), h)
+    end
+    system.species .= sp
+    e = Ref(0.0)
+    check(ccall((:pmc_get_energy, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), h, e), h)
+    system.energy[1] = e[]
+    return system
+end
+
+set_temperature!(system, T) = check(ccall((:pmc_set_temperature, LIB), Cint, (Ptr{Cvoid}, Float64), system.neighbour_list.handle, T),
+                                    system.neighbour_list.handle)
+
+# ---- the reference's other list types on the device's reference-order engine --------------------------------------
+# Construct HIPLinkedList with the geometry of that list (pmc_cell_list_geometry / pmc_verlet_list_geometry) and call
+# this right after pmc_create: 0 EmptyList, 1 LinkedList, 2 CellList, 3 VerletList (dr = list_parameters["dr"]).
+set_list_type!(L::HIPLinkedList, list_type::Integer, dr::Real=0.0) =
+    check(ccall((:pmc_set_list_type, LIB), Cint, (Ptr{Cvoid}, Int32, Float64), L.handle, list_type, dr), L.handle)
+
+# ---- chains in flight concurrently (parallel = true): one HIP stream per handle ------------------------------------
+
+function sweep_many!(systems, pool::Vector{CMove}, nsweeps::Integer; mode::Integer=1)
+    for s in systems
+        h = s.neighbour_list.handle
+        check(ccall((:pmc_sweep_begin, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{CMove}, Int32, Int64), h, mode, pool, length(pool), nsweeps), h)
+    end
+    stats = Vector{Stats}(undef, length(systems))
+    for (k, s) in enumerate(systems)
+        h = s.neighbour_list.handle
+        st = Ref{Stats}()
+        check(ccall((:pmc_sweep_end, LIB), Cint, (Ptr{Cvoid}, Ref{Stats}), h, st), h)
+        stats[k] = st[]
+        s.energy[1] = st[].energy
+    end
+    return stats
+end
+
+end # module PMCHip
