@@ -2,10 +2,10 @@
 import sys, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
 import numpy as np
 import particlesmc_amd as pmc
-from inputs import lj_lattice
+from particlesmc_amd.workloads import lj_lattice
 pos, sp, rho = lj_lattice(100, jitter=0.05, seed=42)
 s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
 s.total_energy()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the checkerboard engine over the BASELINE configurations and other sizes
-(the numbers quoted in DESIGN.md section 5).  One MI355X, synthetic inputs of tests/inputs.py.
+(the numbers quoted in DESIGN.md section 5).  One MI355X, synthetic inputs of particlesmc_amd/workloads.py.
 
   python examples/throughput_table.py            # all rows
   python examples/throughput_table.py lj ka      # selected groups: lj, ka, ss2d, many, equil
@@ -12,11 +12,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import particlesmc_amd as pmc  # noqa: E402
-from inputs import binary_lattice, lj_lattice  # noqa: E402
+from particlesmc_amd.workloads import binary_lattice, lj_lattice  # noqa: E402
 
 
 def disp(sigma=0.05, p=1.0):

@@ -24,6 +24,7 @@ struct pmc_system {
     double energy = 0.0;         // system.energy[1]
     long long e_fix = 0;
     bool e_fix_valid = false;
+    bool energy_stale = false;   // a partial throughput sweep changed positions without folding its dE: recompute before use
     uint64_t step_ctr = 0, sweep_ctr = 0;
     uint32_t key[2] = {0, 0};
     // particle-id-ordered state
@@ -581,15 +582,19 @@ extern "C" int pmc_get_temperature(pmc_system *h, double *T)
     *T = h->p.temperature;
     return PMC_OK;
 }
+static int refresh_stale_energy(pmc_system *h);
+
 extern "C" int pmc_set_energy(pmc_system *h, double e)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_energy: null handle");
     h->energy = e;
+    h->energy_stale = false;
     return PMC_OK;
 }
 extern "C" int pmc_get_energy(pmc_system *h, double *e)
 {
     if (!h || !e) return fail(h, PMC_ERR_BADARG, "pmc_get_energy: null argument");
+    if (int rc = refresh_stale_energy(h)) return rc;
     *e = h->energy;
     return PMC_OK;
 }
@@ -916,6 +921,7 @@ extern "C" int pmc_init_energy(pmc_system *h, double *e)
     if (std::isinf(en) || std::isnan(en))              // src/atoms.jl:53-55
         return fail(h, PMC_ERR_NONFINITE, "Initial configuration has infinite or NaN energy.");
     h->energy = en;
+    h->energy_stale = false;
     h->e_fix_valid = false;
     if (e) *e = en;
     return PMC_OK;
@@ -984,8 +990,21 @@ static MovePool make_pool(const pmc_move *pool, int npool)
     return mp;
 }
 
+// system.energy[1] after a throughput sweep that failed part-way (cb_invalidate): recomputed from the
+// current positions (exact sum) before anything reads it
+static int refresh_stale_energy(pmc_system *h)
+{
+    if (!h->energy_stale) return PMC_OK;
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    h->energy_stale = false;
+    const int rc = pmc_total_energy(h, nullptr, nullptr);
+    if (rc) h->energy_stale = true;
+    return rc;
+}
+
 static int ref_op_launch(pmc_system *h, RefOp &o)
 {
+    if (int rs = refresh_stale_energy(h)) return rs;
     RefArgs a = ref_args(h);
     HIPCHK(h, hipMemcpyAsync(h->d_energy, &h->energy, sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (h->D == 3) hipLaunchKernelGGL(k_ref_ops<3>, dim3(1), dim3(64), 0, h->stream, a, o);
@@ -1231,9 +1250,11 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
 static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
 {
     if (st[17] & 1ull)
-        return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity");
+        return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity (that cell's slots were "
+                                            "skipped; moves accepted in other cells are kept and the energy is recomputed on the next call)");
     if (st[17] & 2ull)
-        return fail(h, PMC_ERR_STATE, "fused sweep: a cell's completion flag was never seen (state is invalid; upload again)");
+        return fail(h, PMC_ERR_STATE, "fused sweep: a cell's completion flag was never seen (positions were modified by a partial "
+                                      "sweep: the chain is invalid; upload the configuration again)");
     return PMC_OK;
 }
 
@@ -1276,6 +1297,7 @@ extern "C" int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix)
     h->e_fix = tot / 2;
     h->e_fix_valid = true;
     h->energy = (double)h->e_fix / PMC_FIX;
+    h->energy_stale = false;
     if (E) *E = h->energy;
     if (E_fix) *E_fix = h->e_fix;
     return PMC_OK;
@@ -1386,7 +1408,32 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
     return PMC_OK;
 }
 
+// after a failed or partial throughput sweep: positions may have changed, so the running energy, the
+// cell-sorted copy, the reference lists and the SpeciesList are all recomputed by their next consumer
+static void cb_invalidate(pmc_system *h)
+{
+    h->e_fix_valid = false;
+    h->energy_stale = true;
+    h->mc_binned = false;
+    h->cells_built = false;
+    h->count_is_zero = false;
+    if (h->S > 1) h->species_list_stale = true;
+}
+
+static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing);
+
 static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing)
+{
+    const int rc = cb_enqueue_sweeps(h, pool, npool, nsweeps, want_timing);
+    if (rc != PMC_OK && !h->pending) {
+        // an error part-way through the loop leaves launches queued: drain them, then distrust the state
+        (void)hipStreamSynchronize(h->stream);
+        cb_invalidate(h);
+    }
+    return rc;
+}
+
+static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing)
 {
     pmc_stats *out = want_timing ? &h->done_stats : nullptr;
     if (!h->mc_ok)
@@ -1514,7 +1561,13 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
     h->sweep_ctr += (uint64_t)nsweeps;
     h->cells_built = false;
     int rc = check_kernel_flags(h, st);
-    if (rc) return rc;
+    if (rc) {
+        // the other cells of these sweeps have committed their accepted moves: nothing derived from the
+        // state before the call may be trusted any more (a caller that falls back to PMC_SEQUENTIAL gets a
+        // freshly recomputed energy, a fresh binning and a fresh reference list)
+        cb_invalidate(h);
+        return rc;
+    }
 #ifdef PMC_DEBUG_COUNT
     fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], (double)st[24] / st[21]);
 #endif

@@ -67,13 +67,25 @@ def mc_sweep_many(systems, pool, nsweeps=1, mode="checkerboard"):
     enqueued on its own HIP stream before any is waited for, so small chains share the GPU."""
     arr = c_pool(pool)
     L = _lib.lib()
-    for s in systems:
-        _lib.check(L.pmc_sweep_begin(s._h, MODES[mode], arr, len(pool), int(nsweeps)), s._h)
-    out = []
-    for s in systems:
+    begun, out, first_error = [], [], None
+    try:
+        for s in systems:
+            _lib.check(L.pmc_sweep_begin(s._h, MODES[mode], arr, len(pool), int(nsweeps)), s._h)
+            begun.append(s)
+    except Exception as exc:           # the chains already in flight are still drained below
+        first_error = exc
+    # every handle that has begun is ended, whatever happens to the others: a handle left `pending`
+    # refuses every later call with PMC_ERR_STATE
+    for s in begun:
         st = _lib.Stats()
-        _lib.check(L.pmc_sweep_end(s._h, C.byref(st)), s._h)
-        out.append(SweepStats(st, len(pool)))
+        try:
+            _lib.check(L.pmc_sweep_end(s._h, C.byref(st)), s._h)
+            out.append(SweepStats(st, len(pool)))
+        except Exception as exc:
+            if first_error is None:
+                first_error = exc
+    if first_error is not None:
+        raise first_error
     return out
 
 

@@ -64,31 +64,53 @@ def _pools(pmc, rng, S, g):
     return pm, po
 
 
+def _oracle_accepts(O, pos, sp, rho, T, mo):
+    """The reference's LinkedList constructor rejects boxes where Int(box / cell) is inexact
+    (src/neighbours.jl:238); the oracle restates that as ValueError("bad arguments")."""
+    try:
+        O.System(pos, sp, rho, T, mo, O.LINKEDLIST)
+        return True
+    except ValueError as e:
+        assert "bad arguments" in str(e), e
+        return False
+
+
+def _draw_configuration(pmc, O, case):
+    """Case `case`, attempt 0, 1, ...: the first draw whose geometry the reference accepts.  No case skips;
+    the rejected geometries have their own test below."""
+    for attempt in range(50):
+        rng = np.random.default_rng(1000 + case + 100000 * attempt)
+        d = int(rng.choice([2, 3], p=[0.3, 0.7]))
+        n = int(rng.integers(24, 60)) if d == 2 else int(rng.integers(11, 19))
+        rho = float(rng.uniform(0.35, 1.25))
+        S = int(rng.choice([1, 2, 3]))
+        pos, sp, _ = lj_lattice(n, jitter=0.08 * rho ** (-1.0 / d), seed=case, rho=rho, d=d)
+        if S > 1:
+            sp = rng.integers(1, S + 1, size=len(sp)).astype(np.int32)
+            sp[:S] = np.arange(1, S + 1)                       # every species present
+        pos = pos + rng.integers(-1, 2, size=pos.shape) * (len(pos) / rho) ** (1.0 / d)   # unwrapped images
+        T = float(rng.uniform(0.5, 2.0))
+        seed, chain = int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 8))
+        env = {}
+        for var, p in (("PMC_TEAM", 0.6), ("PMC_NO_FILTER", 0.25), ("PMC_NO_ORDER", 0.25)):
+            if rng.random() < p:
+                env[var] = str(int(rng.choice([1, 2, 4, 8]))) if var == "PMC_TEAM" else "1"
+        mm, mo = _models(pmc, O, rng, S)
+        if _oracle_accepts(O, pos, sp, rho, T, mo):
+            return rng, d, S, pos, sp, rho, T, seed, chain, env, mm, mo
+    raise AssertionError(f"case {case}: no acceptable geometry in 50 draws")
+
+
 @pytest.mark.parametrize("case", range(NCASES))
 def test_random_configuration_both_engines(gpu, case, monkeypatch):
     from oracle import oracle as O
     pmc = gpu
-    rng = np.random.default_rng(1000 + case)
-    d = int(rng.choice([2, 3], p=[0.3, 0.7]))
-    n = int(rng.integers(24, 60)) if d == 2 else int(rng.integers(11, 19))
-    rho = float(rng.uniform(0.35, 1.25))
-    S = int(rng.choice([1, 2, 3]))
-    pos, sp, _ = lj_lattice(n, jitter=0.08 * rho ** (-1.0 / d), seed=case, rho=rho, d=d)
-    if S > 1:
-        sp = rng.integers(1, S + 1, size=len(sp)).astype(np.int32)
-        sp[:S] = np.arange(1, S + 1)                       # every species present
-    pos = pos + rng.integers(-1, 2, size=pos.shape) * (len(pos) / rho) ** (1.0 / d)   # unwrapped images
-    T = float(rng.uniform(0.5, 2.0))
-    seed, chain = int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 8))
-    for var, p in (("PMC_TEAM", 0.6), ("PMC_NO_FILTER", 0.25), ("PMC_NO_ORDER", 0.25)):
+    rng, d, S, pos, sp, rho, T, seed, chain, env, mm, mo = _draw_configuration(pmc, O, case)
+    for var in ("PMC_TEAM", "PMC_NO_FILTER", "PMC_NO_ORDER"):
         monkeypatch.delenv(var, raising=False)
-        if rng.random() < p:
-            monkeypatch.setenv(var, str(int(rng.choice([1, 2, 4, 8]))) if var == "PMC_TEAM" else "1")
-    mm, mo = _models(pmc, O, rng, S)
-    try:
-        g = pmc.System(pos, sp, rho, T, mm, seed=seed, chain=chain)
-    except (ValueError, RuntimeError) as e:                # geometry the reference itself rejects
-        pytest.skip(f"case {case}: {e}")
+    for var, val in env.items():
+        monkeypatch.setenv(var, val)
+    g = pmc.System(pos, sp, rho, T, mm, seed=seed, chain=chain)      # any exception here is a failure, not a skip
     pm, po = _pools(pmc, rng, S, g)
     pool_o = O.make_pool(po)
 
@@ -130,23 +152,25 @@ def test_random_operation_sequences(gpu, case):
     position/species round trips on ONE handle; after every operation the device state equals the oracle's."""
     from oracle import oracle as O
     pmc = gpu
-    rng = np.random.default_rng(5000 + case)
-    d = int(rng.choice([2, 3]))
-    n = int(rng.integers(26, 40)) if d == 2 else int(rng.integers(11, 14))
-    rho = float(rng.uniform(0.6, 1.2))
-    S = int(rng.choice([1, 2, 3]))
-    pos, sp, _ = lj_lattice(n, jitter=0.08 * rho ** (-1.0 / d), seed=100 + case, rho=rho, d=d)
-    N = len(pos)
-    if S > 1:
-        sp = rng.integers(1, S + 1, size=N).astype(np.int32)
-        sp[:S] = np.arange(1, S + 1)
-    T = float(rng.uniform(0.6, 1.8))
-    seed, chain = int(rng.integers(0, 2 ** 50)), int(rng.integers(0, 4))
-    mm, mo = _models(pmc, O, rng, S)
-    try:
-        g = pmc.System(pos, sp, rho, T, mm, seed=seed, chain=chain)
-    except (ValueError, RuntimeError) as e:
-        pytest.skip(f"case {case}: {e}")
+    for attempt in range(50):
+        rng = np.random.default_rng(5000 + case + 100000 * attempt)
+        d = int(rng.choice([2, 3]))
+        n = int(rng.integers(26, 40)) if d == 2 else int(rng.integers(11, 14))
+        rho = float(rng.uniform(0.6, 1.2))
+        S = int(rng.choice([1, 2, 3]))
+        pos, sp, _ = lj_lattice(n, jitter=0.08 * rho ** (-1.0 / d), seed=100 + case, rho=rho, d=d)
+        N = len(pos)
+        if S > 1:
+            sp = rng.integers(1, S + 1, size=N).astype(np.int32)
+            sp[:S] = np.arange(1, S + 1)
+        T = float(rng.uniform(0.6, 1.8))
+        seed, chain = int(rng.integers(0, 2 ** 50)), int(rng.integers(0, 4))
+        mm, mo = _models(pmc, O, rng, S)
+        if _oracle_accepts(O, pos, sp, rho, T, mo):
+            break
+    else:
+        raise AssertionError(f"case {case}: no acceptable geometry in 50 draws")
+    g = pmc.System(pos, sp, rho, T, mm, seed=seed, chain=chain)      # any exception here is a failure, not a skip
     pm, po = _pools(pmc, rng, S, g)
     pool_o = O.make_pool(po)
     o = O.System(pos, sp, rho, T, mo, O.LINKEDLIST)
@@ -264,3 +288,28 @@ def test_random_dense_configurations(gpu, case, monkeypatch):
     assert np.array_equal(st.attempted[: len(pm)], att) and np.array_equal(st.accepted[: len(pm)], acc)
     assert np.array_equal(g.position, cb.positions()) and np.array_equal(g.species, cb.species())
     assert st.energy_fix == cb.energy_fix == cb.total_energy_fix() == g.total_energy()[1]
+
+
+def test_geometry_the_reference_rejects_is_rejected_with_badarg(gpu):
+    """Int(box / cell) InexactError of the reference (src/neighbours.jl:238): the oracle says "bad arguments",
+    the library PMC_ERR_BADARG with the geometry message -- and nothing else is ever swallowed by this file."""
+    from oracle import oracle as O
+    from particlesmc_amd import _lib
+    pmc = gpu
+    found = 0
+    for k in range(400):
+        rng = np.random.default_rng(77000 + k)
+        n = int(rng.integers(11, 19))
+        rho = float(rng.uniform(0.35, 1.25))
+        pos, sp, _ = lj_lattice(n, jitter=0.05, seed=k, rho=rho, d=3)
+        rcut = float(rng.uniform(1.6, 2.6))
+        mo = O.single(O.lennard_jones(1.0, 1.0, rcut))
+        if _oracle_accepts(O, pos, sp, rho, 1.0, mo):
+            continue
+        with pytest.raises(pmc.PMCError) as ei:
+            pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0, rcut=rcut))
+        assert ei.value.code == _lib.PMC_ERR_BADARG and "box / cell is not a positive integer" in str(ei.value)
+        found += 1
+        if found == 3:
+            break
+    assert found >= 1, "no rejected geometry among 400 draws: the scan no longer exercises the rejection"
