@@ -3,7 +3,8 @@
 (the numbers quoted in DESIGN.md section 5).  One MI355X, synthetic inputs of particlesmc_amd/workloads.py.
 
   python examples/throughput_table.py            # all rows
-  python examples/throughput_table.py lj ka      # selected groups: lj, ka, ss2d, many, equil
+  python examples/throughput_table.py lj ka      # selected groups: lj, ka, ss2d, many, equil, images
+  PMC_TEAM=2 python examples/throughput_table.py lj   # with a fixed team width (every row carries the team in use)
 """
 import json
 import os
@@ -35,14 +36,15 @@ def rate(system, pool, sweeps, warm):
 
 
 def main():
-    groups = set(sys.argv[1:]) or {"lj", "ka", "ss2d", "many", "equil"}
+    groups = set(sys.argv[1:]) or {"lj", "ka", "ss2d", "many", "equil", "images"}
+    team = os.environ.get("PMC_TEAM", "auto")
     rows = []
     if "lj" in groups:
         for n, sw in ((16, 400), (24, 400), (32, 400), (48, 300), (64, 200), (100, 40), (128, 20), (200, 10)):
             pos, sp, rho = lj_lattice(n, jitter=0.05, seed=42)
             s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
             s.total_energy()
-            rows.append({"row": f"LJ rho=1 T=1 N={len(pos)}", **rate(s, [disp()], sw, max(2, sw // 10))})
+            rows.append({"row": f"LJ rho=1 T=1 N={len(pos)}", "team": team, **rate(s, [disp()], sw, max(2, sw // 10))})
             print(json.dumps(rows[-1]), flush=True)
     if "equil" in groups:
         pos, sp, rho = lj_lattice(100, jitter=0.05, seed=42)
@@ -50,6 +52,18 @@ def main():
         s.total_energy()
         rows.append({"row": "LJ N=1000000 after 2000 warm-up sweeps", **rate(s, [disp()], 100, 2000)})
         print(json.dumps(rows[-1]), flush=True)
+    if "images" in groups:
+        # every particle shifted by random whole boxes: positions are never wrapped (src/moves.jl:46-48), so this is what a
+        # long run of a liquid looks like to the kernels -- every cell visit takes the general minimum-image path
+        pos, sp, rho = lj_lattice(100, jitter=0.05, seed=42)
+        L = (len(pos) / rho) ** (1.0 / 3.0)
+        for shifted in (False, True):
+            p = pos + (np.random.default_rng(7).integers(-3, 4, size=pos.shape) * L if shifted else 0.0)
+            s = pmc.System(p, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+            s.total_energy()
+            rows.append({"row": "LJ N=1000000 " + ("shifted by random whole boxes" if shifted else "all in the primary box"), "team": team,
+                         **rate(s, [disp()], 40, 5)})
+            print(json.dumps(rows[-1]), flush=True)
     if "ka" in groups:
         for N, sw in ((100000, 100), (1000000, 20)):
             for swaps in (True, False):

@@ -96,6 +96,10 @@ typedef struct {
     double kernel_ms;     /* HIP-event time of the sweep kernels on the handle's stream */
     double sweep_kernel_ms; /* of which: the dE/Metropolis kernel alone */
     int64_t sweep_kernel_launches; /* its launches in the timed sweeps: one per sweep (all colours fused), 2^d with PMC_NO_FUSED=1 */
+    /* work counters of the throughput engine, counted by the kernel (0 in PMC_SEQUENTIAL mode): */
+    int64_t pair_tests;       /* (slot, candidate, old|new position) distance tests */
+    int64_t pairs_in_range;   /* pair energies evaluated (r2 <= rcut2, src/atoms.jl:72) */
+    int64_t null_moves;       /* attempted slots that evaluated no dE: Displacements that would leave their cell, swaps in a cell lacking a species */
 } pmc_stats;
 
 typedef struct pmc_system pmc_system;
@@ -196,6 +200,22 @@ int pmc_sweep_end(pmc_system *h, pmc_stats *out);
  * same all-gathered energies and gets the same answer. */
 int pmc_pt_decide(uint64_t seed, uint64_t round, int32_t n, const double *energy,
                   const double *temperature_ladder, int32_t *label, int32_t *n_accepted);
+
+/* One exchange round over n replicas that are handles of THIS process (one GPU, or one handle per device of the
+ * node): reads every handle's running energy, takes the pmc_pt_decide decisions and sets every handle's temperature to
+ * ladder[label[r]].  label (in/out, n entries) is the permutation "replica r holds temperature label[r]". */
+int pmc_replica_exchange(pmc_system **h, int32_t n, const double *temperature_ladder, uint64_t seed, uint64_t round,
+                         int32_t *label, int32_t *n_accepted);
+
+/* The same round for one-process-per-GPU hosts: the only collective of the path, ncclAllGather of ONE double per
+ * rank over RCCL / xGMI, on the handle's stream.  `comm` is an ncclComm_t (from the host's own RCCL binding, or from
+ * pmc_rccl_comm_create); librccl.so is opened on first use.  label has `world` entries and must be identical on
+ * every rank; every rank returns the same label and n_accepted. */
+int pmc_replica_exchange_rccl(pmc_system *h, void *nccl_comm, int32_t rank, int32_t world, const double *temperature_ladder,
+                              uint64_t seed, uint64_t round, int32_t *label, int32_t *n_accepted);
+int pmc_rccl_unique_id(void *id128);                                   /* ncclGetUniqueId: rank 0 calls it and ships the 128 bytes to the others */
+int pmc_rccl_comm_create(const void *id128, int32_t rank, int32_t world, int32_t device, void **nccl_comm);  /* ncclCommInitRank */
+int pmc_rccl_comm_destroy(void *nccl_comm);
 
 /* -- the schedule's random streams, host side (DESIGN.md "random streams") -- */
 int pmc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

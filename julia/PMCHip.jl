@@ -12,6 +12,7 @@
 #
 module PMCHip
 using StaticArrays
+import Random
 import ParticlesMC, Arianna
 const LIB = joinpath(@__DIR__, "libpmc_hip.so")
 
@@ -44,6 +45,7 @@ struct Stats                # pmc_stats
     attempted::NTuple{8,Int64}; accepted::NTuple{8,Int64}
     energy::Float64; energy_fix::Int64
     kernel_ms::Float64; sweep_kernel_ms::Float64; sweep_kernel_launches::Int64
+    pair_tests::Int64; pairs_in_range::Int64; null_moves::Int64
 end
 
 check(rc, h=C_NULL) = rc == 0 || error(unsafe_string(ccall((:pmc_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
@@ -192,6 +194,73 @@ function sweep_many!(systems, pool::Vector{CMove}, nsweeps::Integer; mode::Integ
         s.energy[1] = st[].energy
     end
     return stats
+end
+
+# ---- the device's sequential random stream as an AbstractRNG (the Julia twin of particlesmc_amd.SequentialStream) ----
+# Step k of the device's reference-order chain (pmc_sweep, mode 0) consumes one pair of Philox blocks (R, Q) =
+# pmc_sequential_words(seed, chain, k):  move index from R[1] against the pool's cumulative weights, particle
+# i = mulhi(R[2], N) + 1, ln u from (R[3], R[4]), displacement = sigma * BoxMuller(Q[1], Q[2]), BoxMuller(Q[3], Q[4])
+# (Julia 1-based indices into the NTuples below).  With the sample_action! / accept overloads underneath, Arianna's own
+# mc_step! driven by this RNG proposes and decides exactly what the device does, step for step: that is how the real
+# reference can be compared with the device move by move once a Julia binary is at hand.
+mutable struct SequentialWords <: Random.AbstractRNG
+    seed::UInt64
+    chain::UInt32
+    step::UInt64
+    R::NTuple{4,UInt32}
+    Q::NTuple{4,UInt32}
+    cursor::Int                     # next of the 8 words rand(rng, UInt32) hands out (generic consumers)
+end
+
+function load!(rng::SequentialWords)
+    R = Ref{NTuple{4,UInt32}}((0, 0, 0, 0)); Q = Ref{NTuple{4,UInt32}}((0, 0, 0, 0))
+    check(ccall((:pmc_sequential_words, LIB), Cint, (UInt64, UInt32, UInt64, Ref{NTuple{4,UInt32}}, Ref{NTuple{4,UInt32}}),
+                rng.seed, rng.chain, rng.step, R, Q))
+    rng.R, rng.Q, rng.cursor = R[], Q[], 1
+    return rng
+end
+SequentialWords(seed::Integer, chain::Integer=0, step::Integer=0) =
+    load!(SequentialWords(UInt64(seed), UInt32(chain), UInt64(step), (0, 0, 0, 0), (0, 0, 0, 0), 1))
+advance!(rng::SequentialWords) = (rng.step += 1; load!(rng))
+
+# generic AbstractRNG interface: the eight words of the current step in order, then the next step's
+function Random.rand(rng::SequentialWords, ::Random.SamplerType{UInt32})
+    rng.cursor > 8 && advance!(rng)
+    w = rng.cursor <= 4 ? rng.R[rng.cursor] : rng.Q[rng.cursor - 4]
+    rng.cursor += 1
+    return w
+end
+Random.rand(rng::SequentialWords, ::Random.SamplerType{UInt64}) = (UInt64(rand(rng, UInt32)) << 32) | UInt64(rand(rng, UInt32))
+Random.rng_native_52(::SequentialWords) = UInt64
+
+mulhi(w::UInt32, n::Integer) = Int((UInt64(w) * UInt64(n)) >> 32)
+function device_normals(rng::SequentialWords)
+    z = ntuple(_ -> Ref(0.0), 4)
+    ccall((:pmc_box_muller, LIB), Cint, (UInt32, UInt32, Ref{Float64}, Ref{Float64}), rng.Q[1], rng.Q[2], z[1], z[2])
+    ccall((:pmc_box_muller, LIB), Cint, (UInt32, UInt32, Ref{Float64}, Ref{Float64}), rng.Q[3], rng.Q[4], z[3], z[4])
+    return map(getindex, z)
+end
+function device_log_uniform(rng::SequentialWords)
+    v = Ref(0.0)
+    ccall((:pmc_log_uniform, LIB), Cint, (UInt32, UInt32, Ref{Float64}), rng.R[3], rng.R[4], v)
+    return v[]
+end
+
+# SimpleGaussian with the device's draws (replaces src/moves.jl:114-123 when rng isa SequentialWords)
+function Arianna.sample_action!(action::ParticlesMC.Displacement, ::ParticlesMC.SimpleGaussian, parameters, system::ParticlesMC.Particles,
+                                rng::SequentialWords)
+    action.i = mulhi(rng.R[2], length(system)) + 1
+    z = device_normals(rng)
+    action.δ = SVector{system.d,Float64}(ntuple(a -> parameters.σ * z[a], system.d))
+    return nothing
+end
+# DoubleUniform with the device's draws (replaces src/moves.jl:235-241)
+function Arianna.sample_action!(action::ParticlesMC.DiscreteSwap, ::ParticlesMC.DoubleUniform, parameters, system::ParticlesMC.Particles,
+                                rng::SequentialWords)
+    ids1 = system.species_list.sp_ids[action.species[1]]; ids2 = system.species_list.sp_ids[action.species[2]]
+    action.i = ids1[mulhi(rng.R[2], length(ids1)) + 1]
+    action.j = ids2[mulhi(rng.Q[1], length(ids2)) + 1]
+    return nothing
 end
 
 end # module PMCHip

@@ -408,3 +408,32 @@ def det_sincos2pi(w):
     a, b = C.c_double(), C.c_double()
     lib().orc_det_sincos2pi(w, C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+TAG_PT = 6
+
+
+def pt_decide(seed, rnd, energies, ladder, label):
+    """CPU restatement of one replica-exchange round (the reference has none: README.md:33).
+
+    label[r] = index of the temperature replica r holds.  Round `rnd` pairs the adjacent temperatures
+    (t, t + 1) for t = rnd & 1, +2, ...; the pair swaps iff ln u < (1/T_t - 1/T_{t+1}) (E_a - E_b) with
+    u the 53-bit uniform of Philox(ctr = (t, 0, rnd_lo, rnd_hi | TAG_PT << 24), key = seed).
+    Returns (new label, number of accepted swaps)."""
+    L = lib()
+    n = len(label)
+    lab = [int(v) for v in label]
+    holder = [-1] * n
+    for r, t in enumerate(lab):
+        holder[t] = r
+    acc = 0
+    for t in range(int(rnd) & 1, n - 1, 2):
+        ra, rb = holder[t], holder[t + 1]
+        arg = (1.0 / float(ladder[t]) - 1.0 / float(ladder[t + 1])) * (float(energies[ra]) - float(energies[rb]))
+        w = philox((t, 0, int(rnd) & 0xffffffff, ((int(rnd) >> 32) & 0xffffff) | (TAG_PT << 24)),
+                   (int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff))
+        lnu = L.orc_det_log(L.orc_uniform53(w[0], w[1]))
+        if lnu < arg:
+            lab[ra], lab[rb] = t + 1, t
+            acc += 1
+    return lab, acc

@@ -46,6 +46,7 @@ class Stats(C.Structure):
         ("attempted", C.c_int64 * MAX_MOVES), ("accepted", C.c_int64 * MAX_MOVES),
         ("energy", C.c_double), ("energy_fix", C.c_int64),
         ("kernel_ms", C.c_double), ("sweep_kernel_ms", C.c_double), ("sweep_kernel_launches", C.c_int64),
+        ("pair_tests", C.c_int64), ("pairs_in_range", C.c_int64), ("null_moves", C.c_int64),
     ]
 
 
@@ -100,6 +101,11 @@ SYMBOLS = {
     "pmc_sweep_begin": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64]),
     "pmc_sweep_end": (C.c_int, [_h, C.POINTER(Stats)]),
     "pmc_pt_decide": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int32, _dp, _dp, _ip, _ip]),
+    "pmc_replica_exchange": (C.c_int, [C.POINTER(_h), C.c_int32, _dp, C.c_uint64, C.c_uint64, _ip, _ip]),
+    "pmc_replica_exchange_rccl": (C.c_int, [_h, C.c_void_p, C.c_int32, C.c_int32, _dp, C.c_uint64, C.c_uint64, _ip, _ip]),
+    "pmc_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "pmc_rccl_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pmc_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
     "pmc_philox4x32": (C.c_int, [_up, _up, _up]),
     "pmc_box_muller": (C.c_int, [C.c_uint32, C.c_uint32, _dp, _dp]),
     "pmc_log_uniform": (C.c_int, [C.c_uint32, C.c_uint32, _dp]),

@@ -3,6 +3,9 @@
 #include "../../include/pmc.h"
 #include "pmc_kernels.h"
 
+#include <rccl/rccl.h>     // types only: the library itself is opened with dlopen on first use
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -25,6 +28,7 @@ struct pmc_system {
     long long e_fix = 0;
     bool e_fix_valid = false;
     bool energy_stale = false;   // a partial throughput sweep changed positions without folding its dE: recompute before use
+    bool cb_started = false;     // the current pmc_sweep call has enqueued sweep kernels (errors before that leave the state alone)
     uint64_t step_ctr = 0, sweep_ctr = 0;
     uint32_t key[2] = {0, 0};
     // particle-id-ordered state
@@ -465,10 +469,10 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         if (const char *e = getenv("PMC_NO_FUSED")) h->use_fused = !(e[0] == '1');
         if (const char *e = getenv("PMC_FUSED_LPT")) h->fused_lpt = (e[0] == '1') ? 1 : 0;
     }
-    CR(hipMalloc(&h->d_stats, 32 * sizeof(unsigned long long)));
-    CR(hipMemset(h->d_stats, 0, 32 * sizeof(unsigned long long)));
+    CR(hipMalloc(&h->d_stats, (size_t)PMC_NSHARD * PMC_NSTATS * sizeof(unsigned long long)));
+    CR(hipMemset(h->d_stats, 0, (size_t)PMC_NSHARD * PMC_NSTATS * sizeof(unsigned long long)));
     CR(hipMalloc(&h->d_result, 8 * sizeof(double)));
-    CR(hipHostMalloc(&h->h_stats, 32 * sizeof(unsigned long long)));
+    CR(hipHostMalloc(&h->h_stats, PMC_NSTATS * sizeof(unsigned long long)));
 #undef CR
     *out = h;
     return PMC_OK;
@@ -1176,6 +1180,8 @@ static CbArgs cb_args(pmc_system *h)
     a.stats = h->d_stats;
     a.cap = h->mc_ok ? cb_cap(h) : 128;
     a.rc2pad = h->maxcut * h->maxcut * (1.0 + 1e-9);
+    // threshold of the FP32 pre-filter: rcut_max^2 (1 + 2^-12), rounded UP to float (pmc_kernels.h: error bound 2^-19)
+    a.rc2f = std::nextafter((float)(h->maxcut * h->maxcut * (1.0 + 1.0 / 4096.0)), INFINITY);
     a.filter = h->use_filter ? 1 : 0;
     return a;
 }
@@ -1211,6 +1217,18 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
     DISPATCH_CB_ONE(DD, KK, 2, h, grid, lds, args)                                                              \
     DISPATCH_CB_ONE(DD, KK, 4, h, grid, lds, args)                                                              \
     DISPATCH_CB_ONE(DD, KK, 8, h, grid, lds, args)
+#ifndef PMC_DEV_KIND
+#define PMC_DEV_KIND 0
+#endif
+#ifdef PMC_DEV_BUILD   // development builds: 3-D instances of one model kind only (seconds instead of minutes to compile)
+#define DISPATCH_CB(h, grid, lds, args)                                                                         \
+    do {                                                                                                        \
+        bool done_ = false;                                                                                     \
+        const bool one_ = (args).pool.npool == 1 && (args).pool.kind[0] == 0;                                   \
+        DISPATCH_CB_KIND(3, PMC_DEV_KIND, h, grid, lds, args)                                                   \
+        (void)done_;                                                                                            \
+    } while (0)
+#else
 #define DISPATCH_CB(h, grid, lds, args)                                                                         \
     do {                                                                                                        \
         bool done_ = false;                                                                                     \
@@ -1222,6 +1240,7 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
         DISPATCH_CB_KIND(2, 3, h, grid, lds, args) DISPATCH_CB_KIND(2, 4, h, grid, lds, args)                    \
         (void)done_;                                                                                            \
     } while (0)
+#endif
 
 #define DISPATCH_ONE(KERNEL, DD, KK, h, grid, lds, args)                                                     \
     if (!done_ && (h)->D == DD && (h)->kind == KK) {                                                            \
@@ -1281,14 +1300,15 @@ extern "C" int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix)
         rc = mc_bin(h, z);
         if (rc) return rc;
     }
-    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), h->stream));
     CbArgs a = cb_args(h);
     a.all_cells = 1;
     a.nactive = h->ncell_mc;
     size_t lds = cb_lds_bytes(h);
     DISPATCH_KERNEL(k_total_energy, h, a.nactive, lds, a);
+    hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, h->stream, h->d_stats);   // counter copies -> copy 0
     HIPCHK(h, hipGetLastError());
-    unsigned long long st[32];
+    unsigned long long st[PMC_NSTATS];
     HIPCHK(h, hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     rc = check_kernel_flags(h, st);
@@ -1317,15 +1337,16 @@ extern "C" int pmc_energy_particles_exact(pmc_system *h, double *e)
     }
     DevTmp out;
     HIPCHK(h, out.alloc((size_t)h->N * sizeof(double)));
-    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), h->stream));
     CbArgs a = cb_args(h);
     a.all_cells = 1;
     a.nactive = h->ncell_mc;
     a.e_particle = out.as<double>();
     size_t lds = cb_lds_bytes(h);
     DISPATCH_KERNEL(k_total_energy, h, a.nactive, lds, a);
+    hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, h->stream, h->d_stats);   // counter copies -> copy 0
     HIPCHK(h, hipGetLastError());
-    unsigned long long st[32];
+    unsigned long long st[PMC_NSTATS];
     HIPCHK(h, hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(e, out.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1376,7 +1397,7 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
         int rc = pmc_build_cells(h);
         if (rc) return rc;
     }
-    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), h->stream));
     RefOp o;
     memset(&o, 0, sizeof o);
     o.op = OP_STEPS;
@@ -1394,7 +1415,7 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
     h->step_ctr += (uint64_t)o.nsteps;
     h->sweep_ctr += (uint64_t)nsweeps;
     if (out) {
-        unsigned long long st[32];
+        unsigned long long st[PMC_NSTATS];
         HIPCHK(h, hipMemcpy(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost));
         for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)st[m]; out->accepted[m] = (int64_t)st[8 + m]; }
         float ms = 0;
@@ -1412,6 +1433,7 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
 // cell-sorted copy, the reference lists and the SpeciesList are all recomputed by their next consumer
 static void cb_invalidate(pmc_system *h)
 {
+    (void)hipMemsetAsync(h->d_stats, 0, (size_t)PMC_NSHARD * PMC_NSTATS * sizeof(unsigned long long), h->stream);   // every counter copy
     h->e_fix_valid = false;
     h->energy_stale = true;
     h->mc_binned = false;
@@ -1424,8 +1446,9 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
 
 static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing)
 {
+    h->cb_started = false;
     const int rc = cb_enqueue_sweeps(h, pool, npool, nsweeps, want_timing);
-    if (rc != PMC_OK && !h->pending) {
+    if (rc != PMC_OK && !h->pending && h->cb_started) {
         // an error part-way through the loop leaves launches queued: drain them, then distrust the state
         (void)hipStreamSynchronize(h->stream);
         cb_invalidate(h);
@@ -1450,14 +1473,15 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     // uniform hand-over rule: after throughput sweeps the next consumer of the SpeciesList sees SpeciesList(species)
     // of the current state (swaps here are cell-local and do not maintain the global list)
     if (h->S > 1 && nsweeps > 0) h->species_list_stale = true;
-    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 32 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), h->stream));
     const MovePool mp = make_pool(pool, npool);
     const int ncol = 1 << h->D;
     int nactive = 1;
     for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
-    const size_t lds = cb_lds_bytes(h, h->team >= 4 ? h->team : 0);   // teams of >= 4 keep slot records in LDS
+    const size_t lds = cb_lds_bytes(h, h->team >= 2 ? h->team : 0);   // teams keep slot records and one survivor queue per wavefront in LDS
     int64_t launches = 0, timed_sweeps = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    h->cb_started = nsweeps > 0;
     for (int64_t sw = 0; sw < nsweeps; sw++) {
         const uint64_t g = h->sweep_ctr + (uint64_t)sw;
         const uint32_t s_lo = (uint32_t)g, s_hi = (uint32_t)(g >> 32) & 0xffffffu;
@@ -1542,7 +1566,9 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, h->stream, h->d_stats);   // counter copies -> copy 0
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, PMC_NSTATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->pending_launches_per_sweep = nsweeps > 0 ? (int)(launches / nsweeps) : ncol;
     h->pending = true;
     h->pending_mode = PMC_CHECKERBOARD;
@@ -1568,6 +1594,16 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
         cb_invalidate(h);
         return rc;
     }
+#ifdef PMC_DEBUG_TIME
+    {
+        // shader-clock cycles per cell visit, by phase (wavefront 0 of every workgroup; s_memtime)
+        const double v = (double)st[47];
+        static const char *names[] = {"ticket", "stage+poll", "compact+bounds+fcopy", "slot loop", "writeback+publish",
+                                      "  slot prologue", "  filter", "  dense", "  reduce+accept", "  (slots evaluated)"};
+        fprintf(stderr, "[pmc time] visits=%.0f\n", v);
+        for (int k = 0; k < 10; k++) fprintf(stderr, "[pmc time] %-24s %12.1f cycles/visit\n", names[k], (double)st[32 + k] / v);
+    }
+#endif
 #ifdef PMC_DEBUG_COUNT
     fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], (double)st[24] / st[21]);
 #endif
@@ -1587,6 +1623,9 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
         out->sweep_kernel_launches = timed_sweeps * h->pending_launches_per_sweep;
         out->energy = h->energy;
         out->energy_fix = h->e_fix;
+        out->pair_tests = (int64_t)st[25];
+        out->pairs_in_range = (int64_t)st[26];
+        out->null_moves = (int64_t)st[27];
     }
     return PMC_OK;
 }
@@ -1695,6 +1734,128 @@ extern "C" int pmc_pt_decide(uint64_t seed, uint64_t round, int32_t n, const dou
         }
     }
     if (n_accepted) *n_accepted = acc;
+    return PMC_OK;
+}
+
+// One exchange round over replicas that are handles of THIS process (one GPU, or one handle per device of the node):
+// the energies are the handles' running system.energy[1] (exact in checkerboard mode), the decisions those of
+// pmc_pt_decide, and every handle's temperature becomes ladder[label[r]].  Configurations never move.
+extern "C" int pmc_replica_exchange(pmc_system **hs, int32_t n, const double *ladder, uint64_t seed, uint64_t round,
+                                    int32_t *label, int32_t *n_accepted)
+{
+    if (!hs || n < 1 || !ladder || !label) return fail(nullptr, PMC_ERR_BADARG, "pmc_replica_exchange: bad argument");
+    std::vector<double> e((size_t)n);
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        if (!h) return fail(nullptr, PMC_ERR_BADARG, "pmc_replica_exchange: null handle");
+        if (h->pending) return fail(h, PMC_ERR_STATE, "pmc_replica_exchange: a sweep is in flight on a replica (pmc_sweep_end first)");
+        if (!(ladder[r] > 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_replica_exchange: temperatures must be positive");
+        if (int rc = set_device(h)) return rc;
+        if (int rc = refresh_stale_energy(h)) return rc;
+        e[(size_t)r] = h->energy;
+    }
+    const int rc = pmc_pt_decide(seed, round, n, e.data(), ladder, label, n_accepted);
+    if (rc) return rc;
+    for (int r = 0; r < n; r++) hs[r]->p.temperature = ladder[label[r]];
+    return PMC_OK;
+}
+
+// ---- RCCL (one process per GPU): librccl.so is 570 MB, so it is opened on first use, not linked -----------------
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+            if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) { dlclose(api.lib); api.lib = nullptr; }
+        }
+    }
+    return api.lib ? &api : nullptr;
+}
+int rccl_fail(pmc_system *h, RcclApi *api, const char *what, ncclResult_t r)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s failed: %s", what, (api && api->GetErrorString) ? api->GetErrorString(r) : "RCCL error");
+    return fail(h, PMC_ERR_HIP, buf);
+}
+}   // namespace
+
+extern "C" int pmc_rccl_unique_id(void *id128)
+{
+    if (!id128) return fail(nullptr, PMC_ERR_BADARG, "pmc_rccl_unique_id: null argument");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(nullptr, PMC_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    const ncclResult_t r = api->GetUniqueId(static_cast<ncclUniqueId *>(id128));
+    return r == ncclSuccess ? PMC_OK : rccl_fail(nullptr, api, "ncclGetUniqueId", r);
+}
+
+extern "C" int pmc_rccl_comm_create(const void *id128, int32_t rank, int32_t world, int32_t device, void **comm)
+{
+    if (!id128 || !comm || world < 1 || rank < 0 || rank >= world) return fail(nullptr, PMC_ERR_BADARG, "pmc_rccl_comm_create: bad argument");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(nullptr, PMC_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+    HIPCHK((pmc_system *)nullptr, hipSetDevice(device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = api->CommInitRank(&c, world, id, rank);
+    if (r != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommInitRank", r);
+    *comm = c;
+    return PMC_OK;
+}
+
+extern "C" int pmc_rccl_comm_destroy(void *comm)
+{
+    RcclApi *api = rccl_api();
+    if (!api || !comm) return fail(nullptr, PMC_ERR_BADARG, "pmc_rccl_comm_destroy: bad argument");
+    const ncclResult_t r = api->CommDestroy(static_cast<ncclComm_t>(comm));
+    return r == ncclSuccess ? PMC_OK : rccl_fail(nullptr, api, "ncclCommDestroy", r);
+}
+
+// The same round with one replica per process: ONE double per rank goes through ncclAllGather (RCCL over xGMI) on
+// the handle's stream, every rank then takes the same decisions and adopts its temperature.  label has `world` entries.
+extern "C" int pmc_replica_exchange_rccl(pmc_system *h, void *comm, int32_t rank, int32_t world, const double *ladder,
+                                         uint64_t seed, uint64_t round, int32_t *label, int32_t *n_accepted)
+{
+    if (!h || !comm || !ladder || !label || world < 1 || rank < 0 || rank >= world)
+        return fail(h, PMC_ERR_BADARG, "pmc_replica_exchange_rccl: bad argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "pmc_replica_exchange_rccl: a sweep is in flight (pmc_sweep_end first)");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(h, PMC_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = refresh_stale_energy(h)) return rc;
+    DevTmp buf;
+    HIPCHK(h, buf.alloc((size_t)(world + 1) * sizeof(double)));
+    double *d_send = buf.as<double>(), *d_recv = d_send + 1;
+    HIPCHK(h, hipMemcpyAsync(d_send, &h->energy, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const ncclResult_t r = api->AllGather(d_send, d_recv, 1, ncclDouble, static_cast<ncclComm_t>(comm), h->stream);
+    if (r != ncclSuccess) return rccl_fail(h, api, "ncclAllGather", r);
+    std::vector<double> e((size_t)world);
+    HIPCHK(h, hipMemcpyAsync(e.data(), d_recv, (size_t)world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int rc = pmc_pt_decide(seed, round, world, e.data(), ladder, label, n_accepted);
+    if (rc) return rc;
+    h->p.temperature = ladder[label[rank]];
     return PMC_OK;
 }
 

@@ -19,6 +19,19 @@
 #define PMC_REF_IDS 2048     // neighbourhood size (ids) the ordered-energy LDS buffer holds (8 KB: 20 wavefronts per CU)
 #define PMC_MAXNN 27
 #define PMC_REC 12           // doubles per slot record: old xyz, new xyz, dE, T ln u, LDS slot i, valid, LDS slot j, move
+#define PMC_NSHARD 256       // copies of the counter block: a workgroup adds into copy (ticket or block index) mod 256, k_stats_fold sums
+                             // them into copy 0 (55 000 workgroups adding to ONE cache line serialise at ~6 ns per atomic: that alone
+                             // was 2.3 ms per sweep at N = 10^6)
+#define PMC_NSTATS 64        // counters of one sweep call (CbArgs::stats); [32..47] are used by -DPMC_DEBUG_TIME builds only
+#define PMC_QCAP 640         // entries of a wavefront's survivor queue (2 B each); a filter trip adds at most 128, so the
+                             // first five trips cannot overflow it and one check after the fifth covers the rest
+#ifdef PMC_DEBUG_TIME   // profiling builds only: shader-clock stamps of wavefront 0, summed per phase into stats[32..]
+#define PMC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define PMC_T(var)
+#endif
+
+#define PMC_FTRIPS 8         // filter trips whose float coordinates a wavefront keeps in registers: 512 candidates
 
 // ------------------------------------------------------------------------------
 // binning: cell index -> CSR (cell_start, ids ascending inside each cell)
@@ -974,6 +987,7 @@ struct CbArgs {
     const DevModel *models;
     int cap;                   // candidates staged in LDS per wavefront (multiple of 64)
     double rc2pad;             // (largest cutoff)^2 * (1 + 1e-9): box-distance filter of the staging
+    float rc2f;                // (largest cutoff)^2 * (1 + 2^-12), rounded up: threshold of the FP32 pre-filter (conservative)
     int filter;                // 1: drop candidates that are out of range of the whole centre cell
     const int *order;          // per colour: cells sorted by population, descending (may be null)
     unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
@@ -993,6 +1007,12 @@ struct CbArgs {
 // Agent-scope accesses of the data that workgroups of one fused launch hand to each other (the
 // cell-sorted coordinates and species): sc1 loads bypass the CU's L1, sc1 stores write through
 // (cdna_hip_programming.md Guideline 16, R1).  Outside a fused launch they are merely uncached in L1.
+#ifdef PMC_EXP_PLAIN   // experiment only (valid with PMC_NO_FUSED=1): plain accesses instead of sc1
+__device__ __forceinline__ double ld_agent(const double *p) { return *p; }
+__device__ __forceinline__ unsigned char ld_agent(const unsigned char *p) { return *p; }
+__device__ __forceinline__ void st_agent(double *p, double v) { *p = v; }
+__device__ __forceinline__ void st_agent(unsigned char *p, unsigned char v) { *p = v; }
+#else
 __device__ __forceinline__ double ld_agent(const double *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1009,6 +1029,7 @@ __device__ __forceinline__ void st_agent(unsigned char *p, unsigned char v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#endif
 
 // bijective remap so that blocks sharing an XCD (b % 8) work on one contiguous slab of cells
 // (used by k_total_energy and when the longest-first order is switched off)
@@ -1037,6 +1058,10 @@ struct WaveNbh {
     bool bounds;   // lo/hi below are valid: "stays in the cell" is  lo_a <= x_a < hi_a
     double lo[3], hi[3];
     double *part;  // [8] per-wavefront partial sums (workgroups of several wavefronts)
+    // FP32 pre-filter (wave_delta_e_filtered)
+    unsigned short *queue;   // [max(NW,1)][PMC_QCAP] survivor queues, one per wavefront
+    double bc[3];            // centre of the centre cell (frame of its first particle)
+    bool filt;               // the pre-filter is usable for this visit (everything staged, at most 64 PMC_FTRIPS candidates)
     // proposal-slot values of the first chunk, fetched together with the coordinates (latency-bound teams only)
     double p_tlnu, p_dx, p_dy, p_dz;
     uint32_t p_w1, p_w2;
@@ -1045,6 +1070,8 @@ struct WaveNbh {
     double *cmat;  // [NW][NW] pair corrections c(i,j) of one batch
     int *flag;     // [4] workgroup flags
     int *cnt;      // [16] per-move attempted / accepted counters of this cell visit
+    int *ptab;     // [24] the pool's kind / species pair per move (kind[8], sp0[8], sp1[8]): indexed with a run-time move
+                   // number, which on a by-value kernel argument makes the compiler copy all of CbArgs to scratch
 };
 
 // thread index / stride of the NW wavefronts that share one cell
@@ -1070,7 +1097,7 @@ __device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
 // of its lower-colour neighbour cells; the first poll is issued at the very top so that it
 // travels together with the loads of the CSR offsets instead of after them.
 template <int D, bool MULTI, int NW = 1>
-__device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h, int wait_colour = 0)
+__device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h, int wait_colour = 0)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
     constexpr int NR = (D == 3) ? 9 : 3;
@@ -1293,7 +1320,7 @@ __device__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh 
 // Preconditions: everything is staged (ncand <= cap) and the centre particles' cell coordinates
 // are cached (cfl).  About 30 % of a 27-cell neighbourhood goes away at w ~ rcut.
 template <int D, bool MULTI, int NW>
-__device__ void compact_candidates(const CbArgs &a, WaveNbh &h)
+__device__ __forceinline__ void compact_candidates(const CbArgs &a, WaveNbh &h)
 {
     constexpr int MAXC = 8;                       // chunks of 64 candidates per wavefront held in registers
     const int lane = wave_lane(), wv = team_wave<NW>();
@@ -1381,7 +1408,7 @@ __device__ void compact_candidates(const CbArgs &a, WaveNbh &h)
 // (target f + 1) by stepping single ulps from shift + f w; a final check guards the result.
 // Valid only when all centre particles share one unfolded cell (WaveNbh::nowrap).
 template <int D>
-__device__ void cell_bounds(const CbArgs &a, WaveNbh &h)
+__device__ __forceinline__ void cell_bounds(const CbArgs &a, WaveNbh &h)
 {
     const int lane = wave_lane();
     h.bounds = false;
@@ -1504,6 +1531,275 @@ __device__ __forceinline__ double pot_kind(double r2, const DevModel &m)
     return dev_potential_inrange<(KIND == 4 ? 0 : KIND)>(r2, m);
 }
 
+// ------------------------------------------------------------------------------
+// FP32 pre-filter + survivor queue + dense FP64 evaluation (one wavefront, one Displacement slot)
+//
+// Only ~19 % of the (slot, candidate) pairs of a 3^d-cell neighbourhood are inside the cutoff.  Testing all of
+// them in FP64 and branching into the potential with a fifth of the lanes live is what made the first
+// version of this kernel VALU-bound at 587 wave-instructions per move.  Here every candidate is first tested
+// in FP32 against a CONSERVATIVE threshold, the survivors (candidate, old-or-new position) are compacted into
+// a per-wavefront queue in LDS (ballot + mbcnt), and only the queue is evaluated in FP64 -- the exact distance,
+// the exact `r2 > rcut2` test of src/atoms.jl:72 and the potential -- on dense lanes.
+//
+// Why results do not change by a single bit: a pair the filter drops has r2 > rcut2 in FP64 (bound below) and
+// contributes exactly 0 in the reference arithmetic; a pair it keeps is evaluated by exactly the FP64 operations
+// of the direct loop; every term is a multiple of 2^-32 and the sums are exact (dev_quant), so the order in which
+// the queue yields them is free.
+//
+// Error bound of the filter.  Float coordinates are rel = fl32(x - bc [- image]) with |rel| <= R = 1.5 w + |delta|,
+// so each carries an error <= 2^-24 R; a difference d = fl32(rel_j - rel_i) is off by <= 2^-24 (2 R + |d|); the
+// three squares and two sums add a relative 3 * 2^-24.  For |d| <= rcut this gives
+//   |r2_f32 - r2| <= 2^-24 rcut^2 (2 sqrt(3) (2 R + rcut) / rcut + 3) < 2^-24 * 32 rcut^2 = 2^-19 rcut^2
+// because w <= 1.5 rcut (n >= 4 cells per side) makes R <= 2.3 rcut.  The threshold is rcut_max^2 (1 + 2^-12):
+// 128 times that bound.  (Pairs at |d| ~ L/2, where the two image choices differ, are at >= 2 rcut either way.)
+// ------------------------------------------------------------------------------
+
+// float image of a coordinate of the centre cell's neighbourhood
+template <bool NOWRAP>
+__device__ __forceinline__ float rel_float(double x, double bc, double L, double invL)
+{
+    double t = x - bc;
+    if (!NOWRAP) t -= rint(t * invL) * L;
+    return (float)t;
+}
+
+// Float coordinates (relative to the centre of the centre cell, folded into the nearest image) of the candidates a
+// lane tests: lane l tests candidates l, 64 + l, 128 + l, ... in every slot of the visit, so it keeps exactly those in
+// registers -- the filter then reads no LDS at all.  NaN marks the slots behind the last candidate (NaN fails the
+// `r2 <= threshold` test whatever the image folding did to it).
+struct FRegs {
+    float x[PMC_FTRIPS], y[PMC_FTRIPS], z[PMC_FTRIPS];
+};
+
+template <int D, bool NOWRAP>
+__device__ __forceinline__ void load_fregs(const CbArgs &a, const WaveNbh &h, FRegs &f)
+{
+    const int lane = wave_lane();
+#pragma unroll
+    for (int j = 0; j < PMC_FTRIPS; j++) {
+        const int k = j * PMC_WAVE + lane;
+        f.x[j] = f.y[j] = f.z[j] = __builtin_nanf("");
+        if (k < h.ncand) {
+            f.x[j] = rel_float<NOWRAP>(h.cx[k], h.bc[0], a.L[0], a.invL[0]);
+            f.y[j] = rel_float<NOWRAP>(h.cy[k], h.bc[1], a.L[1], a.invL[1]);
+            f.z[j] = (D == 3) ? rel_float<NOWRAP>(h.cz[k], h.bc[2], a.L[2], a.invL[2]) : 0.0f;
+        }
+    }
+}
+
+// after the box filter has compacted the staged candidates: decide whether the pre-filter applies to this visit and
+// load every wavefront's register copy
+template <int D>
+__device__ __forceinline__ void prepare_filter(const CbArgs &a, WaveNbh &h, FRegs &f)
+{
+#pragma unroll
+    for (int q = 0; q < 3; q++) h.bc[q] = (q < D) ? a.shift[q] + (h.cfl[q * PMC_CFL] + 0.5) * a.w[q] : 0.0;
+    h.filt = (h.nc > 0) && (h.ncand <= h.cap) && (h.ncand <= PMC_FTRIPS * PMC_WAVE);
+    if (!h.filt) return;
+    if (h.nowrap) load_fregs<D, true>(a, h, f); else load_fregs<D, false>(a, h, f);
+}
+
+// an accepted move of the particle in LDS slot pc: the owning lane replaces its float copy
+template <int D>
+__device__ __forceinline__ void update_fregs(FRegs &f, int pc, float fx, float fy, float fz)
+{
+    const int rel = pc - wave_lane();
+#pragma unroll
+    for (int j = 0; j < PMC_FTRIPS; j++) {
+        const bool mine = (rel == j * PMC_WAVE);
+        f.x[j] = mine ? fx : f.x[j];
+        f.y[j] = mine ? fy : f.y[j];
+        if (D == 3) f.z[j] = mine ? fz : f.z[j];
+    }
+}
+
+struct PairCount {
+    unsigned tests, energies;     // per wavefront: FP32 distance tests, in-range pair energies evaluated
+#ifdef PMC_DEBUG_TIME
+    unsigned long long t_filter, t_dense;
+#endif
+};
+
+// the FP64 evaluation of the queued survivors [0, qn) of one slot; returns this lane's partial sum
+template <int D, int KIND, bool MULTI, bool NOWRAP>
+__device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h, const DevModel *tab, const unsigned short *queue,
+                                              int qn, int pc, int si, double xo, double yo, double zo, double xn, double yn, double zn,
+                                              PairCount &pcnt)
+{
+    const int lane = wave_lane();
+    double acc = 0.0;
+    qn = __builtin_amdgcn_readfirstlane(qn);
+    pc = __builtin_amdgcn_readfirstlane(pc);
+#ifdef PMC_DEBUG_NODENSE   // profiling builds only: price the filter alone
+    qn = 0;
+#endif
+    for (int e0 = 0; e0 < qn; e0 += PMC_WAVE) {
+        // lanes behind the last entry re-read it (no branch around the loads) and are masked out of the range test
+        const int e = min(e0 + lane, qn - 1);
+        const unsigned q = queue[e];
+        const bool isnew = (q & 1u) != 0u;
+        const int k = (int)(q >> 3);
+        const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
+        const double xi = isnew ? xn : xo, yi = isnew ? yn : yo, zi = isnew ? zn : zo;
+        const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
+        const double r2 = NOWRAP ? dist2_nowrap<D>(xi, yi, zi, xj, yj, zj) : dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
+        const bool inr = (e0 + lane < qn) && (k != pc) && !(r2 > mm.rcut2);     // k == pc: the particle itself
+        pcnt.energies += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(inr));
+        if (inr) {
+            const double u = dev_quant(pot_kind<KIND>(r2, mm));
+            acc += isnew ? u : -u;
+        }
+    }
+    return acc;
+}
+
+// dE = sum_j q(u(new, j)) - q(u(old, j)) of moving the particle in LDS slot pc from (xo,yo,zo) to (xn,yn,zn), by ONE
+// wavefront, result in every lane.  f = this wavefront's register copy; fo* / fn* = float images of the old and new
+// position (rel_float).  Requires h.filt.  `overflow` is set (and nothing returned) when the survivor queue cannot hold
+// the next trip: the caller then takes the direct loop for this slot (dense clusters only).
+template <int D, int KIND, bool MULTI>
+__device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
+                                                        const FRegs &f, int pc, int si, double xo, double yo, double zo,
+                                                        double xn, double yn, double zn, float fxo, float fyo, float fzo,
+                                                        float fxn, float fyn, float fzn, PairCount &pcnt, bool &overflow)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int lane = wave_lane();
+    // wave-uniform values the compiler cannot prove uniform (they come from loads and cross-lane moves): pin them to
+    // SGPRs so that the trip guards, the ballot masks and the queue cursor stay on the scalar unit
+    const int ncand = __builtin_amdgcn_readfirstlane(h.ncand);
+    const float thr = a.rc2f;
+    // (old, new) pairs: one packed FP32 instruction tests a candidate against both positions
+    const f2 px = {fxo, fxn}, py = {fyo, fyn}, pz = {fzo, fzn};
+    const unsigned lane8 = (unsigned)lane << 3;
+    unsigned qn = 0;
+    int nrun = ncand;
+#ifdef PMC_DEBUG_NOFILTER   // profiling builds only: price the slot prologue / reduction alone
+    nrun = 0;
+#endif
+    overflow = false;
+    PMC_T(tf_0);
+    // The particle itself (distance 0 to its old position) is NOT masked here: it passes the filter like any close
+    // neighbour and queue_flush drops it by index -- one compare per dense trip instead of three operations per filter trip.
+#pragma unroll
+    for (int j = 0; j < PMC_FTRIPS; j++) {
+        if (j * PMC_WAVE < nrun) {
+            const f2 cx = {f.x[j], f.x[j]}, cy = {f.y[j], f.y[j]};
+            const f2 dx = cx - px, dy = cy - py;
+            f2 r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
+            if (D == 3) {
+                const f2 cz = {f.z[j], f.z[j]};
+                const f2 dz = cz - pz;
+                r2 = __builtin_elementwise_fma(dz, dz, r2);
+            }
+            const bool io = r2.x <= thr, in = r2.y <= thr;
+            const unsigned long long mo = __builtin_amdgcn_ballot_w64(io), mn = __builtin_amdgcn_ballot_w64(in);
+            const unsigned kk = lane8 + (unsigned)(j * PMC_WAVE * 8);      // queue entry: (k << 3) | new-position flag
+            if (io) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, qn))] = (unsigned short)kk;
+            qn += (unsigned)__popcll(mo);
+            if (in) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(mn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mn, qn))] = (unsigned short)(kk | 1u);
+            qn += (unsigned)__popcll(mn);
+            if (j == 4 && qn > (unsigned)(PMC_QCAP - (PMC_FTRIPS - 5) * 2 * PMC_WAVE) && 5 * PMC_WAVE < ncand) {
+                overflow = true;      // the remaining trips might not fit (dense clusters only)
+                nrun = 0;
+            }
+        }
+    }
+    if (overflow) return 0.0;
+    pcnt.tests += 2u * (unsigned)ncand;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PMC_T(tf_1);
+    double acc = h.nowrap ? queue_flush<D, KIND, MULTI, true>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt)
+                          : queue_flush<D, KIND, MULTI, false>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef PMC_DEBUG_TIME
+    {
+        // the stamp must not be taken before the FP64 work has finished: make it depend on the sum
+        const double probe = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 0" :: "v"(probe) : "memory");
+        PMC_T(tf_2);
+        pcnt.t_filter += tf_1 - tf_0;
+        pcnt.t_dense += tf_2 - tf_1;
+    }
+#endif
+    return wave_sum_exact(acc);
+}
+
+// dE of one Displacement slot by one wavefront: the pre-filter where it applies, the direct loop otherwise
+template <int D, int KIND, bool MULTI>
+__device__ __forceinline__ double wave_delta_e_direct(const CbArgs &a, const WaveNbh &h, const DevModel *tab, int pc, int si,
+                                                      double xo, double yo, double zo, double xn, double yn, double zn,
+                                                      PairCount &pcnt);
+
+template <int D, int KIND, bool MULTI>
+__device__ __forceinline__ double wave_delta_e(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
+                                               const FRegs &f, int pc, int si, double xo, double yo, double zo, double xn,
+                                               double yn, double zn, float &fxn, float &fyn, float &fzn, PairCount &pcnt)
+{
+    if (h.filt) {
+        float fxo, fyo, fzo = 0.0f;
+        fzn = 0.0f;
+        if (h.nowrap) {
+            fxo = rel_float<true>(xo, h.bc[0], a.L[0], a.invL[0]);  fxn = rel_float<true>(xn, h.bc[0], a.L[0], a.invL[0]);
+            fyo = rel_float<true>(yo, h.bc[1], a.L[1], a.invL[1]);  fyn = rel_float<true>(yn, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) { fzo = rel_float<true>(zo, h.bc[2], a.L[2], a.invL[2]); fzn = rel_float<true>(zn, h.bc[2], a.L[2], a.invL[2]); }
+        } else {
+            fxo = rel_float<false>(xo, h.bc[0], a.L[0], a.invL[0]); fxn = rel_float<false>(xn, h.bc[0], a.L[0], a.invL[0]);
+            fyo = rel_float<false>(yo, h.bc[1], a.L[1], a.invL[1]); fyn = rel_float<false>(yn, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) { fzo = rel_float<false>(zo, h.bc[2], a.L[2], a.invL[2]); fzn = rel_float<false>(zn, h.bc[2], a.L[2], a.invL[2]); }
+        }
+        bool overflow;
+        const double de = wave_delta_e_filtered<D, KIND, MULTI>(a, h, tab, queue, f, pc, si, xo, yo, zo, xn, yn, zn,
+                                                                fxo, fyo, fzo, fxn, fyn, fzn, pcnt, overflow);
+        if (!overflow) return de;
+    }
+    return wave_delta_e_direct<D, KIND, MULTI>(a, h, tab, pc, si, xo, yo, zo, xn, yn, zn, pcnt);
+}
+
+// The same dE by the direct loop (every candidate tested in FP64): visits whose neighbourhood does not fit the LDS
+// staging capacity (candidates beyond it are read from HBM / L2).
+template <int D, int KIND, bool MULTI>
+__device__ __forceinline__ double wave_delta_e_direct(const CbArgs &a, const WaveNbh &h, const DevModel *tab, int pc, int si,
+                                                      double xo, double yo, double zo, double xn, double yn, double zn,
+                                                      PairCount &pcnt)
+{
+    const int lane = wave_lane();
+    const int lim = min(h.ncand, h.cap);
+    double dsum = 0.0;
+    unsigned nin = 0;
+    auto term = [&](int k, double xj, double yj, double zj, int sj, auto nowrap_tag) {
+        constexpr bool NOWRAP = decltype(nowrap_tag)::value;
+        const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
+        const double r2o = NOWRAP ? dist2_nowrap<D>(xo, yo, zo, xj, yj, zj) : dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
+        const double r2n = NOWRAP ? dist2_nowrap<D>(xn, yn, zn, xj, yj, zj) : dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
+        if (k != pc) {
+            if (!(r2n > mm.rcut2)) { dsum += dev_quant(pot_kind<KIND>(r2n, mm)); nin++; }
+            if (!(r2o > mm.rcut2)) { dsum -= dev_quant(pot_kind<KIND>(r2o, mm)); nin++; }
+        }
+    };
+    auto sweep_lds = [&](auto nowrap_tag) {
+        for (int k = lane; k < lim; k += PMC_WAVE)
+            term(k, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0, MULTI ? (int)h.csp[k] : 0, nowrap_tag);
+    };
+    if (h.nowrap) sweep_lds(std::true_type{}); else sweep_lds(std::false_type{});
+    for (int k = lim + lane; k < h.ncand; k += PMC_WAVE) {
+        double xj, yj, zj;
+        int sj;
+        nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
+        term(k, xj, yj, zj, sj, std::false_type{});
+    }
+    pcnt.tests += 2u * (unsigned)h.ncand;
+    unsigned tot = nin;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) tot += __shfl_xor(tot, s, PMC_WAVE);
+    pcnt.energies += tot;
+    return wave_sum_exact(dsum);
+}
+
 // exact per-particle energy of a particle at (xi,yi,zi) with species si against the staged
 // neighbourhood, skipping the LDS slots ex1 / ex2; result in every lane
 template <int D, int KIND, bool MULTI, int NW = 1>
@@ -1569,8 +1865,8 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
 // two wavefronts needs <= 13 312 B for twelve workgroups (six wavefronts per SIMD) per CU.
 __host__ __device__ inline size_t pmc_lds_wave_bytes(int cap, bool multi, int batch_nw)
 {
-    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (size_t)(PMC_REC * batch_nw + batch_nw * batch_nw) * 8 + 4 * 4 + 16 * 4 +
-           2 * 32 * 4 + (multi ? cap : 0);
+    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (size_t)(2 * PMC_REC * batch_nw + batch_nw * batch_nw) * 8 + 4 * 4 + 16 * 4 +
+           24 * 4 + 2 * 32 * 4 + (size_t)(batch_nw > 0 ? batch_nw : 1) * PMC_QCAP * 2 + (multi ? cap : 0);
 }
 
 template <int D, bool MULTI, int BATCH = 0>   // BATCH: team size of the speculative slot batches (0: none)
@@ -1583,12 +1879,15 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cfl = h.cz + h.cap;
     h.part = h.cfl + 3 * PMC_CFL;
     h.rec = h.part + 8;
-    h.cmat = h.rec + PMC_REC * BATCH;
+    h.cmat = h.rec + 2 * PMC_REC * BATCH;      // two record buffers, used by alternate batches
     h.flag = reinterpret_cast<int *>(h.cmat + BATCH * BATCH);
     h.cnt = h.flag + 4;
-    h.segoff = h.cnt + 16;
+    h.ptab = h.cnt + 16;
+    h.segoff = h.ptab + 24;
     h.segsrc = h.segoff + 32;
-    h.csp = reinterpret_cast<unsigned char *>(h.segsrc + 32);
+    h.queue = reinterpret_cast<unsigned short *>(h.segsrc + 32);
+    h.csp = reinterpret_cast<unsigned char *>(h.queue + (BATCH > 0 ? BATCH : 1) * PMC_QCAP);
+    h.filt = false;
     DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap, MULTI, BATCH) + 15) & ~(size_t)15));
     if (MULTI) {
         for (int k = threadIdx.x; k < a.S * a.S; k += blockDim.x) tab[k] = a.models[k];
@@ -1639,7 +1938,8 @@ __global__ __launch_bounds__(64) void k_total_energy(CbArgs a)
     h.lin = lin;
     stage_neighbourhood<D, MULTI>(a, cell, h);
     if (h.nc == 0) return;
-    if (h.ctr + h.nc > h.cap) { if (wave_lane() == 0) atomicOr(&a.stats[17], 1ull); return; }
+    unsigned long long *const st = a.stats + (size_t)(blockIdx.x & (PMC_NSHARD - 1)) * PMC_NSTATS;
+    if (h.ctr + h.nc > h.cap) { if (wave_lane() == 0) atomicOr(&st[17], 1ull); return; }
     long long tot = 0;
     for (int p = 0; p < h.nc; p++) {
         const int pc = h.ctr + p;
@@ -1649,7 +1949,7 @@ __global__ __launch_bounds__(64) void k_total_energy(CbArgs a)
         tot += (long long)(e * PMC_FIX);
         if (a.e_particle && wave_lane() == 0) a.e_particle[a.ids[h.k0 + p]] = e;
     }
-    if (wave_lane() == 0) atomicAdd(&a.stats[16], (unsigned long long)tot);
+    if (wave_lane() == 0) atomicAdd(&st[16], (unsigned long long)tot);
 }
 
 // k-th (0-based) centre-cell particle of species sp, in cell order (index inside the cell); uniform
@@ -1700,60 +2000,67 @@ __device__ __forceinline__ void publish_done(const CbArgs &a, int lin, bool lead
 // wavefronts splitting every candidate loop; Displacement slots that would leave the cell are
 // rejected.
 // ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
+// counters of one workgroup, summed over all the cells it visits and added to its counter copy once, at the end
+struct CbTotals {
+    unsigned long long att1, acc1;   // single-Displacement pools (multi-move pools count per move in LDS, WaveNbh::cnt)
+    long long efix;                  // accepted energy change in units of 2^-32
+    unsigned long long nnull;
+    unsigned long long tests, energies;
+    PairCount pcnt;                  // per-wavefront work counters of the current visit
+#ifdef PMC_DEBUG_TIME
+    unsigned long long tp[12];
+#endif
+};
+
 template <int D, int KIND, bool MULTI, int NW, bool ONE>
-__global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
+__device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevModel *tab, int colour, int aidx,
+                                         unsigned long long *st, CbTotals &tot)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    WaveNbh h;
-    const DevModel *tab = setup_lds<D, MULTI, (NW >= 4 ? NW : 0)>(a, smem, h);
     const int lane = wave_lane();
     const int tid = team_tid<NW>(), wv = team_wave<NW>();
     constexpr int TS = NW * PMC_WAVE;
-    // speculative batches pay off where a cell visit is latency-bound (few cells per colour, teams of 4:
-    // N=32768 +22 %); with teams of 2 the chip is VALU-bound and the shared candidate loop is as fast
-    constexpr bool BATCH = (NW >= 4);
-    int aidx, colour = a.colour;
-    if (a.fused) {
-        // ticket order = colour order (see the comment above publish_done)
-        if (tid == 0) h.flag[2] = (int)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
-        __syncthreads();
-        const int t = h.flag[2];
-        colour = t / a.nactive;
-        aidx = t - colour * a.nactive;
-    } else {
-        aidx = a.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-        if (aidx >= a.nactive) return;
-    }
+    // one wavefront evaluates one slot alone (FP32 pre-filter, survivor queue, dense FP64: wave_delta_e_filtered);
+    // teams of NW >= 2 wavefronts evaluate NW slots of the cell speculatively at once and resolve them in order
+    constexpr bool BATCH = (NW >= 2);
+    unsigned short *const my_queue = h.queue + wv * PMC_QCAP;
+    PairCount &pcnt = tot.pcnt;
+    unsigned nnull = 0;
+#ifdef PMC_DEBUG_TIME
+    unsigned long long tp_pro = 0, tp_red = 0, tp_n = 0;
+    const unsigned long long tf_base = pcnt.t_filter, td_base = pcnt.t_dense;
+#endif
+    PMC_T(t_0);
     int cell[3] = {0, 0, 0}, lin;
     decode_cell<D>(a, colour, aidx, cell, lin);
     h.lin = lin;
+    PMC_T(t_1);
     stage_neighbourhood<D, MULTI, NW>(a, cell, h, a.fused ? colour : 0);
+    PMC_T(t_2);
     const int nc = h.nc;
     if (nc == 0) { if (a.fused) publish_done(a, lin, tid == 0); return; }
     if (h.ctr + nc > h.cap) {
-        if (tid == 0) atomicOr(&a.stats[17], 1ull);
+        if (tid == 0) atomicOr(&st[17], 1ull);
         if (a.fused) publish_done(a, lin, tid == 0);
         return;
     }
     compact_candidates<D, MULTI, NW>(a, h);
     cell_bounds<D>(a, h);
+    FRegs fr;
+    prepare_filter<D>(a, h, fr);
+    PMC_T(t_3);
 #ifdef PMC_DEBUG_COUNT   // profiling builds only
-    if (tid == 0) { atomicAdd(&a.stats[20], (unsigned long long)h.ncand); atomicAdd(&a.stats[21], 1ull); atomicAdd(&a.stats[22], (unsigned long long)h.nowrap); atomicAdd(&a.stats[23], (unsigned long long)h.bounds); atomicAdd(&a.stats[24], (unsigned long long)h.nseg); }
+    if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], (unsigned long long)h.bounds); atomicAdd(&st[24], (unsigned long long)h.nseg); }
 #endif
 
     // multi-move pools count per move in LDS (cnt[0..7] attempted, cnt[8..15] accepted); a
     // single-Displacement pool counts in two scalars
     int *cnt = h.cnt;
-    if (!ONE) {
-        if (tid < 16) cnt[tid] = 0;
-        __syncthreads();
-    }
     unsigned long long att1 = 0, acc1 = 0;
     long long efix = 0;
     bool dirty = false;
+    int nbatch = 0;
     const double my_shift = (lane == 0) ? a.shift[0] : ((lane == 1) ? a.shift[1] : a.shift[2]);
     const double my_w = (lane == 0) ? a.w[0] : ((lane == 1) ? a.w[1] : a.w[2]);
-    const int lim = min(h.ncand, h.cap);
 
     for (int chunk = 0; chunk < nc; chunk += PMC_WAVE) {
         // lanes generate the slots of this chunk in parallel
@@ -1794,14 +2101,21 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
             int s0 = 0;
             while (s0 < nslots) {
                 const int K = min(NW, nslots - s0);
+#ifdef PMC_EXP_SINGLEREC
+                double *const recs = h.rec;
+#else
+                double *const recs = h.rec + (nbatch & 1) * (NW * PMC_REC);   // records of this batch (two buffers alternate)
+#endif
+                nbatch++;
+                PMC_T(tb_0);
                 if (wv < K) {
                     const int my = __builtin_amdgcn_readfirstlane(s0 + wv);
                     const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, my);
                     const int mm_ = ONE ? 0 : __builtin_amdgcn_readlane(g_m, my);
-                    if (MULTI && !ONE && a.pool.kind[mm_] != 0) {
+                    if (MULTI && !ONE && h.ptab[mm_] != 0) {
                         // DiscreteSwap slot: both particles and the fused four-energy difference by this wavefront alone
                         const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)g_w2, my);
-                        const int sa = a.pool.sp0[mm_], sb = a.pool.sp1[mm_];
+                        const int sa = h.ptab[8 + mm_], sb = h.ptab[16 + mm_];
                         const int na = count_species(h, sa), nb = count_species(h, sb);
                         const bool valid = (na > 0 && nb > 0 && sa != sb);
                         int pi = 0, pj = 0;
@@ -1812,7 +2126,7 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                             de = swap_delta<D, KIND, MULTI, 1>(a, h, tab, pi, pj, sa, sb);
                         }
                         if (lane == 0) {
-                            double *r = h.rec + wv * PMC_REC;
+                            double *r = recs + wv * PMC_REC;
                             r[6] = de;
                             r[7] = readlane_double(g_tlnu, my);
                             r[8] = (double)pi;
@@ -1842,40 +2156,11 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                     double de = 0.0;
                     if (inside) {
                         const int si = MULTI ? (int)h.csp[pc] : 0;
-                        double dsum = 0.0;
-                        auto term = [&](int k, double xj, double yj, double zj, int sj, auto nowrap_tag) {
-                            constexpr bool NOWRAP = decltype(nowrap_tag)::value;
-                            const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
-                            const double r2o = NOWRAP ? dist2_nowrap<D>(xo, yo, zo, xj, yj, zj) : dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
-                            const double r2n = NOWRAP ? dist2_nowrap<D>(xn, yn, zn, xj, yj, zj) : dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
-                            if (k != pc) {
-                                if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
-                                if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
-                            }
-                        };
-                        auto sweep_lds = [&](auto nowrap_tag) {
-                            int k = lane;
-                            for (; k + PMC_WAVE < lim; k += 2 * PMC_WAVE) {
-                                const int k2 = k + PMC_WAVE;
-                                const double xa = h.cx[k], ya = h.cy[k], za = (D == 3) ? h.cz[k] : 0.0;
-                                const double xb = h.cx[k2], yb = h.cy[k2], zb = (D == 3) ? h.cz[k2] : 0.0;
-                                const int sa_ = MULTI ? (int)h.csp[k] : 0, sb_ = MULTI ? (int)h.csp[k2] : 0;
-                                term(k, xa, ya, za, sa_, nowrap_tag);
-                                term(k2, xb, yb, zb, sb_, nowrap_tag);
-                            }
-                            if (k < lim) term(k, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0, MULTI ? (int)h.csp[k] : 0, nowrap_tag);
-                        };
-                        if (h.nowrap) sweep_lds(std::true_type{}); else sweep_lds(std::false_type{});
-                        for (int k = lim + lane; k < h.ncand; k += PMC_WAVE) {
-                            double xj, yj, zj;
-                            int sj;
-                            nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
-                            term(k, xj, yj, zj, sj, std::false_type{});
-                        }
-                        de = wave_sum_exact(dsum);
+                        float fxn, fyn, fzn;
+                        de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
                     }
                     if (lane == 0) {
-                        double *r = h.rec + wv * PMC_REC;
+                        double *r = recs + wv * PMC_REC;
                         r[0] = xo; r[1] = yo; r[2] = zo;
                         r[3] = xn; r[4] = yn; r[5] = zn;
                         r[6] = de;
@@ -1887,11 +2172,13 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                     }
                     }
                 }
+                PMC_T(tb_1);
                 __syncthreads();           // every evaluation has read the pre-batch state; records are posted
+                PMC_T(tb_2);
                 if (wv == 0) {
                     // this lane's record (lanes 0..K-1)
                     const int jl = min(lane, NW - 1);
-                    const double *rl = h.rec + jl * PMC_REC;
+                    const double *rl = recs + jl * PMC_REC;
                     const double l_de = rl[6], l_tlnu = rl[7];
                     const int l_pc = (int)rl[8];
                     const bool l_in = rl[9] != 0.0;
@@ -1909,9 +2196,9 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         const int pjc = min(pj, NW - 1);
                         double v = 0.0;
                         // record[10] >= 0 marks a DiscreteSwap slot (its second particle); pair terms exist between Displacement slots only
-                        const bool both_disp = ONE || (h.rec[pi * PMC_REC + 10] < 0.0 && h.rec[pjc * PMC_REC + 10] < 0.0);
+                        const bool both_disp = ONE || (recs[pi * PMC_REC + 10] < 0.0 && recs[pjc * PMC_REC + 10] < 0.0);
                         if (pr < NP && pj < K && both_disp) {
-                            const double *ri = h.rec + pi * PMC_REC, *rj = h.rec + pj * PMC_REC;
+                            const double *ri = recs + pi * PMC_REC, *rj = recs + pj * PMC_REC;
                             const int oi = (tt & 2) ? 0 : 3, oj = (tt & 1) ? 0 : 3;   // old or new coordinates
                             const double xi_ = ri[oi], yi_ = ri[oi + 1], zi_ = ri[oi + 2];
                             const double xj_ = rj[oj], yj_ = rj[oj + 1], zj_ = rj[oj + 2];
@@ -1985,19 +2272,50 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                             if (D == 3) h.cz[l_pc] = rl[5];
                         }
                     }
-                    if (lane == 0) h.flag[3] = nres;
+                    nnull += (unsigned)__popcll(__ballot(lane < nres && !l_in));
+                    if (lane == 0) { h.flag[3] = nres; h.flag[1] = (int)accmask; }
                 }
+                PMC_T(tb_3);
                 __syncthreads();           // accepted moves and the number of resolved slots are visible
+#ifdef PMC_DEBUG_TIME
+                { PMC_T(tb_4); tp_pro += tb_1 - tb_0; tp_red += tb_3 - tb_2; tp_n += 1; pcnt.t_filter += tb_2 - tb_1; pcnt.t_dense += tb_4 - tb_3; }
+#endif
                 s0 += h.flag[3];
+                if (h.filt) {
+                    // every wavefront brings its register copy of the float coordinates up to date with the accepted
+                    // Displacements of this batch (the records stay intact: the next batch writes the other buffer)
+                    const unsigned am = (unsigned)h.flag[1];
+#pragma unroll
+                    for (int i = 0; i < NW; i++) {
+                        if ((am >> i) & 1u) {
+                            const double *ri = recs + i * PMC_REC;
+                            if (ONE || !MULTI || ri[10] < 0.0) {
+                                const int pci = (int)ri[8];
+                                float gx, gy, gz = 0.0f;
+                                if (h.nowrap) {
+                                    gx = rel_float<true>(ri[3], h.bc[0], a.L[0], a.invL[0]);
+                                    gy = rel_float<true>(ri[4], h.bc[1], a.L[1], a.invL[1]);
+                                    if (D == 3) gz = rel_float<true>(ri[5], h.bc[2], a.L[2], a.invL[2]);
+                                } else {
+                                    gx = rel_float<false>(ri[3], h.bc[0], a.L[0], a.invL[0]);
+                                    gy = rel_float<false>(ri[4], h.bc[1], a.L[1], a.invL[1]);
+                                    if (D == 3) gz = rel_float<false>(ri[5], h.bc[2], a.L[2], a.invL[2]);
+                                }
+                                update_fregs<D>(fr, pci, gx, gy, gz);
+                            }
+                        }
+                    }
+                }
             }
             dirty = true;
         } else
         for (int s = 0; s < nslots; s++) {
+            PMC_T(ts_0);
             const int m = ONE ? 0 : __builtin_amdgcn_readlane(g_m, s);
             const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, s);
             const double tlnu = readlane_double(g_tlnu, s);     // T * ln u: accept iff T ln u < -dE
             bool ok = false;
-            if (ONE || a.pool.kind[m] == 0) {
+            if (ONE || h.ptab[m] == 0) {
                 const int p = (int)mulhi32(w1, (uint32_t)nc);
                 const int pc = h.ctr + p;
                 const double xo = h.cx[pc], yo = h.cy[pc], zo = (D == 3) ? h.cz[pc] : 0.0;
@@ -2020,68 +2338,39 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                     inside = (__ballot(bad) == 0ull);
                 }
                 if (inside) {
+                    // one wavefront per cell here (teams of NW >= 2 take the batch branch above)
                     const int si = MULTI ? (int)h.csp[pc] : 0;
-                    double dsum = 0.0;             // sum_j q(u_new) - q(u_old): every term and the sum are exact
-                    auto term = [&](int k, double xj, double yj, double zj, int sj, auto nowrap_tag) {
-                        constexpr bool NOWRAP = decltype(nowrap_tag)::value;
-                        const DevModel &mm = MULTI ? tab[si * a.S + sj] : a.m0;
-                        const double r2o = NOWRAP ? dist2_nowrap<D>(xo, yo, zo, xj, yj, zj) : dist2_fast<D>(a, xo, yo, zo, xj, yj, zj);
-                        const double r2n = NOWRAP ? dist2_nowrap<D>(xn, yn, zn, xj, yj, zj) : dist2_fast<D>(a, xn, yn, zn, xj, yj, zj);
-                        if (k != pc) {
-                            if (!(r2n > mm.rcut2)) dsum += dev_quant(pot_kind<KIND>(r2n, mm));
-#ifndef PMC_DEBUG_NOOLD   // profiling builds only: price the old-position evaluation
-                            if (!(r2o > mm.rcut2)) dsum -= dev_quant(pot_kind<KIND>(r2o, mm));
+                    float fxn = 0.0f, fyn = 0.0f, fzn = 0.0f;
+#ifdef PMC_DEBUG_TIME
+                    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 0" :: "v"(xn + yn + zn) : "memory");
+                    PMC_T(ts_1);
+                    tp_pro += ts_1 - ts_0;
+                    tp_n += 1;
 #endif
-                        }
-                    };
-                    // LDS-resident candidates, two per lane and trip: both loads are issued before the first
-                    // evaluation, so the second candidate's LDS latency hides behind the first one's arithmetic
-                    auto sweep_lds = [&](auto nowrap_tag) {
-                        int k = tid;
-                        for (; k + TS < lim; k += 2 * TS) {
-                            const int k2 = k + TS;
-                            const double xa = h.cx[k], ya = h.cy[k], za = (D == 3) ? h.cz[k] : 0.0;
-                            const double xb = h.cx[k2], yb = h.cy[k2], zb = (D == 3) ? h.cz[k2] : 0.0;
-                            const int sa_ = MULTI ? (int)h.csp[k] : 0, sb_ = MULTI ? (int)h.csp[k2] : 0;
-                            term(k, xa, ya, za, sa_, nowrap_tag);
-                            term(k2, xb, yb, zb, sb_, nowrap_tag);
-                        }
-                        if (k < lim) term(k, h.cx[k], h.cy[k], (D == 3) ? h.cz[k] : 0.0, MULTI ? (int)h.csp[k] : 0, nowrap_tag);
-                    };
-                    if (h.nowrap) sweep_lds(std::true_type{}); else sweep_lds(std::false_type{});
-                    for (int k = lim + tid; k < h.ncand; k += TS) {
-                        double xj, yj, zj;
-                        int sj;
-                        nbh_load<D, MULTI>(a, h, k, xj, yj, zj, sj);
-                        term(k, xj, yj, zj, sj, std::false_type{});
-                    }
-                    double de = wave_sum_exact(dsum);
-                    if (NW > 1) {
-                        // combine the wavefronts' partial sums (exact, so the order is free); after this
-                        // barrier nobody reads the old position any more, so the writer may proceed
-                        if (lane == 0) h.part[wv] = de;
-                        __syncthreads();
-                        de = h.part[0];
-#pragma unroll
-                        for (int w = 1; w < NW; w++) de += h.part[w];
-                    }
+                    const double de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
+                    PMC_T(ts_2);
                     ok = tlnu < -de;
                     if (ok) {
-                        if (NW == 1) __syncthreads();
+                        __syncthreads();
                         if (tid == 0) {
                             h.cx[pc] = xn;
                             h.cy[pc] = yn;
                             if (D == 3) h.cz[pc] = zn;
                         }
-                        if (NW == 1) __syncthreads();
+                        __syncthreads();
+                        if (h.filt) update_fregs<D>(fr, pc, fxn, fyn, fzn);
                         efix += (long long)(de * PMC_FIX);
                         dirty = true;
                     }
-                    if (NW > 1) __syncthreads();   // publishes the move and frees part[] for the next slot
+#ifdef PMC_DEBUG_TIME
+                    { PMC_T(ts_3); tp_red += ts_3 - ts_2; }
+#endif
+                } else {
+                    nnull += 1;
                 }
             } else if (MULTI && !ONE) {
                 const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)g_w2, s);
-                const int sa = a.pool.sp0[m], sb = a.pool.sp1[m];
+                const int sa = h.ptab[8 + m], sb = h.ptab[16 + m];
                 const int na = count_species(h, sa), nb = count_species(h, sb);
                 if (na > 0 && nb > 0 && sa != sb) {
                     const int pi = h.ctr + kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
@@ -2098,6 +2387,8 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
                         efix += (long long)(de * PMC_FIX);
                         dirty = true;
                     }
+                } else {
+                    nnull += 1;
                 }
             }
             if (ONE) {
@@ -2111,6 +2402,7 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
             }
         }
     }
+    PMC_T(t_4);
     if (dirty) {
         for (int k = tid; k < nc; k += TS) {
             const int kc = h.ctr + k;
@@ -2130,17 +2422,81 @@ __global__ __launch_bounds__(NW * 64, PMC_CB_MINWAVES) void k_cb_pass(CbArgs a)
         }
     }
     if (a.fused) publish_done(a, lin, tid == 0);
+    tot.att1 += att1;
+    tot.acc1 += acc1;
+    tot.efix += efix;
+    tot.nnull += nnull;
+#ifdef PMC_DEBUG_TIME
+    {
+        PMC_T(t_5);
+        tot.tp[0] += t_1 - t_0; tot.tp[1] += t_2 - t_1; tot.tp[2] += t_3 - t_2; tot.tp[3] += t_4 - t_3; tot.tp[4] += t_5 - t_4;
+        tot.tp[5] += tp_pro; tot.tp[6] += pcnt.t_filter - tf_base; tot.tp[7] += pcnt.t_dense - td_base; tot.tp[8] += tp_red;
+        tot.tp[9] += tp_n; tot.tp[11] += 1;
+    }
+#endif
+}
+
+// The Metropolis sweep kernel: one workgroup of NW wavefronts per cell visit (cb_visit).
+//  * separate colour launches (a.fused == 0): block b visits one cell of colour a.colour;
+//  * fused sweep (a.fused == 1): all 2^d colours in one launch; a workgroup takes a ticket (atomicAdd, so start order =
+//    colour order whatever the dispatch order), ticket t <-> (colour t / nactive, cell t mod nactive).  A cell waits
+//    (inside stage_neighbourhood) for the completion flags of its lower-colour neighbours: those have lower tickets,
+//    i.e. are held by workgroups that are resident or finished: no deadlock.
+//    (Persistent workgroups that loop over tickets were measured twice and rejected: the loop around the visit takes the
+//    kernel from 84 to 188 VGPRs -- or 128 with scratch spills -- and chunks of tickets let workgroups run ahead by more
+//    than one colour, so cells stall on their neighbours: 1.65 ms against 1.41 ms at N = 10^6.)
+// ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
+template <int D, int KIND, bool MULTI, int NW, bool ONE>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 3 : PMC_CB_MINWAVES)) void k_cb_pass(CbArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    WaveNbh h;
+    const DevModel *tab = setup_lds<D, MULTI, (NW >= 2 ? NW : 0)>(a, smem, h);
+    const int tid = team_tid<NW>();
+    CbTotals tot{};
+    if (!ONE) {
+        if (tid < 16) h.cnt[tid] = 0;
+        if (tid < 8) {           // compile-time indices into the kernel argument: no scratch copy
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (tid == q) { h.ptab[q] = a.pool.kind[q]; h.ptab[8 + q] = a.pool.sp0[q]; h.ptab[16 + q] = a.pool.sp1[q]; }
+        }
+        __syncthreads();
+    }
+    int aidx, colour = a.colour;
+    if (a.fused) {
+        if (tid == 0) h.flag[2] = (int)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
+        __syncthreads();
+        const int t = h.flag[2];
+        colour = t / a.nactive;
+        aidx = t - colour * a.nactive;
+    } else {
+        aidx = a.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+        if (aidx >= a.nactive) return;
+    }
+    unsigned long long *const st = a.stats + (size_t)(aidx & (PMC_NSHARD - 1)) * PMC_NSTATS;   // this workgroup's counter copy
+    cb_visit<D, KIND, MULTI, NW, ONE>(a, h, tab, colour, aidx, st, tot);
     if (tid == 0) {
         if (ONE) {
-            atomicAdd(&a.stats[0], att1);
-            if (acc1) atomicAdd(&a.stats[8], acc1);
+            if (tot.att1) atomicAdd(&st[0], tot.att1);
+            if (tot.acc1) atomicAdd(&st[8], tot.acc1);
         } else {
             for (int q = 0; q < a.pool.npool; q++) {
-                if (cnt[q]) atomicAdd(&a.stats[q], (unsigned long long)cnt[q]);
-                if (cnt[8 + q]) atomicAdd(&a.stats[8 + q], (unsigned long long)cnt[8 + q]);
+                if (h.cnt[q]) atomicAdd(&st[q], (unsigned long long)h.cnt[q]);
+                if (h.cnt[8 + q]) atomicAdd(&st[8 + q], (unsigned long long)h.cnt[8 + q]);
             }
         }
-        if (efix) atomicAdd(&a.stats[16], (unsigned long long)efix);
+        if (tot.efix) atomicAdd(&st[16], (unsigned long long)tot.efix);
+        if (tot.nnull) atomicAdd(&st[27], tot.nnull);
+#ifdef PMC_DEBUG_TIME
+        for (int q = 0; q < 10; q++) atomicAdd(&st[32 + q], tot.tp[q]);
+        atomicAdd(&st[47], tot.tp[11]);
+#endif
+    }
+    // work counters of the roofline (bench.py): every wavefront adds its own
+    if (wave_lane() == 0 && tot.pcnt.tests) {
+        atomicAdd(&st[25], (unsigned long long)tot.pcnt.tests);
+        atomicAdd(&st[26], (unsigned long long)tot.pcnt.energies);
     }
 }
 
@@ -2199,6 +2555,32 @@ __global__ __launch_bounds__(64) void k_delta_e(CbArgs a, int n, const int *__re
         double ea = stream_energy<D>(a, x[0], x[1], x[2], si, i);
         double eb = stream_energy<D>(a, xn[0], xn[1], xn[2], si, i);
         if (wave_lane() == 0) { e1[b] = ea; e2[b] = eb; }
+    }
+}
+
+// Sum the counter copies 1 .. PMC_NSHARD-1 into copy 0 and clear them: one block per counter, one thread per copy
+// (counter 17 holds error flags: OR).  Runs once per pmc_sweep call, after its last sweep.
+__global__ __launch_bounds__(PMC_NSHARD) void k_stats_fold(unsigned long long *__restrict__ stats)
+{
+    __shared__ unsigned long long red[PMC_NSHARD / 64];
+    const int idx = blockIdx.x, t = threadIdx.x;
+    unsigned long long v = 0;
+    if (t > 0) {
+        v = stats[(size_t)t * PMC_NSTATS + idx];
+        if (v) stats[(size_t)t * PMC_NSTATS + idx] = 0;
+    }
+    const bool flags = (idx == 17);
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const unsigned long long o = __shfl_xor(v, sft, 64);
+        v = flags ? (v | o) : (v + o);
+    }
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long tot = stats[idx];
+        for (int w = 0; w < PMC_NSHARD / 64; w++) tot = flags ? (tot | red[w]) : (tot + red[w]);
+        stats[idx] = tot;
     }
 }
 

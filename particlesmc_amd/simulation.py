@@ -41,6 +41,7 @@ class SweepStats:
         self.kernel_ms = st.kernel_ms
         self.sweep_kernel_ms = st.sweep_kernel_ms
         self.sweep_kernel_launches = st.sweep_kernel_launches
+        self.pair_tests, self.pairs_in_range, self.null_moves = st.pair_tests, st.pairs_in_range, st.null_moves
 
 
 MODES = {"sequential": _lib.SEQUENTIAL, "checkerboard": _lib.CHECKERBOARD}

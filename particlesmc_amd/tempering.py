@@ -82,10 +82,55 @@ def run_tempering(system, pool, ladder, nsweeps, exchange_every, seed, rank=0, w
     return rex, trace
 
 
+def replica_exchange(systems, ladder, seed, rnd, label):
+    """pmc_replica_exchange: one round over replicas held as handles of this process.  The library reads the
+    handles' running energies, decides and sets their temperatures.  Returns (label, n_accepted)."""
+    n = len(systems)
+    hs = (C.c_void_p * n)(*[s._h for s in systems])
+    lad = np.ascontiguousarray(ladder, dtype=np.float64)
+    lab = np.ascontiguousarray(label, dtype=np.int32).copy()
+    nacc = C.c_int32()
+    _lib.check(_lib.lib().pmc_replica_exchange(hs, n, lad.ctypes.data_as(C.POINTER(C.c_double)), int(seed), int(rnd),
+                                               lab.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nacc)))
+    return lab, nacc.value
+
+
+class RcclComm:
+    """An RCCL communicator created through the library's own entry points (pmc_rccl_*), for hosts without torch."""
+
+    def __init__(self, unique_id, rank, world, device):
+        self.rank, self.world = rank, world
+        self._c = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        _lib.check(_lib.lib().pmc_rccl_comm_create(buf, rank, world, device, C.byref(self._c)))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _lib.check(_lib.lib().pmc_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def exchange(self, system, ladder, seed, rnd, label):
+        """pmc_replica_exchange_rccl: ncclAllGather of one double per rank, identical decisions on every rank."""
+        lad = np.ascontiguousarray(ladder, dtype=np.float64)
+        lab = np.ascontiguousarray(label, dtype=np.int32).copy()
+        nacc = C.c_int32()
+        _lib.check(_lib.lib().pmc_replica_exchange_rccl(system._h, self._c, self.rank, self.world,
+                                                        lad.ctypes.data_as(C.POINTER(C.c_double)), int(seed), int(rnd),
+                                                        lab.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nacc)), system._h)
+        return lab, nacc.value
+
+    def close(self):
+        if self._c:
+            _lib.check(_lib.lib().pmc_rccl_comm_destroy(self._c))
+            self._c = C.c_void_p()
+
+
 def run_tempering_local(systems, pool, ladder, nsweeps, exchange_every, seed, mode="checkerboard"):
     """Parallel tempering with all replicas as handles of this process (one GPU, or several
     devices through the handles' `device`): same decisions as the one-rank-per-GPU driver, the
-    energies simply need no collective.  Returns (labels, accepted, attempted, per-replica energy traces)."""
+    energies simply need no collective (pmc_replica_exchange).  Returns (labels, accepted, attempted,
+    per-replica traces of (temperature index, energy))."""
     from .simulation import mc_sweep_many
     n = len(systems)
     ladder = np.ascontiguousarray(ladder, dtype=np.float64)
@@ -96,15 +141,11 @@ def run_tempering_local(systems, pool, ladder, nsweeps, exchange_every, seed, mo
     traces = [[] for _ in range(n)]
     while done < nsweeps:
         k = min(exchange_every, nsweeps - done)
-        energies = np.zeros(n)
         for r, st in enumerate(mc_sweep_many(systems, pool, nsweeps=k, mode=mode)):
-            energies[r] = st.energy
             traces[r].append((int(label[r]), st.energy))
         done += k
-        label, nacc = pt_decide(seed, rnd, energies, ladder, label)
+        label, nacc = replica_exchange(systems, ladder, seed, rnd, label)
         att += max(0, (n - (rnd & 1)) // 2)
         acc += nacc
         rnd += 1
-        for r, s in enumerate(systems):
-            s.temperature = float(ladder[label[r]])
     return label, acc, att, traces

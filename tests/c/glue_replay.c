@@ -1,0 +1,180 @@
+/* glue_replay.c -- the call sequences of julia/PMCHip.jl, replayed in C against libpmc_hip.so.
+ *
+ * Julia is not available in the build image, so the ccall glue cannot run there.  What CAN be checked without Julia:
+ *  (1) that the isbits structs PMCHip.jl declares (PairModel, Params, CMove, Stats) have exactly the layout of
+ *      include/pmc.h  -- `glue_replay --layout` prints size / offset of every field as the C compiler lays them out;
+ *      tests/test_julia_glue.py derives the same numbers from the field list in the .jl file (Julia lays isbits structs
+ *      out like C) and from the ctypes mirror, and compares all three;
+ *  (2) that every call sequence the glue performs is accepted by the library and returns what the reference semantics
+ *      require -- `glue_replay <input> <output>` performs them in the glue's order with the glue's argument shapes
+ *      (1-based ids, AoS positions, Ref-style out parameters) and writes the results for comparison with the oracle.
+ * Each block names the PMCHip.jl function it replays.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pmc.h"
+
+#define CHECK(call)                                                                            \
+    do {                                                                                       \
+        int rc_ = (call);                                                                      \
+        if (rc_ != 0) {                                                                        \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, pmc_last_error(h));                  \
+            return 2;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+static void layout(void)
+{
+#define F(S, f) printf(#S "." #f " %zu %zu\n", offsetof(S, f), sizeof(((S *)0)->f))
+    printf("pmc_pair_model.sizeof %zu\n", sizeof(pmc_pair_model));
+    F(pmc_pair_model, kind); F(pmc_pair_model, n); F(pmc_pair_model, eps); F(pmc_pair_model, eps4); F(pmc_pair_model, sigma);
+    F(pmc_pair_model, sigma2); F(pmc_pair_model, rcut); F(pmc_pair_model, rcut2); F(pmc_pair_model, shift);
+    F(pmc_pair_model, ndiv2_i); F(pmc_pair_model, ndiv2_f); F(pmc_pair_model, C0); F(pmc_pair_model, C2_s2); F(pmc_pair_model, C4_s4);
+    printf("pmc_params.sizeof %zu\n", sizeof(pmc_params));
+    F(pmc_params, N); F(pmc_params, d); F(pmc_params, nspecies); F(pmc_params, box); F(pmc_params, cell); F(pmc_params, ncells);
+    F(pmc_params, temperature); F(pmc_params, density); F(pmc_params, models); F(pmc_params, device); F(pmc_params, chain); F(pmc_params, seed);
+    printf("pmc_move.sizeof %zu\n", sizeof(pmc_move));
+    F(pmc_move, kind); F(pmc_move, species); F(pmc_move, probability); F(pmc_move, sigma);
+    printf("pmc_stats.sizeof %zu\n", sizeof(pmc_stats));
+    F(pmc_stats, attempted); F(pmc_stats, accepted); F(pmc_stats, energy); F(pmc_stats, energy_fix); F(pmc_stats, kernel_ms);
+    F(pmc_stats, sweep_kernel_ms); F(pmc_stats, sweep_kernel_launches); F(pmc_stats, pair_tests); F(pmc_stats, pairs_in_range);
+    F(pmc_stats, null_moves);
+#undef F
+}
+
+int main(int argc, char **argv)
+{
+    pmc_system *h = NULL;
+    if (argc == 2 && strcmp(argv[1], "--layout") == 0) { layout(); return 0; }
+    if (argc != 3) { fprintf(stderr, "usage: glue_replay --layout | glue_replay <input.bin> <output.txt>\n"); return 1; }
+
+    /* input: int64 N, int32 d, int32 S, double rho, double T, double rcut, N*d doubles, N int32 species */
+    FILE *fi = fopen(argv[1], "rb");
+    if (!fi) { perror(argv[1]); return 1; }
+    int64_t N; int32_t d, S; double rho, T, rcut;
+    if (fread(&N, 8, 1, fi) != 1 || fread(&d, 4, 1, fi) != 1 || fread(&S, 4, 1, fi) != 1 || fread(&rho, 8, 1, fi) != 1 ||
+        fread(&T, 8, 1, fi) != 1 || fread(&rcut, 8, 1, fi) != 1) return 1;
+    double *pos = malloc((size_t)N * d * sizeof(double));
+    int32_t *sp = malloc((size_t)N * sizeof(int32_t));
+    if (fread(pos, sizeof(double), (size_t)N * d, fi) != (size_t)N * d || fread(sp, 4, (size_t)N, fi) != (size_t)N) return 1;
+    fclose(fi);
+    FILE *fo = fopen(argv[2], "w");
+    if (!fo) { perror(argv[2]); return 1; }
+
+    /* ---- HIPLinkedList(box, rcut, N) + build_neighbour_list!: Params by reference, models row-major [i][j] ---------- */
+    pmc_pair_model *models = calloc((size_t)S * S, sizeof *models);
+    for (int i = 0; i < S; i++)
+        for (int j = 0; j < S; j++)
+            CHECK(pmc_model_lennard_jones(1.0 + 0.25 * (i != j), 1.0 - 0.1 * (i + j) / 2.0, rcut, 1, &models[i * S + j]));
+    pmc_params p;
+    memset(&p, 0, sizeof p);
+    p.N = N; p.d = d; p.nspecies = S; p.temperature = T; p.density = rho; p.models = models;
+    p.device = 0; p.chain = 3; p.seed = 77;
+    for (int a = 0; a < 3; a++) { p.box[a] = 1.0; p.cell[a] = 1.0; p.ncells[a] = 1; }      /* pad3(v, fill) */
+    double box1;
+    CHECK(pmc_box_from_density(N, rho, d, &box1));
+    for (int a = 0; a < d; a++) p.box[a] = box1;
+    CHECK(pmc_linked_list_geometry(d, p.box, rcut, p.cell, p.ncells));
+    CHECK(pmc_create(&p, &h));
+    CHECK(pmc_upload(h, pos, sp));
+    CHECK(pmc_build_cells(h));
+    double e_init;
+    CHECK(pmc_init_energy(h, &e_init));        /* System(...) computes it once (src/atoms.jl:50-56) ... */
+    CHECK(pmc_set_energy(h, e_init));          /* ... and the glue hands system.energy[1] over */
+    fprintf(fo, "energy0 %.17g\n", e_init);
+
+    /* ---- getproperty(L, :cs) ------------------------------------------------------------------------------------ */
+    int64_t *cs = malloc((size_t)N * sizeof(int64_t));
+    CHECK(pmc_get_cells(h, cs));
+    fprintf(fo, "cs");
+    for (int64_t i = 0; i < N; i++) fprintf(fo, " %lld", (long long)cs[i]);
+    fprintf(fo, "\n");
+
+    /* ---- compute_energy_particle(system, i, L): 1-based id, Ref{Float64} out ---------------------------------------- */
+    for (int64_t i = 1; i <= N; i += N / 7 + 1) {
+        double e = 0.0;
+        CHECK(pmc_energy_particle(h, i, &e));
+        fprintf(fo, "e_particle %lld %.17g\n", (long long)i, e);
+    }
+
+    /* ---- perform_action!(Displacement) / revert_action!: delta as a d-vector, (e1, e2) returned, de stored ---------- */
+    {
+        const int64_t i = 5;
+        double delta[3] = {0.031, -0.017, 0.044}, e1 = 0, e2 = 0, de = 0, en = 0;
+        CHECK(pmc_displacement_perform(h, i, delta, &e1, &e2, &de));
+        CHECK(pmc_get_energy(h, &en));
+        fprintf(fo, "disp_perform %.17g %.17g %.17g %.17g\n", e1, e2, de, en);
+        double minus[3] = {-delta[0], -delta[1], -delta[2]};       /* invert_action! negated it (src/moves.jl:88-90) */
+        CHECK(pmc_displacement_revert(h, i, minus, de));
+        CHECK(pmc_get_energy(h, &en));
+        fprintf(fo, "disp_revert %.17g\n", en);
+    }
+
+    /* ---- perform_action!(DiscreteSwap) / revert_action! ------------------------------------------------------------- */
+    if (S > 1) {
+        int64_t i = 0, j = 0;
+        for (int64_t k = 0; k < N && (!i || !j); k++) { if (sp[k] == 1 && !i) i = k + 1; if (sp[k] == 2 && !j) j = k + 1; }
+        double e1 = 0, e2 = 0, de = 0, en = 0;
+        CHECK(pmc_swap_perform(h, i, j, &e1, &e2, &de));
+        CHECK(pmc_get_energy(h, &en));
+        fprintf(fo, "swap_perform %lld %lld %.17g %.17g %.17g %.17g\n", (long long)i, (long long)j, e1, e2, de, en);
+        CHECK(pmc_swap_revert(h, j, i, de));                       /* the inverted action swaps the roles of i and j */
+        CHECK(pmc_get_energy(h, &en));
+        fprintf(fo, "swap_revert %.17g\n", en);
+    }
+
+    /* ---- make_step!(sim, HIPMetropolis): one scheduler tick = pmc_sweep(h, mode, pool, npool, 1, Ref{Stats}) --------- */
+    pmc_move pool[2];
+    memset(pool, 0, sizeof pool);
+    pool[0].kind = PMC_MOVE_DISPLACEMENT; pool[0].probability = S > 1 ? 0.8 : 1.0; pool[0].sigma = 0.05;
+    pool[1].kind = PMC_MOVE_SWAP; pool[1].species[0] = 1; pool[1].species[1] = 2; pool[1].probability = 0.2;
+    const int npool = S > 1 ? 2 : 1;
+    for (int mode = 0; mode <= 1; mode++) {                         /* 0 = the reference's sequential chain, 1 = checkerboard */
+        pmc_stats st;
+        memset(&st, 0, sizeof st);
+        CHECK(pmc_sweep(h, mode, pool, npool, 1, &st));
+        fprintf(fo, "sweep %d %lld %lld %lld %lld %.17g %lld\n", mode, (long long)st.attempted[0], (long long)st.accepted[0],
+                (long long)st.attempted[1], (long long)st.accepted[1], st.energy, (long long)st.energy_fix);
+    }
+
+    /* ---- sweep_many!: begin on every handle, then end on every handle (here: one handle, two rounds) ----------------- */
+    for (int round = 0; round < 2; round++) {
+        pmc_stats st;
+        CHECK(pmc_sweep_begin(h, PMC_CHECKERBOARD, pool, npool, 2));
+        CHECK(pmc_sweep_end(h, &st));
+        fprintf(fo, "sweep_many %lld %lld %.17g %lld\n", (long long)st.attempted[0], (long long)st.accepted[0], st.energy, (long long)st.energy_fix);
+    }
+
+    /* ---- refresh!: positions straight into the Vector{SVector{d,Float64}} buffer, species as Int32, energy ------------ */
+    double en = 0;
+    CHECK(pmc_download(h, pos, sp));
+    CHECK(pmc_get_energy(h, &en));
+    fprintf(fo, "refresh_energy %.17g\n", en);
+    fprintf(fo, "pos");
+    for (int64_t k = 0; k < N * d; k++) fprintf(fo, " %.17g", pos[k]);
+    fprintf(fo, "\nspecies");
+    for (int64_t k = 0; k < N; k++) fprintf(fo, " %d", sp[k]);
+    fprintf(fo, "\n");
+
+    /* ---- set_temperature! -------------------------------------------------------------------------------------------- */
+    CHECK(pmc_set_temperature(h, 1.5 * T));
+    double T2 = 0;
+    CHECK(pmc_get_temperature(h, &T2));
+    fprintf(fo, "temperature %.17g\n", T2);
+
+    /* ---- the AbstractRNG wrapper (PMCHip.SequentialWords): the words of sequential step k, host side ------------------ */
+    for (uint64_t step = 0; step < 3; step++) {
+        uint32_t R[4], Q[4];
+        CHECK(pmc_sequential_words(77, 3, step, R, Q));
+        fprintf(fo, "words %llu %u %u %u %u %u %u %u %u\n", (unsigned long long)step, R[0], R[1], R[2], R[3], Q[0], Q[1], Q[2], Q[3]);
+    }
+    CHECK(pmc_destroy(h));
+    h = NULL;
+    fclose(fo);
+    free(pos); free(sp); free(cs); free(models);
+    return 0;
+}

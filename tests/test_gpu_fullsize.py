@@ -186,7 +186,17 @@ def test_bench_line_contract(gpu):
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the binding roofline is FP64 vector arithmetic, priced from work the kernel counted in THIS run; a fraction
+    # above 1 would mean a wrong model
+    assert r["bound"] == "fp64-valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    fm = r["flop_model"]
+    assert 200 < fm["pair_tests_per_move"] < 1200 and 60 < fm["pair_energies_per_move"] < 250
+    assert abs(fm["flop_per_move"] - (9 * fm["pair_tests_per_move"] + 9 * fm["pair_energies_per_move"])) < 1e-6
+    assert "contract_hbm_equiv" in r and "over_hbm_peak" in r["contract_hbm_equiv"]      # named, never `frac`
+    for k in ("hbm_measured_frac", "valu_issue_frac"):
+        assert k not in r or "source" in r[k]                                           # replayed numbers carry a source
+    assert 0.0 <= d["null_move_fraction"] < 0.1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e3 and "sample" in c
     assert d["value"] > 1e6 and d["running_energy_equals_recomputed"] is True

@@ -1,0 +1,165 @@
+"""julia/PMCHip.jl made falsifiable without a Julia binary (there is none in the build image).
+
+* layout (CPU): the isbits structs the glue declares are parsed out of the .jl text, laid out by the C rules Julia
+  uses for isbits structs, and compared with `offsetof` from the C compiler (tests/c/glue_replay.c --layout) and
+  with the ctypes mirror the GPU tests go through;
+* call sequences (-m gpu): tests/c/glue_replay.c performs every call the glue performs, in the glue's order and
+  with its argument shapes, against libpmc_hip.so; the results are compared with the oracle.
+"""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = os.path.join(ROOT, "julia", "PMCHip.jl")
+SRC = os.path.join(ROOT, "tests", "c", "glue_replay.c")
+CSRC = os.path.join(ROOT, "particlesmc_amd", "csrc")
+
+JL_TYPES = {"Int32": (4, 4), "UInt32": (4, 4), "Int64": (8, 8), "UInt64": (8, 8), "Float64": (8, 8)}
+
+
+def _jl_field(t):
+    """(size, alignment) of a Julia isbits field type as C lays it out."""
+    t = t.strip()
+    if t in JL_TYPES:
+        return JL_TYPES[t]
+    m = re.fullmatch(r"NTuple\{(\d+),\s*(\w+)\}", t)
+    if m:
+        s, a = JL_TYPES[m.group(2)]
+        return int(m.group(1)) * s, a
+    if t.startswith("Ptr{"):
+        return 8, 8
+    raise AssertionError(f"unhandled Julia field type {t}")
+
+
+def _jl_struct(name):
+    txt = open(JL).read()
+    body = re.search(r"^struct " + name + r"\b[^\n]*\n(.*?)^end", txt, re.S | re.M).group(1)
+    fields = []
+    for line in body.split("\n"):
+        line = line.split("#")[0]
+        for part in line.split(";"):
+            part = part.strip()
+            if part:
+                fname, ftype = part.split("::")
+                fields.append((fname.strip(), ftype.strip()))
+    off, maxa, out = 0, 1, []
+    for fname, ftype in fields:
+        size, align = _jl_field(ftype)
+        off = (off + align - 1) // align * align
+        out.append((fname, off, size))
+        off += size
+        maxa = max(maxa, align)
+    return out, (off + maxa - 1) // maxa * maxa
+
+
+@pytest.fixture(scope="module")
+def harness(built, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("glue") / "glue_replay")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe, SRC,
+                           "-L", CSRC, "-lpmc_hip", "-Wl,-rpath," + CSRC])
+    return exe
+
+
+def test_julia_struct_layouts_equal_the_c_header_and_the_ctypes_mirror(harness):
+    from particlesmc_amd import _lib
+    lines = subprocess.check_output([harness, "--layout"]).decode().split("\n")
+    c = {}
+    for ln in lines:
+        if ln.strip():
+            parts = ln.split()
+            c[parts[0]] = tuple(int(v) for v in parts[1:])
+    pairs = [("PairModel", "pmc_pair_model", _lib.PairModel), ("Params", "pmc_params", _lib.Params),
+             ("CMove", "pmc_move", _lib.Move), ("Stats", "pmc_stats", _lib.Stats)]
+    import ctypes as C
+    for jl, cname, ct in pairs:
+        fields, size = _jl_struct(jl)
+        assert (size,) == c[f"{cname}.sizeof"] and size == C.sizeof(ct), (jl, size, c[f"{cname}.sizeof"], C.sizeof(ct))
+        cfields = [k.split(".")[1] for k in c if k.startswith(cname + ".") and not k.endswith(".sizeof")]
+        assert len(fields) == len(cfields) == len(ct._fields_), (jl, len(fields), len(cfields))
+        for (fname, off, fsize), cf, (ctname, *_rest) in zip(fields, cfields, ct._fields_):
+            assert (off, fsize) == c[f"{cname}.{cf}"], (jl, fname, cf, off, fsize, c[f"{cname}.{cf}"])
+            assert getattr(ct, ctname).offset == off and getattr(ct, ctname).size == fsize, (jl, fname, ctname)
+            # same name on all three sides (Greek letters in the Julia constructors aside, the struct fields are ASCII)
+            assert fname == cf == ctname, (fname, cf, ctname)
+
+
+def test_glue_declares_an_abstract_rng_over_the_sequential_words():
+    txt = open(JL).read()
+    assert "struct SequentialWords <: Random.AbstractRNG" in txt and ":pmc_sequential_words" in txt
+    assert "Random.rand(rng::SequentialWords, ::Random.SamplerType{UInt32})" in txt
+
+
+@pytest.mark.gpu
+def test_glue_call_sequences_replayed_in_c_match_the_oracle(gpu, harness, tmp_path):
+    from oracle import oracle as O
+    from inputs import lj_lattice
+    pmc = gpu
+    pos, sp, rho = lj_lattice(12, jitter=0.06, seed=21)
+    N, d, S, T, rcut = len(pos), 3, 2, 1.1, 2.4
+    sp = np.ones(N, dtype=np.int32)
+    sp[np.random.default_rng(4).permutation(N)[: N // 3]] = 2
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.txt")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<qiiddd", N, d, S, rho, T, rcut))
+        f.write(np.ascontiguousarray(pos).tobytes())
+        f.write(sp.tobytes())
+    subprocess.check_call([harness, fin, fout], timeout=300)
+    out = {}
+    for ln in open(fout):
+        k, *v = ln.split()
+        out.setdefault(k, []).append(v)
+
+    # the harness builds its models with the library's host constructors; the oracle's are the independent restatement
+    arr = (O.Model * (S * S))()
+    for i in range(S):
+        for j in range(S):
+            arr[i * S + j] = O.lennard_jones(1.0 + 0.25 * (i != j), 1.0 - 0.1 * (i + j) / 2.0, rcut)
+    mo = (arr, S)
+    o = O.System(pos, sp, rho, T, mo, O.LINKEDLIST)
+    assert float(out["energy0"][0][0]) == o.energy
+    assert np.array_equal(np.array(out["cs"][0], dtype=np.int64), o.cells())
+    for i, e in out["e_particle"]:
+        assert float(e) == o.energy_particle(int(i))
+    delta = np.array([0.031, -0.017, 0.044])
+    r = o.displacement_perform(5, delta)
+    assert tuple(float(v) for v in out["disp_perform"][0][:3]) == r and float(out["disp_perform"][0][3]) == o.energy
+    o.displacement_revert(5, -delta, r[2])
+    assert float(out["disp_revert"][0][0]) == o.energy
+    i, j = int(out["swap_perform"][0][0]), int(out["swap_perform"][0][1])
+    r = o.swap_perform(i, j, 1, 2)
+    assert tuple(float(v) for v in out["swap_perform"][0][2:5]) == r and float(out["swap_perform"][0][5]) == o.energy
+    o.swap_revert(j, i, 1, 2, r[2])
+    assert float(out["swap_revert"][0][0]) == o.energy
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.8},
+                        {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.2}])
+    # make_step! in sequential mode: N steps of the reference chain (seed 77, chain 3, from step 0)
+    att, acc = o.mc_steps(pool, 77, 3, 0, N)
+    s0 = out["sweep"][0]
+    assert [int(s0[1]), int(s0[2]), int(s0[3]), int(s0[4])] == [att[0], acc[0], att[1], acc[1]] and float(s0[5]) == o.energy
+    # ... then in checkerboard mode: sweep 1 of the schedule (the sequential sweep advanced the sweep counter to 1)
+    cb = O.Checkerboard(o.positions(), o.species(), o.box, T, mo, seed=77, chain=3)
+    att, acc = cb.sweeps(pool, 1, 1)
+    s1 = out["sweep"][1]
+    assert [int(s1[1]), int(s1[2]), int(s1[3]), int(s1[4])] == [att[0], acc[0], att[1], acc[1]] and int(s1[6]) == cb.energy_fix
+    # sweep_many!: two rounds of two sweeps
+    for k, row in enumerate(out["sweep_many"]):
+        att, acc = cb.sweeps(pool, 2 + 2 * k, 2)
+        assert [int(row[0]), int(row[1])] == [att[0], acc[0]] and int(row[3]) == cb.energy_fix
+    # refresh!: positions, species, energy
+    assert np.array_equal(np.array(out["pos"][0], dtype=np.float64).reshape(N, d), cb.positions())
+    assert np.array_equal(np.array(out["species"][0], dtype=np.int32), cb.species())
+    assert float(out["refresh_energy"][0][0]) == cb.energy_fix / 2.0 ** 32
+    assert float(out["temperature"][0][0]) == 1.5 * T
+    # the words the AbstractRNG wrapper serves: Philox blocks of the sequential stream
+    # (DESIGN.md "random streams": ctr = (step_lo, step_hi, 0, TAG_SEQ0 | TAG_SEQ1), key = (seed_lo, seed_hi + chain))
+    for row in out["words"]:
+        step = int(row[0])
+        assert [int(v) for v in row[1:5]] == O.philox((step & 0xffffffff, step >> 32, 0, 1), (77, 3))
+        assert [int(v) for v in row[5:9]] == O.philox((step & 0xffffffff, step >> 32, 0, 2), (77, 3))
+    assert len(out["words"]) == 3
+    del pmc
