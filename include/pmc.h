@@ -172,6 +172,19 @@ int pmc_swap_perform(pmc_system *h, int64_t i, int64_t j,
                      double *e1, double *e2, double *de);           /* src/moves.jl:11-20,187-194 */
 int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de);/* src/moves.jl:201-207 */
 
+/* -- EnergyBias policy on the device (src/moves.jl:246-280) ----------------- */
+/* sample_action!(::DiscreteSwap, ::EnergyBias, ...): i from species sp1 with probability exp(theta1 e_i) / sum, j from sp2
+ * with exp(theta2 e_j) / sum, over the DEVICE-resident per-particle energies (reference-order compute_energy_particle of
+ * every particle; nothing of size N crosses the bus).  u1, u2: the caller's uniforms in [0, 1) for the two
+ * rand(rng, Categorical(w)) picks (inverse CDF in sp_ids order).  Also returns log q(i, j) (moves.jl:254-263). */
+int pmc_energy_bias_sample(pmc_system *h, int32_t sp1, int32_t sp2, double theta1, double theta2, double u1, double u2,
+                           int64_t *i, int64_t *j, double *logq);
+/* log_proposal_density(::DiscreteSwap, ::EnergyBias, ...) of a given pair in the CURRENT state (called again after
+ * invert_action! for the backward move). */
+int pmc_energy_bias_logq(pmc_system *h, int32_t sp1, int32_t sp2, double theta1, double theta2, int64_t i, int64_t j,
+                         double *logq);
+int pmc_exp(double x, double *y);                                  /* the fixed-operation-sequence exp of the weights */
+
 /* -- throughput engine ----------------------------------------------------- */
 int pmc_total_energy(pmc_system *h, double *E, int64_t *E_fix);  /* sum(local)/2 src/atoms.jl:51-52, exact fixed-point */
 int pmc_energy_particles_exact(pmc_system *h, double *e);         /* all compute_energy_particle(i) at once (src/ParticlesMC.jl:104-113), exact sums */

@@ -108,6 +108,11 @@ def lib():
     L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.orc_det_log.restype = C.c_double
     L.orc_det_log.argtypes = [C.c_double]
+    L.orc_det_exp.restype = C.c_double
+    L.orc_det_exp.argtypes = [C.c_double]
+    L.orc_energy_bias.restype = C.c_int
+    L.orc_energy_bias.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                  lp, lp, dp]
     L.orc_det_sincos2pi.argtypes = [C.c_uint32, dp, dp]
     L.orc_box_muller.argtypes = [C.c_uint32, C.c_uint32, dp, dp]
     L.orc_uniform53.restype = C.c_double
@@ -325,6 +330,15 @@ class System:
 
     def set_temperature(self, T):
         lib().orc_system_set_temperature(self.h, C.c_double(T))
+
+    def energy_bias(self, species, theta, u=(0.0, 0.0), given=(0, 0)):
+        """EnergyBias (moves.jl:246-280): (i, j, log q) sampled with the uniforms u, or log q of a given pair."""
+        i, j, lq = C.c_int64(), C.c_int64(), C.c_double()
+        rc = lib().orc_energy_bias(self.h, species[0], species[1], theta[0], theta[1], u[0], u[1], given[0], given[1],
+                                   C.byref(i), C.byref(j), C.byref(lq))
+        if rc:
+            raise ValueError("a species of the pair has no particles")
+        return i.value, j.value, lq.value
 
     def mc_steps(self, pool, seed, chain, step0, nsteps):
         st = Stats()

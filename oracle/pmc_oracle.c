@@ -731,6 +731,45 @@ void orc_system_get_positions(const orc_system *s, double *pos) { memcpy(pos, s-
 void orc_system_get_species(const orc_system *s, int32_t *sp) { memcpy(sp, s->species, sizeof(int32_t) * (size_t)s->N); }
 int64_t orc_species_count(const orc_system *s, int32_t sp) { return s->sp_n[sp - 1]; }
 void orc_species_ids(const orc_system *s, int32_t sp, int64_t *ids) { memcpy(ids, s->sp_ids[sp - 1], sizeof(int64_t) * (size_t)s->sp_n[sp - 1]); }
+
+
+/* EnergyBias (moves.jl:246-280).  sample: w = exp.(theta .* compute_energy_particle(system, sp_ids[species])),
+ * w ./= sum(w) (Base pairwise sum), rand(rng, Categorical(w)) as the inverse-CDF walk `cp <= u` over the caller's
+ * uniform; log density: theta1 e_i + theta2 e_j - log(sum(w1)) - log(sum(w2)).  gi / gj > 0: density of a given pair.
+ * exp and log are the fixed-operation-sequence versions, so the device reproduces every bit. */
+int orc_energy_bias(const orc_system *s, int32_t sp1, int32_t sp2, double theta1, double theta2, double u1, double u2,
+                    int64_t gi, int64_t gj, int64_t *i_out, int64_t *j_out, double *logq)
+{
+    const int32_t sp[2] = {sp1, sp2};
+    const double theta[2] = {theta1, theta2}, u[2] = {u1, u2};
+    const int64_t given[2] = {gi, gj};
+    int64_t pick[2] = {0, 0};
+    double numer = 0.0, lse[2] = {0.0, 0.0};
+    for (int side = 0; side < 2; side++) {
+        const int64_t n = s->sp_n[sp[side] - 1];
+        const int64_t *ids = s->sp_ids[sp[side] - 1];
+        if (n <= 0) return 1;
+        double *w = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int64_t k = 0; k < n; k++) w[k] = orc_det_exp(theta[side] * orc_energy_particle(s, ids[k]));
+        const double S = pairwise_sum(w, 0, n - 1);
+        if (given[side] > 0) {
+            pick[side] = given[side];
+        } else {
+            for (int64_t k = 0; k < n; k++) w[k] = w[k] / S;
+            int64_t i = 0;
+            double cp = w[0];
+            while (cp <= u[side] && i < n - 1) { i++; cp += w[i]; }
+            pick[side] = ids[i];
+        }
+        lse[side] = orc_det_log(S);
+        numer += theta[side] * orc_energy_particle(s, pick[side]);
+        free(w);
+    }
+    if (i_out) *i_out = pick[0];
+    if (j_out) *j_out = pick[1];
+    if (logq) *logq = numer - lse[0] - lse[1];
+    return 0;
+}
 void orc_species_heads(const orc_system *s, int64_t *h) { memcpy(h, s->sp_heads, sizeof(int64_t) * (size_t)s->N); }
 
 /* ======================================================================== */
@@ -868,6 +907,36 @@ double orc_det_log(double x)
     double R = t2 + t1;
     double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* exp(x) in a fixed sequence of IEEE operations (fdlibm e_exp.c), finite |x| <= 700: the weights of the EnergyBias
+ * policy must come out with the same bits on a CPU and a GPU (pmc_device.h:det_exp). */
+double orc_det_exp(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                        invln2 = 1.44269504088896338700e+00,
+                        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x > 700.0) x = 700.0;
+    if (x < -700.0) x = -700.0;
+    double hi = x, lo = 0.0;
+    int64_t k = 0;
+    if (x > 0.34657359027997264 || x < -0.34657359027997264) {
+        k = (int64_t)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+        double t = (double)k;
+        hi = x - t * ln2_hi;
+        lo = t * ln2_lo;
+        x = hi - lo;
+    }
+    double t = x * x;
+    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    uint64_t b;
+    memcpy(&b, &y, 8);
+    b += (uint64_t)(k << 52);
+    memcpy(&y, &b, 8);
+    return y;
 }
 
 /* sin and cos of 2*pi*w/2^32: the octant comes from the top 3 bits, the

@@ -92,6 +92,9 @@ void orc_species_heads(const orc_system *s, int64_t *heads);
 /* ---- RNG + deterministic math (the schedule's proposal generator) --------- */
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_det_log(double x);
+double orc_det_exp(double x);
+int orc_energy_bias(const orc_system *s, int32_t sp1, int32_t sp2, double theta1, double theta2, double u1, double u2,
+                    int64_t gi, int64_t gj, int64_t *i_out, int64_t *j_out, double *logq);   /* moves.jl:246-280 */
 void orc_det_sincos2pi(uint32_t w, double *s, double *c);
 void orc_box_muller(uint32_t w1, uint32_t w2, double *z0, double *z1);
 double orc_uniform53(uint32_t hi, uint32_t lo);

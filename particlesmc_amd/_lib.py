@@ -93,6 +93,9 @@ SYMBOLS = {
     "pmc_displacement_revert": (C.c_int, [_h, C.c_int64, _dp, C.c_double]),
     "pmc_swap_perform": (C.c_int, [_h, C.c_int64, C.c_int64, _dp, _dp, _dp]),
     "pmc_swap_revert": (C.c_int, [_h, C.c_int64, C.c_int64, C.c_double]),
+    "pmc_energy_bias_sample": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _lp, _lp, _dp]),
+    "pmc_energy_bias_logq": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_int64, _dp]),
+    "pmc_exp": (C.c_int, [C.c_double, _dp]),
     "pmc_total_energy": (C.c_int, [_h, _dp, _lp]),
     "pmc_energy_particles_exact": (C.c_int, [_h, _dp]),
     "pmc_delta_e": (C.c_int, [_h, C.c_int64, _lp, _dp, _dp, _dp]),

@@ -242,6 +242,36 @@ __device__ __host__ __forceinline__ double det_log(double x)
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+// exp(x) as a fixed sequence of IEEE operations (fdlibm e_exp.c: k = round(x / ln 2), r = x - k ln 2 in two pieces,
+// exp(r) from a degree-5 rational correction, scaling by 2^k through the exponent field): the same bits on the host, the
+// device and in the oracle (EnergyBias weights, src/moves.jl:270-273).  Finite |x| < 700 only; beyond that it saturates.
+__device__ __host__ __forceinline__ double det_exp(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00,
+                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x > 700.0) x = 700.0;
+    if (x < -700.0) x = -700.0;
+    double hi = x, lo = 0.0;
+    long long k = 0;
+    if (x > 0.34657359027997264 || x < -0.34657359027997264) {      // |x| > ln(2) / 2
+        k = (long long)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+        const double t = (double)k;
+        hi = x - t * ln2_hi;
+        lo = t * ln2_lo;
+        x = hi - lo;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double y;
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    uint64_t b = (uint64_t)__builtin_bit_cast(uint64_t, y);
+    b += (uint64_t)(k << 52);                                        // |k| <= 1010: y stays a normal number
+    return __builtin_bit_cast(double, b);
+}
+
 __device__ __host__ __forceinline__ void det_sincos2pi(uint32_t w, double *sn, double *cs)
 {
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,

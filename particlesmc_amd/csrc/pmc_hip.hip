@@ -436,18 +436,20 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     CR(hipMalloc(&h->d_hist, (8 * 256 + 1) * sizeof(int)));
     if (const char *e = getenv("PMC_NO_ORDER")) h->use_order = !(e[0] == '1');
     {
-        // wavefronts per cell: small systems have too few cells per colour to fill 256 CUs with one
-        // wavefront each; teams of 4 (speculative slot batches for single-Displacement pools) win up to
-        // ~1500 cells per colour (N=32768 +30 %, N=110592 +23 %, N=175616 +11 % over teams of 2), above
-        // that two wavefronts per cell (half the LDS per wavefront, half the latency of a cell visit); up to ~500
-        // cells per colour (N <~ 9e4) teams of 8 resolve eight slots per batch (N=13824 +13 %, N=32768 +11 %,
-        // N=64000 +13 %, N=85184 +9 % over teams of 4; N=110592 -12 %)
+        // Wavefronts per cell.  Every wavefront evaluates one proposal slot alone (wave_delta_e); a team of NW
+        // wavefronts evaluates NW slots of its cell speculatively at once and resolves them in order.  Small systems
+        // have too few cells per colour to fill 256 CUs with one wavefront each, so they take wide teams; from a few
+        // thousand cells per colour on, one wavefront per cell wastes nothing on the resolution step.  Measured on
+        // MI355X (r02, 3-D LJ, moves/s for teams of 1 / 2 / 4 / 8): N=32768 (216 cells per colour) 0.54 / 0.85 / 1.21 /
+        // 1.30e8; N=110592 (729) 1.7 / 2.7 / 3.5 / 2.9e8; N=262144 (1728) 3.9 / 5.5 / 5.0 / 3.1e8; N=10^6 (6859)
+        // 7.6 / 7.1 / 5.3 / 3.3e8.  Multi-species kernels carry more registers and a larger LDS footprint per cell:
+        // there two wavefronts per cell stay ahead at every size measured (Kob-Andersen N=10^6: 4.0 vs 5.9e8).
         long long nact = 1;
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
-        h->team = (nact <= 512) ? 8 : ((nact <= 1536) ? 4 : 2);
-        // 2-d neighbourhoods hold ~70-100 candidates: a shared candidate loop leaves half of two wavefronts' lanes
-        // empty, one wavefront per slot does not (N=65536 soft spheres, one chain: 3.4e8 vs 3.2e8 moves/s)
-        if (h->D == 2 && nact > 512 && nact <= 2048) h->team = 4;
+        h->team = (nact <= 512) ? 8 : ((nact <= 900) ? 4 : ((nact <= 3000 || h->S > 1) ? 2 : 1));
+        // 2-d neighbourhoods hold ~70-100 candidates (two filter trips): N=65536 binary soft spheres (1600 cells per
+        // colour) 3.5 / 3.9 / 3.6e8 for teams of 1 / 2 / 4
+        if (h->D == 2 && nact > 512) h->team = 2;
         if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4 || t == 8) h->team = t; }
     }
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
@@ -1757,6 +1759,69 @@ extern "C" int pmc_replica_exchange(pmc_system **hs, int32_t n, const double *la
     const int rc = pmc_pt_decide(seed, round, n, e.data(), ladder, label, n_accepted);
     if (rc) return rc;
     for (int r = 0; r < n; r++) hs[r]->p.temperature = ladder[label[r]];
+    return PMC_OK;
+}
+
+// ---- EnergyBias on the device (src/moves.jl:246-280) ---------------------------------------------------------------
+static int energy_bias(pmc_system *h, int32_t sp1, int32_t sp2, double theta1, double theta2, double u1, double u2,
+                       int64_t gi, int64_t gj, int64_t *i, int64_t *j, double *logq)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_energy_bias: null handle");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    if (sp1 < 1 || sp1 > h->S || sp2 < 1 || sp2 > h->S) return fail(h, PMC_ERR_BADARG, "pmc_energy_bias: species out of range");
+    if (!(u1 >= 0.0 && u1 < 1.0 && u2 >= 0.0 && u2 < 1.0)) return fail(h, PMC_ERR_BADARG, "pmc_energy_bias: uniforms must lie in [0, 1)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (!h->cells_built) {
+        rc = pmc_build_cells(h);
+        if (rc) return rc;
+    }
+    rc = ensure_species_list(h);
+    if (rc) return rc;
+    DevTmp buf;
+    HIPCHK(h, buf.alloc(((size_t)2 * h->N + 8) * sizeof(double)));
+    double *d_e = buf.as<double>(), *d_w = d_e + h->N, *d_out = d_w + h->N;
+    rc = ref_energy_launch(h, nullptr, h->N, d_e);        // [compute_energy_particle(system, i) for i], reference order
+    if (rc) return rc;
+    BiasArgs a;
+    memset(&a, 0, sizeof a);
+    a.e = d_e; a.sp_off = h->d_sp_off; a.sp_ids = h->d_sp_ids;
+    a.sp[0] = sp1 - 1; a.sp[1] = sp2 - 1;
+    a.theta[0] = theta1; a.theta[1] = theta2;
+    a.u[0] = u1; a.u[1] = u2;
+    a.given[0] = gi > 0 ? (int)gi - 1 : -1;
+    a.given[1] = gj > 0 ? (int)gj - 1 : -1;
+    a.w = d_w; a.out = d_out;
+    hipLaunchKernelGGL(k_energy_bias, dim3(1), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    double out[5];
+    HIPCHK(h, hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out[0] < 0.0 || out[1] < 0.0) return fail(h, PMC_ERR_BADARG, "pmc_energy_bias: a species of the pair has no particles");
+    if (i) *i = (int64_t)out[0] + 1;
+    if (j) *j = (int64_t)out[1] + 1;
+    if (logq) *logq = out[2];
+    return PMC_OK;
+}
+
+extern "C" int pmc_energy_bias_sample(pmc_system *h, int32_t sp1, int32_t sp2, double theta1, double theta2, double u1, double u2,
+                                      int64_t *i, int64_t *j, double *logq)
+{
+    if (!i || !j) return fail(h, PMC_ERR_BADARG, "pmc_energy_bias_sample: null argument");
+    return energy_bias(h, sp1, sp2, theta1, theta2, u1, u2, 0, 0, i, j, logq);
+}
+
+extern "C" int pmc_energy_bias_logq(pmc_system *h, int32_t sp1, int32_t sp2, double theta1, double theta2, int64_t i, int64_t j,
+                                    double *logq)
+{
+    if (!h || !logq || i < 1 || j < 1 || i > h->N || j > h->N) return fail(h, PMC_ERR_BADARG, "pmc_energy_bias_logq: bad argument");
+    return energy_bias(h, sp1, sp2, theta1, theta2, 0.0, 0.0, i, j, nullptr, nullptr, logq);
+}
+
+extern "C" int pmc_exp(double x, double *y)          // the deterministic exp the weights use (bit-parity tests)
+{
+    if (!y) return PMC_ERR_BADARG;
+    *y = det_exp(x);
     return PMC_OK;
 }
 

@@ -924,6 +924,76 @@ __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
 }
 
 // ------------------------------------------------------------------------------
+// EnergyBias (src/moves.jl:246-280): energy-weighted choice of a DiscreteSwap pair, on the device
+// ------------------------------------------------------------------------------
+
+// Base sum(::Vector{Float64}): pairwise with 1024-element leaves (base/reduce.jl), as pmc_hip.hip:pairwise_sum
+__device__ double dev_pairwise_sum(const double *v, long long lo, long long hi)
+{
+    if (hi - lo < 1024) {
+        double a = v[lo];
+        for (long long k = lo + 1; k <= hi; k++) a += v[k];
+        return a;
+    }
+    const long long mid = lo + ((hi - lo) >> 1);
+    return dev_pairwise_sum(v, lo, mid) + dev_pairwise_sum(v, mid + 1, hi);
+}
+
+struct BiasArgs {
+    const double *e;           // per-particle energies, particle-id order (reference-order sums)
+    const int *sp_off, *sp_ids;
+    int sp[2];                 // 0-based species of the pair
+    double theta[2], u[2];     // policy parameters; the caller's two uniforms in [0, 1)
+    int given[2];              // >= 0: particle ids of a given pair (log density only), -1: sample
+    double *w;                 // scratch, N doubles
+    double *out;               // [0] i, [1] j (0-based ids), [2] log q, [3] log-sum-exp 1, [4] log-sum-exp 2
+};
+
+// One workgroup.  For each of the two species: w_k = exp(theta e_k) over sp_ids[species] in list order (parallel),
+// S = sum(w) in Julia's pairwise order (one thread: the order is the result), p_k = w_k / S (parallel), and either the
+// inverse-CDF pick `cp <= u` of rand(rng, Categorical(p)) (src/moves.jl:274-277) or nothing (log density of a given pair).
+__global__ __launch_bounds__(256) void k_energy_bias(BiasArgs a)
+{
+    __shared__ double s_sum;
+    __shared__ int s_pick;
+    double numer = 0.0, lse[2] = {0.0, 0.0};
+    int pick[2] = {0, 0};
+    for (int side = 0; side < 2; side++) {
+        const int lo = a.sp_off[a.sp[side]], n = a.sp_off[a.sp[side] + 1] - lo;
+        double *w = a.w + lo;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) w[k] = det_exp(a.theta[side] * a.e[a.sp_ids[lo + k]]);
+        __syncthreads();
+        if (threadIdx.x == 0) s_sum = (n > 0) ? dev_pairwise_sum(w, 0, n - 1) : 0.0;
+        __syncthreads();
+        const double S = s_sum;
+        if (a.given[side] < 0) {
+            for (int k = threadIdx.x; k < n; k += blockDim.x) w[k] = w[k] / S;          // w1s .= w1s ./ sum(w1s)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int i = 0;
+                double cp = (n > 0) ? w[0] : 1.0;
+                while (cp <= a.u[side] && i < n - 1) { i++; cp += w[i]; }
+                s_pick = (n > 0) ? a.sp_ids[lo + i] : -1;
+            }
+            __syncthreads();
+            pick[side] = s_pick;
+        } else {
+            pick[side] = a.given[side];
+        }
+        lse[side] = det_log(S);
+        if (pick[side] >= 0) numer += a.theta[side] * a.e[pick[side]];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.out[0] = (double)pick[0];
+        a.out[1] = (double)pick[1];
+        a.out[2] = numer - lse[0] - lse[1];       // src/moves.jl:257-262
+        a.out[3] = lse[0];
+        a.out[4] = lse[1];
+    }
+}
+
+// ------------------------------------------------------------------------------
 // throughput engine
 // ------------------------------------------------------------------------------
 
@@ -1663,47 +1733,67 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
                                                         double xn, double yn, double zn, float fxo, float fyo, float fzo,
                                                         float fxn, float fyn, float fzn, PairCount &pcnt, bool &overflow)
 {
-    typedef float f2 __attribute__((ext_vector_type(2)));
     const int lane = wave_lane();
     // wave-uniform values the compiler cannot prove uniform (they come from loads and cross-lane moves): pin them to
     // SGPRs so that the trip guards, the ballot masks and the queue cursor stay on the scalar unit
     const int ncand = __builtin_amdgcn_readfirstlane(h.ncand);
     const float thr = a.rc2f;
-    // (old, new) pairs: one packed FP32 instruction tests a candidate against both positions
-    const f2 px = {fxo, fxn}, py = {fyo, fyn}, pz = {fzo, fzn};
     const unsigned lane8 = (unsigned)lane << 3;
     unsigned qn = 0;
     int nrun = ncand;
 #ifdef PMC_DEBUG_NOFILTER   // profiling builds only: price the slot prologue / reduction alone
     nrun = 0;
 #endif
+#ifdef PMC_DEBUG_TRIPS      // profiling builds only: price one filter trip
+    nrun = min(nrun, PMC_DEBUG_TRIPS * PMC_WAVE);
+#endif
     overflow = false;
     PMC_T(tf_0);
     // The particle itself (distance 0 to its old position) is NOT masked here: it passes the filter like any close
     // neighbour and queue_flush drops it by index -- one compare per dense trip instead of three operations per filter trip.
+    // (old, new) pairs in one packed FP32 instruction each: measured equal in time to twelve plain v_*_f32 (a trip
+    // holds the VALU for ~40 quad-cycles either way, rocprofv3 SQ_INSTS_VALU), with half the instructions to issue.
+    // Trips are processed TWO at a time in straight-line code: a trip is one dependent chain (subtract, multiply, two
+    // fused multiply-adds, compare, two lane counts, address, store), and with only 2-3 wavefronts per SIMD nothing
+    // else hides its stalls; two trips give the scheduler four independent chains to interleave.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 px = {fxo, fxn}, py = {fyo, fyn}, pz = {fzo, fzn};
+    auto trips2 = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        f2 r2[2];
 #pragma unroll
-    for (int j = 0; j < PMC_FTRIPS; j++) {
-        if (j * PMC_WAVE < nrun) {
-            const f2 cx = {f.x[j], f.x[j]}, cy = {f.y[j], f.y[j]};
+        for (int t = 0; t < 2; t++) {
+            const f2 cx = {f.x[J + t], f.x[J + t]}, cy = {f.y[J + t], f.y[J + t]};
             const f2 dx = cx - px, dy = cy - py;
-            f2 r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
+            r2[t] = __builtin_elementwise_fma(dy, dy, dx * dx);
             if (D == 3) {
-                const f2 cz = {f.z[j], f.z[j]};
+                const f2 cz = {f.z[J + t], f.z[J + t]};
                 const f2 dz = cz - pz;
-                r2 = __builtin_elementwise_fma(dz, dz, r2);
-            }
-            const bool io = r2.x <= thr, in = r2.y <= thr;
-            const unsigned long long mo = __builtin_amdgcn_ballot_w64(io), mn = __builtin_amdgcn_ballot_w64(in);
-            const unsigned kk = lane8 + (unsigned)(j * PMC_WAVE * 8);      // queue entry: (k << 3) | new-position flag
-            if (io) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, qn))] = (unsigned short)kk;
-            qn += (unsigned)__popcll(mo);
-            if (in) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(mn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mn, qn))] = (unsigned short)(kk | 1u);
-            qn += (unsigned)__popcll(mn);
-            if (j == 4 && qn > (unsigned)(PMC_QCAP - (PMC_FTRIPS - 5) * 2 * PMC_WAVE) && 5 * PMC_WAVE < ncand) {
-                overflow = true;      // the remaining trips might not fit (dense clusters only)
-                nrun = 0;
+                r2[t] = __builtin_elementwise_fma(dz, dz, r2[t]);
             }
         }
+        unsigned long long m[4];
+        const bool b0 = r2[0].x <= thr, b1 = r2[0].y <= thr, b2 = r2[1].x <= thr, b3 = r2[1].y <= thr;
+        m[0] = __builtin_amdgcn_ballot_w64(b0); m[1] = __builtin_amdgcn_ballot_w64(b1);
+        m[2] = __builtin_amdgcn_ballot_w64(b2); m[3] = __builtin_amdgcn_ballot_w64(b3);
+        // queue entry: (k << 3) | new-position flag; slots behind the last candidate hold NaN and never pass
+        const unsigned k0 = lane8 + (unsigned)(J * PMC_WAVE * 8), k1 = k0 + (unsigned)(PMC_WAVE * 8);
+        const unsigned q0 = qn, q1 = q0 + (unsigned)__popcll(m[0]), q2 = q1 + (unsigned)__popcll(m[1]), q3 = q2 + (unsigned)__popcll(m[2]);
+        if (b0) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[0], q0))] = (unsigned short)k0;
+        if (b1) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[1], q1))] = (unsigned short)(k0 | 1u);
+        if (b2) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[2] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[2], q2))] = (unsigned short)k1;
+        if (b3) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[3] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[3], q3))] = (unsigned short)(k1 | 1u);
+        qn = q3 + (unsigned)__popcll(m[3]);
+    };
+    static_assert(PMC_FTRIPS == 8 && PMC_QCAP >= 4 * 2 * PMC_WAVE, "the first four trips must fit the queue unchecked");
+    if (nrun > 0) trips2(std::integral_constant<int, 0>{});
+    if (nrun > 2 * PMC_WAVE) trips2(std::integral_constant<int, 2>{});
+    if (nrun > 4 * PMC_WAVE) {
+        // four trips cannot overflow the queue (512 <= PMC_QCAP); each further pair adds at most 256 entries
+        if (qn > (unsigned)(PMC_QCAP - 4 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 4>{});
+    }
+    if (nrun > 6 * PMC_WAVE && !overflow) {
+        if (qn > (unsigned)(PMC_QCAP - 4 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 6>{});
     }
     if (overflow) return 0.0;
     pcnt.tests += 2u * (unsigned)ncand;

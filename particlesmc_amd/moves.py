@@ -124,23 +124,29 @@ def _theta(parameters):
     return float(parameters[0]), float(parameters[1])
 
 
-def _energy_bias_tables(action, parameters, system):
-    """exp.(theta .* compute_energy_particle(system, sp_ids[species])) for both species (moves.jl:270-273);
-    the energies are the device's reference-order sums."""
-    from .system import compute_energy_particles
+def energy_bias_sample(system, species, parameters, u1, u2):
+    """pmc_energy_bias_sample: the two energy-weighted picks and log q(i, j) on the device (src/moves.jl:254-279);
+    only the pair and one double come back."""
     th1, th2 = _theta(parameters)
-    e = compute_energy_particles(system)
-    ids1, ids2 = system.species_ids(action.species[0]), system.species_ids(action.species[1])
-    return ids1, ids2, e, np.exp(th1 * e[ids1 - 1]), np.exp(th2 * e[ids2 - 1])
+    i, j, lq = C.c_int64(), C.c_int64(), C.c_double()
+    _lib.check(_lib.lib().pmc_energy_bias_sample(system._h, int(species[0]), int(species[1]), th1, th2, float(u1), float(u2),
+                                                 C.byref(i), C.byref(j), C.byref(lq)), system._h)
+    return i.value, j.value, lq.value
+
+
+def energy_bias_logq(system, species, parameters, i, j):
+    """pmc_energy_bias_logq: log_proposal_density(::DiscreteSwap, ::EnergyBias, ...) of the pair (i, j) in the current state."""
+    th1, th2 = _theta(parameters)
+    lq = C.c_double()
+    _lib.check(_lib.lib().pmc_energy_bias_logq(system._h, int(species[0]), int(species[1]), th1, th2, int(i), int(j),
+                                               C.byref(lq)), system._h)
+    return lq.value
 
 
 def log_proposal_density(action, policy, parameters, system):
     """src/moves.jl:110-112, 231-233, 254-263."""
     if isinstance(policy, EnergyBias):
-        th1, th2 = _theta(parameters)
-        ids1, ids2, e, w1, w2 = _energy_bias_tables(action, parameters, system)
-        numerator = th1 * e[action.i - 1] + th2 * e[action.j - 1]
-        return float(numerator - math.log(w1.sum()) - math.log(w2.sum()))
+        return energy_bias_logq(system, action.species, parameters, action.i, action.j)
     if isinstance(action, Displacement):
         sigma = parameters["sigma"] if isinstance(parameters, dict) else float(parameters)
         n2 = float(np.dot(action.delta[: system.d], action.delta[: system.d]))
@@ -217,13 +223,10 @@ class SequentialStream:
 def sample_action(action, policy, parameters, system, rng):
     """Arianna.sample_action! -- src/moves.jl:120-123, 238-241; rng is a SequentialStream."""
     if isinstance(policy, EnergyBias):
-        # rand(rng, Categorical(w / sum(w))) for both species (moves.jl:274-279): inverse-CDF picks from the
-        # step's two 32-bit words
-        ids1, ids2, _, w1, w2 = _energy_bias_tables(action, parameters, system)
+        # rand(rng, Categorical(w / sum(w))) for both species (moves.jl:274-279): inverse-CDF picks on the device from
+        # the step's two 32-bit words
         u1, u2 = rng.R[1] * (1.0 / 4294967296.0), rng.Q[0] * (1.0 / 4294967296.0)
-        k1 = min(int(np.searchsorted(np.cumsum(w1 / w1.sum()), u1, side="right")), len(ids1) - 1)
-        k2 = min(int(np.searchsorted(np.cumsum(w2 / w2.sum()), u2, side="right")), len(ids2) - 1)
-        action.i, action.j = int(ids1[k1]), int(ids2[k2])
+        action.i, action.j, _ = energy_bias_sample(system, action.species, parameters, u1, u2)
         return
     if isinstance(action, Displacement):
         sigma = parameters["sigma"] if isinstance(parameters, dict) else float(parameters)

@@ -11,5 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace --
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/write -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/prof/sq -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/prof/sq2 -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
+python3 bench.py --steps 100 --warmup 5 --equilibrate 2000 --no-cpu > gpurun_out/prof/bench_equilibrated.json 2> /dev/null
 python3 examples/throughput_table.py > gpurun_out/throughput_table.jsonl 2>&1
 ls gpurun_out/prof

@@ -42,7 +42,8 @@ for k, v in summary.items():
     if k.startswith("void k_cb_pass<3, 0, false") and "FETCH_SIZE" in v and "WRITE_SIZE" in v and "SQ_WAVES" in v:
         fetch_kib, write_kib = v["FETCH_SIZE"]["mean"], v["WRITE_SIZE"]["mean"]
         traffic = {
-            "kernel": k, "round": tag,
+            "kernel": k, "round": tag, "lattice": 100,
+            "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 1 --no-cpu`, builder's lease)",
             "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
             "k_cb_pass_hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
             "moves_per_launch": 1000000,
@@ -53,9 +54,10 @@ for k, v in summary.items():
         }
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
         print(traffic)
-bj = os.path.join(SRC, "bench_full.json")
-if os.path.exists(bj):
-    line = [l for l in open(bj) if l.startswith('{"metric"')]
-    if line:
-        json.dump(json.loads(line[0]), open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w"), indent=1)
+for src, dst in (("bench_full.json", f"{tag}_bench.json"), ("bench_equilibrated.json", f"{tag}_bench_equilibrated.json")):
+    bj = os.path.join(SRC, src)
+    if os.path.exists(bj):
+        line = [l for l in open(bj) if l.startswith('{"metric"')]
+        if line:
+            json.dump(json.loads(line[0]), open(os.path.join(ROOT, "profiles", dst), "w"), indent=1)
 print("wrote", tag)

@@ -300,35 +300,55 @@ def test_eight_million_particles(gpu):
 
 
 def test_energy_bias_policy(gpu):
-    """EnergyBias (src/moves.jl:246-280) on the per-move verbs: the proposal density uses the device's
-    reference-order per-particle energies, so it equals the same formula fed with the oracle's energies;
-    mc_step with it keeps the chain consistent (energy bookkeeping exact against a recomputation)."""
-    import math
+    """EnergyBias (src/moves.jl:246-280) on the device: the energy-weighted picks and the proposal density are computed
+    from the device-resident reference-order energies (pmc_energy_bias_sample / _logq) and equal the oracle's
+    restatement bit for bit -- weights (fixed-sequence exp), Base's pairwise sum, the inverse-CDF walk, the log;
+    mc_step with the policy keeps the chain consistent (energy bookkeeping against a recomputation)."""
     from oracle import oracle as O
+    from particlesmc_amd.moves import energy_bias_logq, energy_bias_sample
     pmc = gpu
     pos, sp, rho = binary_lattice(729, frac_b=0.3, rho=1.1, jitter=0.08, seed=5)
     g = pmc.System(pos, sp, rho, 0.7, pmc.KobAndersen(), seed=9)
     o = O.System(pos, sp, rho, 0.7, O.kob_andersen(), O.LINKEDLIST)
-    act = pmc.DiscreteSwap([1, 2], g)
-    pol, par = pmc.EnergyBias(), {"theta1": 0.3, "theta2": -0.2}
-    rng = pmc.SequentialStream(seed=9, chain=0, step=0)
-    pmc.sample_action(act, pol, par, g, rng)
-    e = o.energy_particles()
+    par = {"theta1": 0.3, "theta2": -0.2}
+    rng = np.random.default_rng(2)
+    for species in ((1, 2), (2, 1)):
+        for _ in range(40):
+            u1, u2 = float(rng.random()), float(rng.random())
+            got = energy_bias_sample(g, species, par, u1, u2)
+            assert got == o.energy_bias(species, (0.3, -0.2), (u1, u2))
+            # the density of that pair, and of an arbitrary other pair, as log_proposal_density sees them
+            assert energy_bias_logq(g, species, par, got[0], got[1]) == got[2]
     ids1, ids2 = o.species_ids(1), o.species_ids(2)
-    w1, w2 = np.exp(0.3 * e[ids1 - 1]), np.exp(-0.2 * e[ids2 - 1])
-    k1 = int(np.searchsorted(np.cumsum(w1 / w1.sum()), rng.R[1] / 2 ** 32, side="right"))
-    k2 = int(np.searchsorted(np.cumsum(w2 / w2.sum()), rng.Q[0] / 2 ** 32, side="right"))
-    assert (act.i, act.j) == (int(ids1[k1]), int(ids2[k2]))
-    want = 0.3 * e[act.i - 1] - 0.2 * e[act.j - 1] - math.log(w1.sum()) - math.log(w2.sum())
-    assert pmc.log_proposal_density(act, pol, par, g) == want
+    for i, j in ((int(ids1[3]), int(ids2[5])), (int(ids1[-1]), int(ids2[0]))):
+        assert energy_bias_logq(g, (1, 2), par, i, j) == o.energy_bias((1, 2), (0.3, -0.2), given=(i, j))[2]
+    # the extremes of the inverse-CDF walk: u = 0 picks the first id of each list, u -> 1 the last
+    assert energy_bias_sample(g, (1, 2), par, 0.0, 0.0)[:2] == (int(ids1[0]), int(ids2[0]))
+    assert energy_bias_sample(g, (1, 2), par, 1.0 - 2.0 ** -53, 1.0 - 2.0 ** -53)[:2] == (int(ids1[-1]), int(ids2[-1]))
+    with pytest.raises(pmc.PMCError):
+        energy_bias_sample(g, (1, 3), par, 0.1, 0.1)                              # no such species
+    # the policy inside the Arianna step contract, against the oracle driven with the same words
+    act = pmc.DiscreteSwap([1, 2], g)
+    pol = pmc.EnergyBias()
+    stream = pmc.SequentialStream(seed=9, chain=0, step=0)
     acc = 0
     for _ in range(30):
-        acc += bool(pmc.mc_step(g, act, pol, par, rng))
-        rng.advance()
-    assert 0 <= acc <= 30 and np.count_nonzero(g.species == 2) == np.count_nonzero(sp == 2)
-    running = g.energy[0]
-    g.build_neighbour_list()
-    assert abs(pmc.compute_energy_particles(g).sum() / 2 - running) <= 1e-9 * abs(running)
+        u1, u2 = stream.R[1] / 2.0 ** 32, stream.Q[0] / 2.0 ** 32
+        oi, oj, olq = o.energy_bias((1, 2), (0.3, -0.2), (u1, u2))
+        ok = bool(pmc.mc_step(g, act, pol, par, stream))
+        # replay on the oracle: forward density, swap, backward density of the inverted action, Metropolis-Hastings
+        assert (act.i, act.j) in ((oi, oj), (oj, oi))
+        e1, e2, de = o.swap_perform(oi, oj, 1, 2)
+        blq = o.energy_bias((1, 2), (0.3, -0.2), given=(oj, oi))[2]       # the inverted action: j now carries species 1
+        want = stream.log_uniform() < -(e2 - e1) / 0.7 + (blq - olq)
+        assert ok == want
+        if not want:
+            o.swap_revert(oj, oi, 1, 2, de)
+        acc += ok
+        stream.advance()
+        assert g.energy[0] == o.energy
+    assert 0 < acc <= 30 and np.count_nonzero(g.species == 2) == np.count_nonzero(sp == 2)
+    assert np.array_equal(g.species, o.species())
 
 
 def test_soft_spheres_odd_exponent(gpu):
