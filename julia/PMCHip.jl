@@ -178,22 +178,70 @@ set_temperature!(system, T) = check(ccall((:pmc_set_temperature, LIB), Cint, (Pt
 set_list_type!(L::HIPLinkedList, list_type::Integer, dr::Real=0.0) =
     check(ccall((:pmc_set_list_type, LIB), Cint, (Ptr{Cvoid}, Int32, Float64), L.handle, list_type, dr), L.handle)
 
-# ---- chains in flight concurrently (parallel = true): one HIP stream per handle ------------------------------------
+# ---- all the chains of a run (parallel = true) in shared launches: pmc_sweep_many ------------------------------------
+# Chains of one shape (same N, box, models) share every kernel launch; anything else runs as one stream per handle.
 
 function sweep_many!(systems, pool::Vector{CMove}, nsweeps::Integer; mode::Integer=1)
-    for s in systems
-        h = s.neighbour_list.handle
-        check(ccall((:pmc_sweep_begin, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{CMove}, Int32, Int64), h, mode, pool, length(pool), nsweeps), h)
-    end
+    hs = Ptr{Cvoid}[s.neighbour_list.handle for s in systems]
     stats = Vector{Stats}(undef, length(systems))
+    GC.@preserve hs stats pool begin
+        check(ccall((:pmc_sweep_many, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int32, Int32, Ptr{CMove}, Int32, Int64, Ptr{Stats}),
+                    hs, length(hs), mode, pool, length(pool), nsweeps, stats), hs[1])
+    end
     for (k, s) in enumerate(systems)
-        h = s.neighbour_list.handle
-        st = Ref{Stats}()
-        check(ccall((:pmc_sweep_end, LIB), Cint, (Ptr{Cvoid}, Ref{Stats}), h, st), h)
-        stats[k] = st[]
-        s.energy[1] = st[].energy
+        s.energy[1] = stats[k].energy
     end
     return stats
+end
+
+# ---- parallel tempering (the reference has none: README.md:33) -------------------------------------------------------
+# label[r] = index (0-based) of the temperature replica r holds; the library reads the handles' running energies,
+# decides, and sets every handle's temperature.  Replicas of one process (one GPU, or one handle per device):
+function replica_exchange!(systems, ladder::Vector{Float64}, seed::Integer, round::Integer, label::Vector{Int32})
+    hs = Ptr{Cvoid}[s.neighbour_list.handle for s in systems]
+    nacc = Ref{Int32}(0)
+    GC.@preserve hs ladder label begin
+        check(ccall((:pmc_replica_exchange, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, UInt64, UInt64, Ptr{Int32}, Ref{Int32}),
+                    hs, length(hs), ladder, seed, round, label, nacc), hs[1])
+    end
+    for (r, s) in enumerate(systems)
+        s.temperature = ladder[label[r] + 1]
+    end
+    return nacc[]
+end
+# One process per GPU: `comm` from pmc_rccl_comm_create (rank 0 calls pmc_rccl_unique_id and ships the 128 bytes, e.g. with
+# MPI.Bcast or a file); the round is ONE ncclAllGather of a Float64 per rank over RCCL / xGMI.
+function replica_exchange_rccl!(system, comm::Ptr{Cvoid}, rank::Integer, world::Integer, ladder::Vector{Float64}, seed::Integer,
+                                round::Integer, label::Vector{Int32})
+    h = system.neighbour_list.handle
+    nacc = Ref{Int32}(0)
+    GC.@preserve ladder label begin
+        check(ccall((:pmc_replica_exchange_rccl, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, UInt64, UInt64, Ptr{Int32}, Ref{Int32}),
+                    h, comm, rank, world, ladder, seed, round, label, nacc), h)
+    end
+    system.temperature = ladder[label[rank + 1] + 1]
+    return nacc[]
+end
+
+# ---- EnergyBias on the device (src/moves.jl:246-280): nothing of size N crosses the bus ------------------------------
+function Arianna.sample_action!(action::ParticlesMC.DiscreteSwap, ::ParticlesMC.EnergyBias, parameters,
+                                system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, rng) where {D,V}
+    i, j, lq = Ref{Int64}(0), Ref{Int64}(0), Ref(0.0)
+    h = system.neighbour_list.handle
+    check(ccall((:pmc_energy_bias_sample, LIB), Cint,
+                (Ptr{Cvoid}, Int32, Int32, Float64, Float64, Float64, Float64, Ref{Int64}, Ref{Int64}, Ref{Float64}),
+                h, action.species[1], action.species[2], parameters.θ₁, parameters.θ₂, rand(rng), rand(rng), i, j, lq), h)
+    action.i, action.j = i[], j[]
+    return nothing
+end
+function Arianna.log_proposal_density(action::ParticlesMC.DiscreteSwap, ::ParticlesMC.EnergyBias, parameters,
+                                      system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}) where {D,V}
+    lq = Ref(0.0)
+    h = system.neighbour_list.handle
+    check(ccall((:pmc_energy_bias_logq, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Float64, Float64, Int64, Int64, Ref{Float64}),
+                h, action.species[1], action.species[2], parameters.θ₁, parameters.θ₂, action.i, action.j, lq), h)
+    return lq[]
 end
 
 # ---- the device's sequential random stream as an AbstractRNG (the Julia twin of particlesmc_amd.SequentialStream) ----

@@ -103,6 +103,7 @@ SYMBOLS = {
     "pmc_sweep": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64, C.POINTER(Stats)]),
     "pmc_sweep_begin": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64]),
     "pmc_sweep_end": (C.c_int, [_h, C.POINTER(Stats)]),
+    "pmc_sweep_many": (C.c_int, [C.POINTER(_h), C.c_int32, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64, C.POINTER(Stats)]),
     "pmc_pt_decide": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int32, _dp, _dp, _ip, _ip]),
     "pmc_replica_exchange": (C.c_int, [C.POINTER(_h), C.c_int32, _dp, C.c_uint64, C.c_uint64, _ip, _ip]),
     "pmc_replica_exchange_rccl": (C.c_int, [_h, C.c_void_p, C.c_int32, C.c_int32, _dp, C.c_uint64, C.c_uint64, _ip, _ip]),

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -88,6 +89,7 @@ struct pmc_system {
     bool mc_binned = false;      // CSR + SoA consistent with d_pos
     bool count_is_zero = false;  // d_count[0..ncell_mc] is all zero (left so by the last throughput scan)
     unsigned long long *d_stats = nullptr;
+    CbArgs *d_cbtab = nullptr;   // launch arguments of the sweeps of one chunk (k_cb_pass reads them from device memory)
     double *d_result = nullptr;
     int max_count = 0;
 };
@@ -488,7 +490,7 @@ extern "C" int pmc_destroy(pmc_system *h)
     void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
-                    h->d_sz, h->d_ssp, h->d_stats, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m,
+                    h->d_sz, h->d_ssp, h->d_stats, h->d_cbtab, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m,
                     h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
@@ -1205,13 +1207,15 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
     return b;
 }
 
+#define PMC_ARGS_CHUNK 256     // sweeps whose launch arguments are uploaded together
 // k_cb_pass additionally carries the team size NW (wavefronts per cell)
-#define DISPATCH_CB_ONE(DD, KK, NWV, h, grid, lds, args)                                                        \
+// The launch arguments (CbArgs) are read from device memory: `args` below is a device pointer to nrep_ of them.
+#define DISPATCH_CB_ONE(DD, KK, NWV, h, grid, lds, args)   /* uses pool_ (MovePool) and nrep_ (int) of the caller's scope */                                                        \
     if (!done_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV) {                                        \
-        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
-        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
-        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
-        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args); \
+        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
         done_ = true;                                                                                           \
     }
 #define DISPATCH_CB_KIND(DD, KK, h, grid, lds, args)                                                            \
@@ -1226,7 +1230,7 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
 #define DISPATCH_CB(h, grid, lds, args)                                                                         \
     do {                                                                                                        \
         bool done_ = false;                                                                                     \
-        const bool one_ = (args).pool.npool == 1 && (args).pool.kind[0] == 0;                                   \
+        const bool one_ = (pool_).npool == 1 && (pool_).kind[0] == 0;                                           \
         DISPATCH_CB_KIND(3, PMC_DEV_KIND, h, grid, lds, args)                                                   \
         (void)done_;                                                                                            \
     } while (0)
@@ -1234,7 +1238,7 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
 #define DISPATCH_CB(h, grid, lds, args)                                                                         \
     do {                                                                                                        \
         bool done_ = false;                                                                                     \
-        const bool one_ = (args).pool.npool == 1 && (args).pool.kind[0] == 0;                                   \
+        const bool one_ = (pool_).npool == 1 && (pool_).kind[0] == 0;                                           \
         DISPATCH_CB_KIND(3, 0, h, grid, lds, args) DISPATCH_CB_KIND(3, 1, h, grid, lds, args)                    \
         DISPATCH_CB_KIND(3, 2, h, grid, lds, args) DISPATCH_CB_KIND(3, 3, h, grid, lds, args)                    \
         DISPATCH_CB_KIND(3, 4, h, grid, lds, args) DISPATCH_CB_KIND(2, 0, h, grid, lds, args)                    \
@@ -1482,90 +1486,112 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
     const size_t lds = cb_lds_bytes(h, h->team >= 2 ? h->team : 0);   // teams keep slot records and one survivor queue per wavefront in LDS
     int64_t launches = 0, timed_sweeps = 0;
+    // fused launches stream the cells of every colour in the same spatial order, so that the cells a
+    // workgroup waits for were ticketed long before it (a pipeline with one tail per sweep); separate
+    // colour launches sort each colour longest-first to shorten their eight tails
+    const bool fused = h->use_fused;
+    const bool lpt = h->use_order && (!fused || h->fused_lpt == 1);
+    const bool fuse_slots = h->N < 500000;   // small systems: slots generated inside pass C of the binning (one launch fewer)
+    const int per_sweep = fused ? 1 : ncol;  // launches, and CbArgs entries, per sweep
+    const MovePool &pool_ = mp;
+    const int nrep_ = 1;
+    // The launch arguments of the sweep kernel live in device memory (k_cb_pass): all the sweeps of a chunk are prepared
+    // here and uploaded at once.
+    const int64_t chunk = PMC_ARGS_CHUNK;
+    if (!h->d_cbtab) HIPCHK(h, hipMalloc(&h->d_cbtab, (size_t)PMC_ARGS_CHUNK * per_sweep * sizeof(CbArgs)));   // use_fused is fixed per handle
+    std::vector<CbArgs> tabh;
+    std::vector<std::array<double, 3>> shifts;
+    const size_t Ns = (size_t)h->N;
+    const SlotOut slots{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     h->cb_started = nsweeps > 0;
-    for (int64_t sw = 0; sw < nsweeps; sw++) {
-        const uint64_t g = h->sweep_ctr + (uint64_t)sw;
-        const uint32_t s_lo = (uint32_t)g, s_hi = (uint32_t)(g >> 32) & 0xffffffu;
-        uint32_t W[4];
-        philox4x32(0, 0, s_lo, s_hi | ((uint32_t)TAG_SHIFT << 24), h->key[0], h->key[1], W);
-        double shift[3] = {0, 0, 0};
-        for (int q = 0; q < h->D; q++) shift[q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
-        SlotGen sg;
-        memset(&sg, 0, sizeof sg);
-        {
-            const size_t Ns = (size_t)h->N;
+    for (int64_t s0 = 0; s0 < nsweeps; s0 += chunk) {
+        const int64_t ns = std::min<int64_t>(chunk, nsweeps - s0);
+        tabh.assign((size_t)(ns * per_sweep), CbArgs{});
+        shifts.assign((size_t)ns, std::array<double, 3>{0.0, 0.0, 0.0});
+        bool reset_flags = false;
+        for (int64_t k = 0; k < ns; k++) {
+            const uint64_t g = h->sweep_ctr + (uint64_t)(s0 + k);
+            const uint32_t s_lo = (uint32_t)g, s_hi = (uint32_t)(g >> 32) & 0xffffffu;
+            uint32_t W[4];
+            philox4x32(0, 0, s_lo, s_hi | ((uint32_t)TAG_SHIFT << 24), h->key[0], h->key[1], W);
+            for (int q = 0; q < h->D; q++) shifts[(size_t)k][(size_t)q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
+            for (int q = 0; q < 3; q++) h->grid.shift[q] = shifts[(size_t)k][(size_t)q];
+            CbArgs a = cb_args(h);
+            a.order = lpt ? h->d_order : nullptr;
+            a.slot_tlnu = slots.tlnu; a.slot_dx = slots.dx; a.slot_dy = slots.dy; a.slot_dz = slots.dz;
+            a.slot_w1 = slots.w1; a.slot_w2 = slots.w2; a.slot_m = slots.m;
+            a.s_lo = s_lo; a.s_hi = s_hi;
+            a.pool = mp;
+            a.all_cells = 0;
+            a.nactive = nactive;
+            if (fused) {
+                // one launch for all colours; cells wait on the completion flags of their lower-colour neighbours
+                if (h->epoch == 0xffffffffu) {       // (once in 4e9 sweeps) the flags start over
+                    reset_flags = true;
+                    h->epoch = 0;
+                }
+                a.fused = 1;
+                a.epoch = ++h->epoch;
+                a.done = h->d_done;
+                a.ticket = h->d_ticket;
+                a.ticket_base = h->ticket_next;
+                a.colour = 0;
+                h->ticket_next += (unsigned long long)(ncol * nactive);
+                tabh[(size_t)k] = a;
+            } else {
+                for (int col = 0; col < ncol; col++) {
+                    a.colour = col;
+                    tabh[(size_t)(k * ncol + col)] = a;
+                }
+            }
+        }
+        if (s0 > 0 || reset_flags) HIPCHK(h, hipStreamSynchronize(h->stream));   // the previous chunk's entries are still being read
+        if (reset_flags) HIPCHK(h, hipMemsetAsync(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int), h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_cbtab, tabh.data(), tabh.size() * sizeof(CbArgs), hipMemcpyHostToDevice, h->stream));
+        for (int64_t k = 0; k < ns; k++) {
+            const int64_t sw = s0 + k;
+            const CbArgs &a0 = tabh[(size_t)(k * per_sweep)];
+            SlotGen sg;
+            memset(&sg, 0, sizeof sg);
             sg.enabled = 1;
-            sg.s_lo = s_lo; sg.s_hi = s_hi; sg.key0 = h->key[0]; sg.key1 = h->key[1];
+            sg.s_lo = a0.s_lo; sg.s_hi = a0.s_hi; sg.key0 = h->key[0]; sg.key1 = h->key[1];
             sg.temperature = h->p.temperature;
             sg.pool = mp;
-            sg.out = SlotOut{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
-        }
-        // small systems: generated inside pass C of the binning (one launch fewer); large ones: own launch (coalesced stores)
-        const bool fuse_slots = h->N < 500000;
-        rc = mc_bin(h, shift, fuse_slots ? &sg : nullptr);
-        if (rc) return rc;
-        if (!fuse_slots) {
-            const int nbs = nblk(h->N, 256);
-            if (h->D == 3) hipLaunchKernelGGL(k_mc_slots<3>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
-            else hipLaunchKernelGGL(k_mc_slots<2>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
-        }
-        // fused launches stream the cells of every colour in the same spatial order, so that the cells a
-        // workgroup waits for were ticketed long before it (a pipeline with one tail per sweep); separate
-        // colour launches sort each colour longest-first to shorten their eight tails
-        const bool fused = h->use_fused;
-        const bool lpt = h->use_order && (!fused || h->fused_lpt == 1);
-        if (lpt) {
-            rc = mc_order(h, nactive);
+            sg.out = slots;
+            rc = mc_bin(h, shifts[(size_t)k].data(), fuse_slots ? &sg : nullptr);
             if (rc) return rc;
-        }
-        CbArgs a = cb_args(h);
-        a.order = lpt ? h->d_order : nullptr;
-        a.slot_tlnu = sg.out.tlnu; a.slot_dx = sg.out.dx; a.slot_dy = sg.out.dy; a.slot_dz = sg.out.dz;
-        a.slot_w1 = sg.out.w1; a.slot_w2 = sg.out.w2; a.slot_m = sg.out.m;
-        a.s_lo = s_lo; a.s_hi = s_hi;
-        a.pool = mp;
-        a.all_cells = 0;
-        a.nactive = nactive;
-        // HIP events bracket the colour passes of every sweep on this stream; they are
-        // read back after the final synchronize so the host never stalls the queue
-        const bool timed = out && sw < 4096;
-        if (timed) {
-            while ((int64_t)h->pass_ev.size() < 2 * (sw + 1)) {
-                hipEvent_t e;
-                HIPCHK(h, hipEventCreate(&e));
-                h->pass_ev.push_back(e);
+            if (!fuse_slots) {      // large systems: own launch (coalesced stores)
+                const int nbs = nblk(h->N, 256);
+                if (h->D == 3) hipLaunchKernelGGL(k_mc_slots<3>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
+                else hipLaunchKernelGGL(k_mc_slots<2>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
             }
-            HIPCHK(h, hipEventRecord(h->pass_ev[2 * sw], h->stream));
-        }
-        if (fused) {
-            // one launch for all colours; cells wait on the completion flags of their lower-colour neighbours
-            if (h->epoch == 0xffffffffu) {
-                HIPCHK(h, hipMemsetAsync(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int), h->stream));
-                h->epoch = 0;
+            if (lpt) {
+                rc = mc_order(h, nactive);
+                if (rc) return rc;
             }
-            a.fused = 1;
-            a.epoch = ++h->epoch;
-            a.done = h->d_done;
-            a.ticket = h->d_ticket;
-            a.ticket_base = h->ticket_next;
-            a.colour = 0;
-            const int grid = ncol * nactive;
-            h->ticket_next += (unsigned long long)grid;
-            DISPATCH_CB(h, grid, lds, a);
-            launches++;
-        } else {
-            for (int col = 0; col < ncol; col++) {
-                a.colour = col;
-                DISPATCH_CB(h, nactive, lds, a);
+            // HIP events bracket the colour passes of every sweep on this stream; they are
+            // read back after the final synchronize so the host never stalls the queue
+            const bool timed = out && sw < 4096;
+            if (timed) {
+                while ((int64_t)h->pass_ev.size() < 2 * (sw + 1)) {
+                    hipEvent_t e;
+                    HIPCHK(h, hipEventCreate(&e));
+                    h->pass_ev.push_back(e);
+                }
+                HIPCHK(h, hipEventRecord(h->pass_ev[2 * sw], h->stream));
+            }
+            for (int l = 0; l < per_sweep; l++) {
+                const CbArgs *args = h->d_cbtab + (k * per_sweep + l);
+                DISPATCH_CB(h, fused ? ncol * nactive : nactive, lds, args);
                 launches++;
             }
+            if (timed) {
+                HIPCHK(h, hipEventRecord(h->pass_ev[2 * sw + 1], h->stream));
+                timed_sweeps = sw + 1;
+            }
+            HIPCHK(h, hipGetLastError());
         }
-        if (timed) {
-            HIPCHK(h, hipEventRecord(h->pass_ev[2 * sw + 1], h->stream));
-            timed_sweeps = sw + 1;
-        }
-        HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, h->stream, h->d_stats);   // counter copies -> copy 0
@@ -1692,6 +1718,201 @@ static int validate_pool(pmc_system *h, const pmc_move *pool, int32_t npool, int
         if (!(pool[m].probability >= 0.0)) return fail(h, PMC_ERR_BADARG, "pmc_sweep: negative probability");
     }
     return PMC_OK;
+}
+
+// ---- many replicas of one shape per launch (chains with parallel = true, tempering ladders) ---------------------------
+// src/ParticlesMC.jl:164,246: the chains of a run are independent Systems of the same shape.  One stream per handle
+// (pmc_sweep_begin / _end) overlaps them, but a small system is a chain of ~6 short dependent launches per sweep and the
+// launches of eight streams do not interleave well (8 x N = 4096: 5.6e7 moves/s against 1.8e7 for one chain).  Here the
+// n handles share every launch: the binning kernels take the replica from blockIdx.y, the fused sweep kernel from the ticket.
+static bool many_compatible(pmc_system **hs, int n)
+{
+    const pmc_system *m = hs[0];
+    if (!m->mc_ok || !m->use_fused || m->N >= 500000 || m->ncell_mc > PMC_SCAN_SMALL_MAX) return false;
+    for (int r = 1; r < n; r++) {
+        const pmc_system *h = hs[r];
+        if (h == m) return false;
+        for (int q = 0; q < r; q++) if (hs[q] == h) return false;
+        if (h->p.device != m->p.device || h->D != m->D || h->N != m->N || h->S != m->S || h->kind != m->kind || h->team != m->team ||
+            h->use_filter != m->use_filter || !h->mc_ok || !h->use_fused || h->ncell_mc != m->ncell_mc)
+            return false;
+        for (int a = 0; a < 3; a++)
+            if (h->grid.n[a] != m->grid.n[a] || h->grid.w[a] != m->grid.w[a] || h->p.box[a] != m->p.box[a]) return false;
+        if (h->models.size() != m->models.size() || memcmp(h->models.data(), m->models.data(), m->models.size() * sizeof(pmc_pair_model)) != 0)
+            return false;
+    }
+    return true;
+}
+
+extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pmc_move *pool, int32_t npool, int64_t nsweeps,
+                              pmc_stats *out)
+{
+    if (!hs || n < 1) return fail(nullptr, PMC_ERR_BADARG, "pmc_sweep_many: bad argument");
+    for (int r = 0; r < n; r++) {
+        if (!hs[r]) return fail(nullptr, PMC_ERR_BADARG, "pmc_sweep_many: null handle");
+        if (hs[r]->pending) return fail(hs[r], PMC_ERR_STATE, "pmc_sweep_many: a sweep is in flight on one of the handles (pmc_sweep_end first)");
+        if (int rc = validate_pool(hs[r], pool, npool, nsweeps)) return rc;
+    }
+    if (out) memset(out, 0, (size_t)n * sizeof *out);
+    if (mode != PMC_CHECKERBOARD || n == 1 || nsweeps == 0 || !many_compatible(hs, n)) {
+        // different shapes, large systems (they fill the chip on their own) or the reference-order engine: one stream per handle
+        int first = PMC_OK, begun = 0;
+        for (; begun < n; begun++) {
+            first = pmc_sweep_begin(hs[begun], mode, pool, npool, nsweeps);
+            if (first) break;
+        }
+        for (int r = 0; r < begun; r++) {
+            const int rc = pmc_sweep_end(hs[r], out ? &out[r] : nullptr);
+            if (rc && !first) first = rc;
+        }
+        return first;
+    }
+    pmc_system *m = hs[0];
+    int rc = set_device(m);
+    if (rc) return rc;
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        if (!h->e_fix_valid) {
+            rc = pmc_total_energy(h, nullptr, nullptr);
+            if (rc) return rc;
+        }
+        for (int k = 0; k < npool; k++)
+            if (pool[k].kind == PMC_MOVE_SWAP && h->S < 2) return fail(h, PMC_ERR_BADARG, "DiscreteSwap needs at least two species");
+        if (h->S > 1) h->species_list_stale = true;
+        if (h->epoch > 0xffffffffu - (unsigned int)std::min<int64_t>(nsweeps, 0x7fffffff) - 2u) {
+            HIPCHK(h, hipMemsetAsync(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int), m->stream));
+            h->epoch = 0;
+        }
+        HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), m->stream));
+        if (!h->count_is_zero) HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)h->ncell_mc + 1) * sizeof(int), m->stream));
+        h->count_is_zero = true;
+    }
+    const MovePool mp = make_pool(pool, npool);
+    const int ncol = 1 << m->D, N = m->N;
+    int nactive = 1;
+    for (int q = 0; q < m->D; q++) nactive *= m->grid.n[q] / 2;
+    const size_t lds = cb_lds_bytes(m, m->team >= 2 ? m->team : 0);
+    const int nb = nblk(N, 256);
+    // replica table (once) and per-sweep table (all sweeps of the call, in chunks)
+    std::vector<ManyRep> reps((size_t)n);
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        const size_t Ns = (size_t)h->N;
+        ManyRep &q = reps[(size_t)r];
+        memset(&q, 0, sizeof q);
+        q.pos_ro = h->d_pos; q.pos = h->d_pos; q.species = h->d_species;
+        q.cell_of = h->d_cell_of; q.count = h->d_count; q.arrival = h->d_arrival; q.start = h->d_start; q.tmp_ids = h->d_tmp_ids; q.ids = h->d_ids;
+        q.sx = h->d_sx; q.sy = h->d_sy; q.sz = h->d_sz; q.ssp = h->d_ssp;
+        q.slots = SlotOut{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
+        q.key0 = h->key[0]; q.key1 = h->key[1];
+        q.temperature = h->p.temperature;
+        q.stats = h->d_stats; q.done = h->d_done;
+    }
+    const int64_t chunk = PMC_ARGS_CHUNK;
+    const int64_t cmax = std::min<int64_t>(chunk, nsweeps);
+    DevTmp d_reps, d_steps, d_args;
+    HIPCHK(m, d_reps.alloc(reps.size() * sizeof(ManyRep)));
+    HIPCHK(m, d_steps.alloc((size_t)cmax * n * sizeof(ManyStep)));
+    HIPCHK(m, d_args.alloc((size_t)cmax * n * sizeof(CbArgs)));
+    HIPCHK(m, hipMemcpyAsync(d_reps.p, reps.data(), reps.size() * sizeof(ManyRep), hipMemcpyHostToDevice, m->stream));
+    std::vector<ManyStep> steps;
+    std::vector<CbArgs> argsh;
+    const MovePool &pool_ = mp;
+    const int nrep_ = n;
+    const int grid = ncol * n * nactive;
+    HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
+    for (int64_t s0 = 0; s0 < nsweeps; s0 += chunk) {
+        const int64_t ns = std::min<int64_t>(chunk, nsweeps - s0);
+        steps.assign((size_t)(ns * n), ManyStep{});
+        argsh.assign((size_t)(ns * n), CbArgs{});
+        for (int64_t sw = 0; sw < ns; sw++) {
+            for (int r = 0; r < n; r++) {
+                pmc_system *h = hs[r];
+                const uint64_t g = h->sweep_ctr + (uint64_t)(s0 + sw);
+                ManyStep &st = steps[(size_t)(sw * n + r)];
+                st.s_lo = (uint32_t)g;
+                st.s_hi = (uint32_t)(g >> 32) & 0xffffffu;
+                uint32_t W[4];
+                philox4x32(0, 0, st.s_lo, st.s_hi | ((uint32_t)TAG_SHIFT << 24), h->key[0], h->key[1], W);
+                for (int q = 0; q < h->D; q++) st.shift[q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
+                st.epoch = h->epoch + (unsigned int)(s0 + sw) + 1u;
+                // the sweep kernel's arguments for this replica and sweep (its own arrays; the launch's shared ticket)
+                for (int q = 0; q < 3; q++) h->grid.shift[q] = st.shift[q];
+                CbArgs a = cb_args(h);
+                const size_t Ns = (size_t)h->N;
+                a.order = nullptr;
+                a.slot_tlnu = h->d_slot_f; a.slot_dx = h->d_slot_f + Ns; a.slot_dy = h->d_slot_f + 2 * Ns; a.slot_dz = h->d_slot_f + 3 * Ns;
+                a.slot_w1 = h->d_slot_w; a.slot_w2 = h->d_slot_w + Ns; a.slot_m = h->d_slot_m;
+                a.s_lo = st.s_lo; a.s_hi = st.s_hi;
+                a.pool = mp;
+                a.all_cells = 0;
+                a.nactive = nactive;
+                a.fused = 1;
+                a.epoch = st.epoch;
+                a.done = h->d_done;
+                a.ticket = m->d_ticket;
+                a.ticket_base = m->ticket_next + (unsigned long long)sw * (unsigned long long)grid;
+                a.colour = 0;
+                argsh[(size_t)(sw * n + r)] = a;
+            }
+        }
+        if (s0 > 0) HIPCHK(m, hipStreamSynchronize(m->stream));      // the previous chunk's tables are still being read
+        HIPCHK(m, hipMemcpyAsync(d_steps.p, steps.data(), steps.size() * sizeof(ManyStep), hipMemcpyHostToDevice, m->stream));
+        HIPCHK(m, hipMemcpyAsync(d_args.p, argsh.data(), argsh.size() * sizeof(CbArgs), hipMemcpyHostToDevice, m->stream));
+        for (int64_t sw = 0; sw < ns; sw++) {
+            const ManyRep *dr = d_reps.as<ManyRep>();
+            const ManyStep *ds = d_steps.as<ManyStep>() + sw * n;
+            if (m->D == 3) hipLaunchKernelGGL(k_many_bin_a<3>, dim3(nb, n), dim3(256), 0, m->stream, N, m->grid, dr, ds);
+            else hipLaunchKernelGGL(k_many_bin_a<2>, dim3(nb, n), dim3(256), 0, m->stream, N, m->grid, dr, ds);
+            hipLaunchKernelGGL(k_many_scan, dim3(n), dim3(1024), 0, m->stream, m->ncell_mc, dr);
+            hipLaunchKernelGGL(k_many_bin_b, dim3(nb, n), dim3(256), 0, m->stream, N, dr);
+            if (m->D == 3) hipLaunchKernelGGL(k_many_bin_c<3>, dim3(nb, n), dim3(256), 0, m->stream, N, mp, dr, ds);
+            else hipLaunchKernelGGL(k_many_bin_c<2>, dim3(nb, n), dim3(256), 0, m->stream, N, mp, dr, ds);
+            const CbArgs *args = d_args.as<CbArgs>() + sw * n;
+            DISPATCH_CB(m, grid, lds, args);
+            HIPCHK(m, hipGetLastError());
+        }
+        m->ticket_next += (unsigned long long)ns * (unsigned long long)grid;
+    }
+    HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
+    for (int r = 0; r < n; r++) {
+        hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, m->stream, hs[r]->d_stats);
+        HIPCHK(m, hipMemcpyAsync(hs[r]->h_stats, hs[r]->d_stats, PMC_NSTATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+    }
+    HIPCHK(m, hipGetLastError());
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, m->ev[0], m->ev[1]);
+    int first = PMC_OK;
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        const unsigned long long *st = h->h_stats;
+        h->sweep_ctr += (uint64_t)nsweeps;
+        h->epoch += (unsigned int)nsweeps;
+        h->cells_built = false;
+        h->mc_binned = true;
+        const int rcf = check_kernel_flags(h, st);
+        if (rcf) {
+            cb_invalidate(h);
+            if (!first) first = rcf;
+            continue;
+        }
+        h->e_fix += (long long)st[16];
+        h->energy = (double)h->e_fix / PMC_FIX;
+        if (out) {
+            pmc_stats &o = out[r];
+            for (int k = 0; k < PMC_MAX_MOVES; k++) { o.attempted[k] = (int64_t)st[k]; o.accepted[k] = (int64_t)st[8 + k]; }
+            o.kernel_ms = ms;
+            o.sweep_kernel_ms = 0.0;
+            o.sweep_kernel_launches = nsweeps;
+            o.energy = h->energy;
+            o.energy_fix = h->e_fix;
+            o.pair_tests = (int64_t)st[25];
+            o.pairs_in_range = (int64_t)st[26];
+            o.null_moves = (int64_t)st[27];
+        }
+    }
+    return first;
 }
 
 extern "C" int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool, int64_t nsweeps,

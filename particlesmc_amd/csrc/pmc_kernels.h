@@ -71,8 +71,8 @@ __device__ __forceinline__ double mc_coord(double x, double shift, double w)
 
 // throughput-grid binning, pass A: cell index + arrival ticket inside the cell
 template <int D>
-__global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of,
-                           int *__restrict__ count, int *__restrict__ arrival)
+__device__ __forceinline__ void mc_bin_a_body(const double *__restrict__ pos, int N, const GridGeom &g, int *__restrict__ cell_of,
+                                              int *__restrict__ count, int *__restrict__ arrival)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -102,6 +102,13 @@ __global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, in
     if (head) base = atomicAdd(&count[c], run_end - lane + 1);
     base = __shfl(base, my_head, PMC_WAVE);
     arrival[i] = base + (lane - my_head);
+}
+
+template <int D>
+__global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of,
+                           int *__restrict__ count, int *__restrict__ arrival)
+{
+    mc_bin_a_body<D>(pos, N, g, cell_of, count, arrival);
 }
 
 // pass B: place ids by ticket (order inside a cell still depends on atomic arrival)
@@ -137,10 +144,11 @@ template <int D>
 __device__ __forceinline__ void generate_slot(const SlotGen &g, int lin, int t, int k);
 
 template <int D>
-__global__ void k_mc_bin_c(const double *__restrict__ pos, const int *__restrict__ species,
-                           const int *__restrict__ cell_of, int N, const int *__restrict__ start,
-                           const int *__restrict__ tmp_ids, int *__restrict__ ids, double *__restrict__ sx,
-                           double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp, SlotGen gen)
+__device__ __forceinline__ void mc_bin_c_body(const double *__restrict__ pos, const int *__restrict__ species,
+                                              const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+                                              const int *__restrict__ tmp_ids, int *__restrict__ ids, double *__restrict__ sx,
+                                              double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp,
+                                              const SlotGen &gen)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -155,6 +163,97 @@ __global__ void k_mc_bin_c(const double *__restrict__ pos, const int *__restrict
     if (D == 3) sz[dst] = pos[(size_t)i * D + 2];
     ssp[dst] = (unsigned char)species[i];
     if (gen.enabled) generate_slot<D>(gen, c, r, dst);
+}
+
+template <int D>
+__global__ void k_mc_bin_c(const double *__restrict__ pos, const int *__restrict__ species,
+                           const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+                           const int *__restrict__ tmp_ids, int *__restrict__ ids, double *__restrict__ sx,
+                           double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp, SlotGen gen)
+{
+    mc_bin_c_body<D>(pos, species, cell_of, N, start, tmp_ids, ids, sx, sy, sz, ssp, gen);
+}
+
+// ------------------------------------------------------------------------------
+// Many replicas in ONE launch (pmc_sweep_many): chains of a `parallel = true` run (src/ParticlesMC.jl:164,246) and the
+// replicas of a tempering ladder have the same shape (N, box, grid, models, pool) and differ in their arrays, random-stream
+// key, temperature and -- per sweep -- grid shift and sweep index.  The shape travels by value, the per-replica arrays in a
+// device table indexed by blockIdx.y (binning) or by the ticket (sweep kernel), the per-sweep values in a second table
+// that is uploaded once per call for all its sweeps.
+// ------------------------------------------------------------------------------
+struct ManyRep {
+    const double *pos_ro;      // binning reads
+    double *pos;               // sweep kernel writes back
+    int *species;
+    int *cell_of, *count, *arrival, *start, *tmp_ids, *ids;
+    double *sx, *sy, *sz;
+    unsigned char *ssp;
+    SlotOut slots;
+    uint32_t key0, key1;
+    double temperature;
+    unsigned long long *stats;
+    unsigned int *done;
+};
+struct ManyStep {
+    double shift[3];
+    uint32_t s_lo, s_hi;
+    unsigned int epoch;
+    unsigned int pad;
+};
+
+template <int D>
+__global__ void k_many_bin_a(int N, GridGeom g, const ManyRep *__restrict__ reps, const ManyStep *__restrict__ steps)
+{
+    const ManyRep &r = reps[blockIdx.y];
+    const ManyStep &st = steps[blockIdx.y];
+#pragma unroll
+    for (int q = 0; q < 3; q++) g.shift[q] = st.shift[q];
+    mc_bin_a_body<D>(r.pos_ro, N, g, r.cell_of, r.count, r.arrival);
+}
+
+// exclusive scan of every replica's cell counts, one block per replica (grids of <= PMC_SCAN_SMALL_MAX cells)
+__device__ __forceinline__ int block_inclusive_scan_1024(int v, int *wsum);
+__global__ __launch_bounds__(1024) void k_many_scan(int ncell, const ManyRep *__restrict__ reps)
+{
+    __shared__ int wsum[16];
+    __shared__ int last;
+    int *count = reps[blockIdx.x].count, *start = reps[blockIdx.x].start;
+    int carry = 0;
+    for (int base = 0; base < ncell; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < ncell) ? count[i] : 0;
+        const int incl = block_inclusive_scan_1024(v, wsum);
+        if (i < ncell) {
+            start[i] = carry + incl - v;
+            count[i] = 0;
+        }
+        if (threadIdx.x == 1023) last = incl;
+        __syncthreads();
+        carry += last;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[ncell] = carry;
+}
+
+__global__ void k_many_bin_b(int N, const ManyRep *__restrict__ reps)
+{
+    const ManyRep &r = reps[blockIdx.y];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) r.tmp_ids[r.start[r.cell_of[i]] + r.arrival[i]] = i;
+}
+
+template <int D>
+__global__ void k_many_bin_c(int N, MovePool pool, const ManyRep *__restrict__ reps, const ManyStep *__restrict__ steps)
+{
+    const ManyRep &r = reps[blockIdx.y];
+    const ManyStep &st = steps[blockIdx.y];
+    SlotGen gen;
+    gen.enabled = 1;
+    gen.s_lo = st.s_lo; gen.s_hi = st.s_hi; gen.key0 = r.key0; gen.key1 = r.key1;
+    gen.temperature = r.temperature;
+    gen.pool = pool;
+    gen.out = r.slots;
+    mc_bin_c_body<D>(r.pos_ro, r.species, r.cell_of, N, r.start, r.tmp_ids, r.ids, r.sx, r.sy, r.sz, r.ssp, gen);
 }
 
 // three-launch exclusive scan: tile sums, scan of the tile sums, tile scan + base
@@ -2537,33 +2636,44 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
 //    than one colour, so cells stall on their neighbours: 1.65 ms against 1.41 ms at N = 10^6.)
 // ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
 template <int D, int KIND, bool MULTI, int NW, bool ONE>
-__global__ __launch_bounds__(NW * 64, (NW == 1 ? 3 : PMC_CB_MINWAVES)) void k_cb_pass(CbArgs a)
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 3 : PMC_CB_MINWAVES)) void k_cb_pass(const CbArgs *__restrict__ args, int nrep)
 {
+    // The arguments of a launch live in DEVICE memory, one CbArgs per replica of the launch (one for a single system,
+    // n for pmc_sweep_many), written once per call for all its sweeps.  They are only ever read through references:
+    // a by-value CbArgs that is modified -- or handed to a function the compiler declines to inline -- is copied to
+    // scratch, and both times that happened (r02) the kernel produced wrong energies.
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;
-    const DevModel *tab = setup_lds<D, MULTI, (NW >= 2 ? NW : 0)>(a, smem, h);
+    const CbArgs &a0 = args[0];                      // the shape (grid, models, pool, capacities) is common to all replicas
+    const DevModel *tab = setup_lds<D, MULTI, (NW >= 2 ? NW : 0)>(a0, smem, h);
     const int tid = team_tid<NW>();
     CbTotals tot{};
     if (!ONE) {
         if (tid < 16) h.cnt[tid] = 0;
-        if (tid < 8) {           // compile-time indices into the kernel argument: no scratch copy
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-                if (tid == q) { h.ptab[q] = a.pool.kind[q]; h.ptab[8 + q] = a.pool.sp0[q]; h.ptab[16 + q] = a.pool.sp1[q]; }
+        if (tid < 8) {
+            h.ptab[tid] = a0.pool.kind[tid];
+            h.ptab[8 + tid] = a0.pool.sp0[tid];
+            h.ptab[16 + tid] = a0.pool.sp1[tid];
         }
         __syncthreads();
     }
-    int aidx, colour = a.colour;
-    if (a.fused) {
-        if (tid == 0) h.flag[2] = (int)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
+    int aidx, colour = a0.colour, r = 0;
+    if (a0.fused) {
+        // ticket -> (colour, replica, cell), colour slowest: a cell's lower-colour neighbours -- cells of the SAME replica --
+        // hold lower tickets, i.e. belong to workgroups that are resident or finished: no deadlock
+        if (tid == 0) h.flag[2] = (int)(atomicAdd(a0.ticket, 1ull) - a0.ticket_base);
         __syncthreads();
         const int t = h.flag[2];
-        colour = t / a.nactive;
-        aidx = t - colour * a.nactive;
+        const int per_colour = nrep * a0.nactive;
+        colour = t / per_colour;
+        const int rem = t - colour * per_colour;
+        r = __builtin_amdgcn_readfirstlane(rem / a0.nactive);
+        aidx = rem - r * a0.nactive;
     } else {
-        aidx = a.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-        if (aidx >= a.nactive) return;
+        aidx = a0.order ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+        if (aidx >= a0.nactive) return;
     }
+    const CbArgs &a = args[r];
     unsigned long long *const st = a.stats + (size_t)(aidx & (PMC_NSHARD - 1)) * PMC_NSTATS;   // this workgroup's counter copy
     cb_visit<D, KIND, MULTI, NW, ONE>(a, h, tab, colour, aidx, st, tot);
     if (tid == 0) {

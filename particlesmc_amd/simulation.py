@@ -64,30 +64,19 @@ def mc_sweep(system, pool, rng=None, mc_steps=None, mode="checkerboard", nsweeps
 
 
 def mc_sweep_many(systems, pool, nsweeps=1, mode="checkerboard"):
-    """The chains of a `parallel=true` run (src/ParticlesMC.jl:164,246): every chain's sweeps are
-    enqueued on its own HIP stream before any is waited for, so small chains share the GPU."""
+    """The chains of a `parallel=true` run (src/ParticlesMC.jl:164,246) through pmc_sweep_many: chains of one shape
+    share every kernel launch; otherwise every chain's sweeps are enqueued on its own HIP stream before any is waited for."""
     arr = c_pool(pool)
     L = _lib.lib()
-    begun, out, first_error = [], [], None
-    try:
-        for s in systems:
-            _lib.check(L.pmc_sweep_begin(s._h, MODES[mode], arr, len(pool), int(nsweeps)), s._h)
-            begun.append(s)
-    except Exception as exc:           # the chains already in flight are still drained below
-        first_error = exc
-    # every handle that has begun is ended, whatever happens to the others: a handle left `pending`
-    # refuses every later call with PMC_ERR_STATE
-    for s in begun:
-        st = _lib.Stats()
-        try:
-            _lib.check(L.pmc_sweep_end(s._h, C.byref(st)), s._h)
-            out.append(SweepStats(st, len(pool)))
-        except Exception as exc:
-            if first_error is None:
-                first_error = exc
-    if first_error is not None:
-        raise first_error
-    return out
+    n = len(systems)
+    if n == 0:
+        return []
+    hs = (C.c_void_p * n)(*[s._h for s in systems])
+    st = (_lib.Stats * n)()
+    # pmc_sweep_many: chains of one shape share every launch; anything else runs as begin ... end on every handle
+    # (and the library ends every chain it has begun whatever happens to the others)
+    _lib.check(L.pmc_sweep_many(hs, n, MODES[mode], arr, len(pool), int(nsweeps), st), systems[0]._h)
+    return [SweepStats(st[k], len(pool)) for k in range(n)]
 
 
 # ---- schedulers (Arianna build_schedule; semantics not pinned by the reference tree) -----

@@ -65,9 +65,37 @@ class ReplicaExchange:
         return self.temperature
 
 
+def rccl_comm_from_env(device, tag="pmc"):
+    """One-process-per-GPU launchers (torchrun, mpirun, srun) export RANK / WORLD_SIZE / MASTER_PORT: rank 0 creates the
+    RCCL unique id and hands its 128 bytes to the other ranks of the node through a file named after the port; every rank
+    then joins through pmc_rccl_comm_create.  No torch, no MPI: the library's own entry points and the file system."""
+    import os
+    import time
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"{tag}_rccl_id_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}")
+    if rank == 0:
+        uid = RcclComm.unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > 120:
+                raise TimeoutError(f"no RCCL id from rank 0 at {path}")
+            time.sleep(0.05)
+        uid = open(path, "rb").read()
+    comm = RcclComm(uid, rank, world, device)
+    if rank == 0 and world == 1:
+        os.remove(path)
+    return comm
+
+
 def run_tempering(system, pool, ladder, nsweeps, exchange_every, seed, rank=0, world=1, group=None, device="cpu",
-                  mode="checkerboard"):
-    """Sweeps on this rank's replica with an exchange round every `exchange_every` sweeps."""
+                  mode="checkerboard", comm=None):
+    """Sweeps on this rank's replica with an exchange round every `exchange_every` sweeps.  With `comm` (an RcclComm)
+    the round is pmc_replica_exchange_rccl -- the library's ncclAllGather, no torch; otherwise torch.distributed
+    gathers the energies (RCCL with the nccl backend, gloo on CPU) and pmc_pt_decide decides."""
     from .simulation import mc_sweep
     rex = ReplicaExchange(ladder, seed, rank, world, group, device)
     system.temperature = rex.temperature
@@ -77,7 +105,13 @@ def run_tempering(system, pool, ladder, nsweeps, exchange_every, seed, rank=0, w
         k = min(exchange_every, nsweeps - done)
         st = mc_sweep(system, pool, nsweeps=k, mode=mode)
         done += k
-        system.temperature = rex.exchange(st.energy)
+        if comm is not None:
+            rex.label, nacc = comm.exchange(system, rex.ladder, rex.seed, rex.round, rex.label)   # sets the handle's temperature
+            rex.attempted += max(0, (world - (rex.round & 1)) // 2)
+            rex.accepted += nacc
+            rex.round += 1
+        else:
+            system.temperature = rex.exchange(st.energy)
         trace.append((done, int(rex.label[rank]), st.energy))
     return rex, trace
 

@@ -166,6 +166,41 @@ int main(int argc, char **argv)
     CHECK(pmc_get_temperature(h, &T2));
     fprintf(fo, "temperature %.17g\n", T2);
 
+    /* ---- EnergyBias overloads: sample_action! / log_proposal_density on the device ------------------------------------- */
+    if (S > 1) {
+        int64_t bi = 0, bj = 0;
+        double lq = 0, lq2 = 0;
+        CHECK(pmc_energy_bias_sample(h, 1, 2, 0.3, -0.2, 0.25, 0.75, &bi, &bj, &lq));
+        CHECK(pmc_energy_bias_logq(h, 1, 2, 0.3, -0.2, bi, bj, &lq2));
+        fprintf(fo, "energy_bias %lld %lld %.17g %.17g\n", (long long)bi, (long long)bj, lq, lq2);
+    }
+
+    /* ---- sweep_many! and replica_exchange!: a second chain of the same shape, both through the shared-launch entry ------ */
+    {
+        pmc_system *h2 = NULL;
+        pmc_params p2 = p;
+        p2.chain = 4;
+        p2.temperature = 1.05 * T;
+        CHECK(pmc_create(&p2, &h2));
+        CHECK(pmc_upload(h2, pos, sp));       /* pos / sp: the first chain's current state (refresh! above) */
+        double e2 = 0;
+        CHECK(pmc_init_energy(h2, &e2));
+        CHECK(pmc_set_energy(h2, e2));
+        CHECK(pmc_set_temperature(h, T));
+        pmc_system *hs[2] = {h, h2};
+        pmc_stats st2[2];
+        CHECK(pmc_sweep_many(hs, 2, PMC_CHECKERBOARD, pool, npool, 2, st2));
+        for (int r = 0; r < 2; r++)
+            fprintf(fo, "many %d %lld %lld %lld\n", r, (long long)st2[r].attempted[0], (long long)st2[r].accepted[0], (long long)st2[r].energy_fix);
+        double ladder[2] = {T, 1.05 * T}, Ta = 0, Tb = 0;
+        int32_t label[2] = {0, 1}, nacc = 0;
+        CHECK(pmc_replica_exchange(hs, 2, ladder, 99, 0, label, &nacc));
+        CHECK(pmc_get_temperature(h, &Ta));
+        CHECK(pmc_get_temperature(h2, &Tb));
+        fprintf(fo, "exchange %d %d %d %.17g %.17g\n", label[0], label[1], nacc, Ta, Tb);
+        CHECK(pmc_destroy(h2));
+    }
+
     /* ---- the AbstractRNG wrapper (PMCHip.SequentialWords): the words of sequential step k, host side ------------------ */
     for (uint64_t step = 0; step < 3; step++) {
         uint32_t R[4], Q[4];

@@ -155,6 +155,22 @@ def test_glue_call_sequences_replayed_in_c_match_the_oracle(gpu, harness, tmp_pa
     assert np.array_equal(np.array(out["species"][0], dtype=np.int32), cb.species())
     assert float(out["refresh_energy"][0][0]) == cb.energy_fix / 2.0 ** 32
     assert float(out["temperature"][0][0]) == 1.5 * T
+    # EnergyBias overloads: the device's pick and densities equal the oracle's restatement on the same state
+    o2 = O.System(cb.positions(), cb.species(), rho, T, mo, O.LINKEDLIST)
+    eb = out["energy_bias"][0]
+    want = o2.energy_bias((1, 2), (0.3, -0.2), (0.25, 0.75))
+    assert (int(eb[0]), int(eb[1]), float(eb[2])) == want and float(eb[3]) == want[2]
+    # sweep_many! over two chains of one shape (chain 3 continues at sweep 6, chain 4 starts at sweep 0), then replica_exchange!
+    att, acc = cb.sweeps(pool, 6, 2)
+    cb2 = O.Checkerboard(o2.positions(), o2.species(), o.box, 1.05 * T, mo, seed=77, chain=4)
+    att2, acc2 = cb2.sweeps(pool, 0, 2)
+    m0, m1 = out["many"]
+    assert [int(m0[1]), int(m0[2]), int(m0[3])] == [att[0], acc[0], cb.energy_fix]
+    assert [int(m1[1]), int(m1[2]), int(m1[3])] == [att2[0], acc2[0], cb2.energy_fix]
+    lab, nacc = O.pt_decide(99, 0, [cb.energy_fix / 2.0 ** 32, cb2.energy_fix / 2.0 ** 32], [T, 1.05 * T], [0, 1])
+    ex = out["exchange"][0]
+    assert [int(ex[0]), int(ex[1]), int(ex[2])] == lab + [nacc]
+    assert [float(ex[3]), float(ex[4])] == [[T, 1.05 * T][lab[0]], [T, 1.05 * T][lab[1]]]
     # the words the AbstractRNG wrapper serves: Philox blocks of the sequential stream
     # (DESIGN.md "random streams": ctr = (step_lo, step_hi, 0, TAG_SEQ0 | TAG_SEQ1), key = (seed_lo, seed_hi + chain))
     for row in out["words"]:
