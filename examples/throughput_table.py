@@ -97,7 +97,7 @@ def main():
         t0 = time.perf_counter()
         pmc.mc_sweep_many(chains, pool, nsweeps=500)
         dt = time.perf_counter() - t0
-        rows.append({"row": "8 concurrent chains of N=4096 (pmc_sweep_begin/end)", "moves_per_s": 8 * 4096 * 500 / dt})
+        rows.append({"row": "8 chains of N=4096 in shared launches (pmc_sweep_many)", "moves_per_s": 8 * 4096 * 500 / dt})
         print(json.dumps(rows[-1]), flush=True)
         t0 = time.perf_counter()
         for c in chains:
