@@ -323,21 +323,63 @@ def test_checkerboard_statistics_match_sequential_chain(O):
     assert abs(a_s - a_c) < 0.06 and a_c < a_s + 0.01
 
 
+@pytest.mark.timeout(600)
+def test_checkerboard_with_swaps_matches_sequential_chain(O):
+    """The same comparison for a binary mixture with DiscreteSwap moves: the parallel schedule draws both swap partners
+    from ONE cell (DoubleUniform restricted to the active domain), the reference chain from the whole box; <e> and BOTH
+    acceptance rates must agree (Displacement up to the cell-leaving rejections)."""
+    from mixture import EPS, SIG
+    from inputs import binary_lattice
+    pos, sp, rho = binary_lattice(1728, frac_b=0.5, rho=0.8, jitter=0.05, seed=2)
+    T = 1.5
+    models = O.model_matrix(lambda e, s: O.lennard_jones(e, s, 2.5 * s), EPS, SIG)
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.08, "probability": 0.8},
+                        {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.2}])
+    seq = O.System(pos, sp, rho, T, models, O.LINKEDLIST)
+    cb = O.Checkerboard(pos, sp, seq.box, T, models, seed=5)
+    N = len(pos)
+    burn, prod = 80, 160
+    seq.mc_steps(pool, 5, 0, 0, burn * N)
+    cb.sweeps(pool, 0, burn)
+    es, ec = [], []
+    att_s, acc_s, att_c, acc_c = np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(2)
+    for t in range(prod):
+        a, c = seq.mc_steps(pool, 5, 0, (burn + t) * N, N)
+        att_s += a
+        acc_s += c
+        es.append(seq.energy / N)
+        a, c = cb.sweeps(pool, burn + t, 1)
+        att_c += a
+        acc_c += c
+        ec.append(cb.energy_fix / 2.0 ** 32 / N)
+    es, ec = np.array(es), np.array(ec)
+
+    def err(x):
+        b = x[: len(x) // 10 * 10].reshape(10, -1).mean(1)
+        return b.std(ddof=1) / np.sqrt(10)
+    assert abs(es.mean() - ec.mean()) < 4 * np.hypot(err(es), err(ec)) + 5e-3
+    rs, rc = acc_s / att_s, acc_c / att_c
+    assert abs(rs[1] - rc[1]) < 0.03, (rs, rc)                      # swap acceptance: cell-local pairs vs box-wide pairs
+    assert abs(rs[0] - rc[0]) < 0.06 and rc[0] < rs[0] + 0.01       # Displacement: lower only by the cell-leaving rejections
+    assert abs(att_c[1] / att_c.sum() - 0.2) < 0.01
+
+
 @pytest.mark.timeout(900)
-def test_oracle_reproduces_the_references_published_mixture_results(O):
+@pytest.mark.parametrize("row_index", [0, 6, 13, 18])
+def test_oracle_reproduces_the_references_published_mixture_results(O, row_index):
     """Statistical pin at the driver level: the reference's own results for
     examples/lj-mixture (calculated-energies.csv) -- mean energy and BOTH acceptance rates -- are
     reproduced by the oracle's sequential chain with the same protocol (N = 1000, rcut = 4,
-    unshifted, 90/10 Displacement/DiscreteSwap, sigma = 0.05; here 400 sweeps, second half
+    unshifted, 90/10 Displacement/DiscreteSwap, sigma = 0.05; here 600 sweeps, second half
     averaged).  This is the only reference data that constrains the Metropolis accept rule."""
     from mixture import EPS, SIG, RCUT, N, make_config, reference_rows
-    row = reference_rows()[0]                 # T = 1.2183, x = 0.5, rho = 0.8
-    pos, sp, rho = make_config(row["x"], row["density"], seed=1)
+    row = reference_rows()[row_index]         # rows 0 / 6 / 13 / 18: x = 0.5, 0.25, 0.75, 0.5; rho = 0.8, 0.5, 0.6, 0.5; T = 1.2183 ... 1.6438
+    pos, sp, rho = make_config(row["x"], row["density"], seed=1 + row_index)
     models = O.model_matrix(lambda e, s: O.lennard_jones(e, s, RCUT, False), EPS, SIG)
     s = O.System(pos, sp, rho, row["t"], models, O.LINKEDLIST)
     pool = O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.9},
                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}])
-    sweeps = 400
+    sweeps = 600
     en = []
     att = np.zeros(2)
     acc = np.zeros(2)
