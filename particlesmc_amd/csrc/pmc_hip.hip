@@ -56,6 +56,8 @@ struct pmc_system {
     int *d_cl_items = nullptr, *d_vl_nb = nullptr, *d_vl_cnt = nullptr, *d_ref_err = nullptr;
     double *d_vl_last = nullptr;
     int cl_cap = 0, vl_cap = 0;
+    int cap_hint = 0;       // LDS staging capacity learnt from the last sweeps' histogram (cb_cap_learn); 0: none yet
+    unsigned long long kept_seen[16] = {0};   // the part of the current call's histogram cb_cap_learn has already used
     // proposal slots of the current sweep (k_mc_slots)
     double *d_slot_f = nullptr;          // [4][N]: T ln u, dx, dy, dz
     uint32_t *d_slot_w = nullptr;        // [2][N]: particle word, second swap word
@@ -1199,9 +1201,41 @@ static int cb_cap(const pmc_system *h)
     return std::min(std::max(cap, 128), PMC_CAP_MAX);
 }
 
-static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
+// ... of k_cb_pass, which applies the box filter while staging (stage_compacted) and only keeps the survivors in LDS --
+// about 73 % of the 3^d-cell population at w ~ rcut.  How many that is depends on the state (a liquid: 343 +- 9 at
+// N = 10^6; the jittered lattice it started from: 343 .. 512), so the kernel counts the visits by survivor count
+// (stats[PMC_STAT_KEPT..]) and the next launches are sized for all but 0.2 % of them.  Those stage the old way, their
+// overflow read from L2: results never depend on the capacity.  Before the first histogram: the full population.
+static int cb_cap_sweep(const pmc_system *h)
 {
-    size_t b = (pmc_lds_wave_bytes(cb_cap(h), h->S > 1, batch_nw) + 15) & ~(size_t)15;
+    if (const char *e = getenv("PMC_CAP")) return std::min(std::max(atoi(e) / 64 * 64, 128), PMC_CAP_MAX);   // experiments
+    if (!h->use_filter || !PMC_FUSED_STAGE || h->team > 2 || h->cap_hint <= 0) return cb_cap(h);   // (teams of 4 and 8 stage the old way)
+    return std::min(std::max(h->cap_hint, 128), cb_cap(h));
+}
+
+static bool cb_cap_sweep_adapts(const pmc_system *h)
+{
+    return h->use_filter && PMC_FUSED_STAGE && h->team <= 2 && !getenv("PMC_CAP");
+}
+
+// `cum`: the call's histogram so far; what was already looked at (kept_seen) is subtracted
+static void cb_cap_learn(pmc_system *h, const unsigned long long *cum)
+{
+    unsigned long long bk[16], total = 0, above = 0;
+    for (int b = 0; b < 16; b++) {
+        bk[b] = cum[b] - h->kept_seen[b];
+        h->kept_seen[b] = cum[b];
+        total += bk[b];
+    }
+    if (total == 0) return;
+    int b = 15;
+    while (b > 1 && above + bk[b] <= total / 500) above += bk[b--];
+    h->cap_hint = b >= 15 ? PMC_CAP_MAX : 64 * b;
+}
+
+static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0, int cap = 0)
+{
+    size_t b = (pmc_lds_wave_bytes(cap > 0 ? cap : cb_cap(h), h->S > 1, batch_nw) + 15) & ~(size_t)15;
     if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
     if (const char *e = getenv("PMC_LDS_PAD")) b += (size_t)atoi(e);   // occupancy experiments
     return b;
@@ -1210,19 +1244,28 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0)
 #define PMC_ARGS_CHUNK 256     // sweeps whose launch arguments are uploaded together
 // k_cb_pass additionally carries the team size NW (wavefronts per cell)
 // The launch arguments (CbArgs) are read from device memory: `args` below is a device pointer to nrep_ of them.
-#define DISPATCH_CB_ONE(DD, KK, NWV, h, grid, lds, args)   /* uses pool_ (MovePool) and nrep_ (int) of the caller's scope */                                                        \
-    if (!done_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV) {                                        \
-        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
-        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
-        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
-        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+#define DISPATCH_CB_ONE(DD, KK, NWV, MWV, h, grid, lds, args)   /* uses pool_ (MovePool), nrep_ and mw_ (int) of the caller's scope */                                      \
+    if (!done_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV && mw_ == MWV) {                           \
+        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true, MWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false, MWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true, MWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false, MWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
         done_ = true;                                                                                           \
     }
+// one wavefront per cell comes in two register budgets: 4 wavefronts per SIMD (128 VGPRs) pays when the LDS footprint lets
+// more than 12 workgroups share a CU, 3 (168 VGPRs) is ~5 % faster when it does not (cb_minwaves)
 #define DISPATCH_CB_KIND(DD, KK, h, grid, lds, args)                                                            \
-    DISPATCH_CB_ONE(DD, KK, 1, h, grid, lds, args)                                                              \
-    DISPATCH_CB_ONE(DD, KK, 2, h, grid, lds, args)                                                              \
-    DISPATCH_CB_ONE(DD, KK, 4, h, grid, lds, args)                                                              \
-    DISPATCH_CB_ONE(DD, KK, 8, h, grid, lds, args)
+    DISPATCH_CB_ONE(DD, KK, 1, 3, h, grid, lds, args)                                                           \
+    DISPATCH_CB_ONE(DD, KK, 1, 4, h, grid, lds, args)                                                           \
+    DISPATCH_CB_ONE(DD, KK, 2, PMC_CB_MINWAVES, h, grid, lds, args)                                             \
+    DISPATCH_CB_ONE(DD, KK, 4, PMC_CB_MINWAVES, h, grid, lds, args)                                             \
+    DISPATCH_CB_ONE(DD, KK, 8, PMC_CB_MINWAVES, h, grid, lds, args)
+static int cb_minwaves(const pmc_system *h, size_t lds)
+{
+    if (const char *e = getenv("PMC_MINWAVES")) return atoi(e) == 3 ? 3 : 4;    // experiments
+    if (h->team != 1) return PMC_CB_MINWAVES;
+    return lds * 13 <= 160 * 1024 ? 4 : 3;
+}
 #ifndef PMC_DEV_KIND
 #define PMC_DEV_KIND 0
 #endif
@@ -1484,7 +1527,8 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     const int ncol = 1 << h->D;
     int nactive = 1;
     for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
-    const size_t lds = cb_lds_bytes(h, h->team >= 2 ? h->team : 0);   // teams keep slot records and one survivor queue per wavefront in LDS
+    int cap_sweep = cb_cap_sweep(h);
+    size_t lds = cb_lds_bytes(h, h->team >= 2 ? h->team : 0, cap_sweep);   // teams keep slot records and one survivor queue per wavefront in LDS
     int64_t launches = 0, timed_sweeps = 0;
     // fused launches stream the cells of every colour in the same spatial order, so that the cells a
     // workgroup waits for were ticketed long before it (a pipeline with one tail per sweep); separate
@@ -1495,6 +1539,12 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     const int per_sweep = fused ? 1 : ncol;  // launches, and CbArgs entries, per sweep
     const MovePool &pool_ = mp;
     const int nrep_ = 1;
+    int mw_ = cb_minwaves(h, lds);
+    // long calls: the staging capacity is fitted again (cb_cap_learn) to what the last chunk of sweeps saw -- a first call on
+    // a handle after 16 sweeps already
+    const bool learn = cb_cap_sweep_adapts(h);
+    const bool learn_early = learn && h->cap_hint <= 0 && nsweeps > 48;
+    memset(h->kept_seen, 0, sizeof h->kept_seen);
     // The launch arguments of the sweep kernel live in device memory (k_cb_pass): all the sweeps of a chunk are prepared
     // here and uploaded at once.
     const int64_t chunk = PMC_ARGS_CHUNK;
@@ -1505,8 +1555,19 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     const SlotOut slots{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     h->cb_started = nsweeps > 0;
-    for (int64_t s0 = 0; s0 < nsweeps; s0 += chunk) {
-        const int64_t ns = std::min<int64_t>(chunk, nsweeps - s0);
+    for (int64_t s0 = 0, ns = 0; s0 < nsweeps; s0 += ns) {
+        ns = std::min<int64_t>(learn_early && s0 == 0 ? 16 : chunk, nsweeps - s0);
+        if (learn && s0 > 0) {
+            unsigned long long buckets[16];
+            hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, h->stream, h->d_stats);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(buckets, h->d_stats + PMC_STAT_KEPT, sizeof buckets, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            cb_cap_learn(h, buckets);
+            cap_sweep = cb_cap_sweep(h);
+            lds = cb_lds_bytes(h, h->team >= 2 ? h->team : 0, cap_sweep);
+            mw_ = cb_minwaves(h, lds);
+        }
         tabh.assign((size_t)(ns * per_sweep), CbArgs{});
         shifts.assign((size_t)ns, std::array<double, 3>{0.0, 0.0, 0.0});
         bool reset_flags = false;
@@ -1518,6 +1579,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
             for (int q = 0; q < h->D; q++) shifts[(size_t)k][(size_t)q] = ((double)W[q] * (1.0 / 4294967296.0)) * h->grid.w[q];
             for (int q = 0; q < 3; q++) h->grid.shift[q] = shifts[(size_t)k][(size_t)q];
             CbArgs a = cb_args(h);
+            a.cap = cap_sweep;
             a.order = lpt ? h->d_order : nullptr;
             a.slot_tlnu = slots.tlnu; a.slot_dx = slots.dx; a.slot_dy = slots.dy; a.slot_dz = slots.dz;
             a.slot_w1 = slots.w1; a.slot_w2 = slots.w2; a.slot_m = slots.m;
@@ -1633,10 +1695,11 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
     }
 #endif
 #ifdef PMC_DEBUG_COUNT
-    fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], (double)st[24] / st[21]);
+    fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f compacted=%.4f filt=%.4f sd_ncand=%.1f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], (double)st[24] / st[21], (double)st[28] / st[21], (double)st[29] / st[21], sqrt((double)st[30] / st[21] - ((double)st[20] / st[21]) * ((double)st[20] / st[21])));
 #endif
     h->e_fix += (long long)st[16];
     h->energy = (double)h->e_fix / PMC_FIX;
+    cb_cap_learn(h, st + PMC_STAT_KEPT);
     if (out) {
         for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)st[m]; out->accepted[m] = (int64_t)st[8 + m]; }
         float ms = 0;
@@ -1784,6 +1847,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             h->epoch = 0;
         }
         HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), m->stream));
+        memset(h->kept_seen, 0, sizeof h->kept_seen);
         if (!h->count_is_zero) HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)h->ncell_mc + 1) * sizeof(int), m->stream));
         h->count_is_zero = true;
     }
@@ -1791,7 +1855,9 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     const int ncol = 1 << m->D, N = m->N;
     int nactive = 1;
     for (int q = 0; q < m->D; q++) nactive *= m->grid.n[q] / 2;
-    const size_t lds = cb_lds_bytes(m, m->team >= 2 ? m->team : 0);
+    int cap_sweep = 0;                                       // one LDS layout for all the replicas
+    for (int r = 0; r < n; r++) cap_sweep = std::max(cap_sweep, cb_cap_sweep(hs[r]));
+    const size_t lds = cb_lds_bytes(m, m->team >= 2 ? m->team : 0, cap_sweep);
     const int nb = nblk(N, 256);
     // replica table (once) and per-sweep table (all sweeps of the call, in chunks)
     std::vector<ManyRep> reps((size_t)n);
@@ -1819,6 +1885,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     std::vector<CbArgs> argsh;
     const MovePool &pool_ = mp;
     const int nrep_ = n;
+    const int mw_ = cb_minwaves(m, lds);
     const int grid = ncol * n * nactive;
     HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
     for (int64_t s0 = 0; s0 < nsweeps; s0 += chunk) {
@@ -1839,6 +1906,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
                 // the sweep kernel's arguments for this replica and sweep (its own arrays; the launch's shared ticket)
                 for (int q = 0; q < 3; q++) h->grid.shift[q] = st.shift[q];
                 CbArgs a = cb_args(h);
+                a.cap = cap_sweep;
                 const size_t Ns = (size_t)h->N;
                 a.order = nullptr;
                 a.slot_tlnu = h->d_slot_f; a.slot_dx = h->d_slot_f + Ns; a.slot_dy = h->d_slot_f + 2 * Ns; a.slot_dz = h->d_slot_f + 3 * Ns;

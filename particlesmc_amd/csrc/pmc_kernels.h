@@ -13,6 +13,9 @@
 
 #define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
 #define PMC_CFL 16           // centre-cell particles whose cell coordinates are cached (cells without exact bounds)
+#ifndef PMC_FUSED_STAGE
+#define PMC_FUSED_STAGE true  // k_cb_pass applies the box filter while staging (stage_compacted)
+#endif
 #ifndef PMC_CB_MINWAVES
 #define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget)
 #endif
@@ -23,6 +26,7 @@
                              // them into copy 0 (55 000 workgroups adding to ONE cache line serialise at ~6 ns per atomic: that alone
                              // was 2.3 ms per sweep at N = 10^6)
 #define PMC_NSTATS 64        // counters of one sweep call (CbArgs::stats); [32..47] are used by -DPMC_DEBUG_TIME builds only
+#define PMC_STAT_KEPT 48     // [48..63]: cell visits by box-filtered neighbourhood size, bucket b = sizes in (64 (b-1), 64 b]
 #define PMC_QCAP 640         // entries of a wavefront's survivor queue (2 B each); a filter trip adds at most 128, so the
                              // first five trips cannot overflow it and one check after the fifth covers the rest
 #ifdef PMC_DEBUG_TIME   // profiling builds only: shader-clock stamps of wavefront 0, summed per phase into stats[32..]
@@ -1231,6 +1235,8 @@ struct WaveNbh {
     unsigned short *queue;   // [max(NW,1)][PMC_QCAP] survivor queues, one per wavefront
     double bc[3];            // centre of the centre cell (frame of its first particle)
     bool filt;               // the pre-filter is usable for this visit (everything staged, at most 64 PMC_FTRIPS candidates)
+    bool compacted;          // the box filter was applied while staging (stage_compacted)
+    int kept;                // candidates that passed the box filter (stage_compacted; a huge value if it could not count them)
     // proposal-slot values of the first chunk, fetched together with the coordinates (latency-bound teams only)
     double p_tlnu, p_dx, p_dy, p_dz;
     uint32_t p_w1, p_w2;
@@ -1257,6 +1263,133 @@ __device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
     return h.segsrc[lo] + (k - h.segoff[lo]);
 }
 
+// Fused staging: the segments of the neighbourhood (runs of 3 cells, or single cells) go from global memory to registers,
+// are tested against the centre cell's box there (the test of compact_candidates below, same arithmetic), and only the
+// survivors are written to LDS, already compacted.  The staging capacity then only has to hold the ~73 % of a 3^d-cell
+// neighbourhood that can be in range of the centre cell, and the LDS round trip of a separate compaction pass is gone.
+// lanes 0..nseg-1 hold (seg_start, seg_cnt).  Returns false -- with nothing but LDS scratch modified -- when a segment is
+// longer than a wavefront or the survivors do not fit: the caller then stages the old way.
+template <int D, bool MULTI, int NW>
+__device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int seg_start, int seg_cnt, int nseg)
+{
+    constexpr int NR = (D == 3) ? 9 : 3;
+    const int lane = wave_lane(), wv = team_wave<NW>();
+    h.kept = 1 << 20;
+    if (__builtin_amdgcn_ballot_w64(lane < nseg && seg_cnt > PMC_WAVE) != 0ull) return false;
+    const int k0 = h.k0, k1 = h.k0 + h.nc;
+    // reference particle (the first of the centre cell): its cell coordinates define the box, its image the no-wrap test
+    const double xr = ld_agent(a.sx + k0), yr = ld_agent(a.sy + k0), zr = (D == 3) ? ld_agent(a.sz + k0) : 0.0;
+    double bc[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
+    bool have_box = false;
+    int base = 0;
+    bool wrapped_any = false;
+    for (int b = 0; b < nseg; b += NR) {
+        double tx[NR], ty[NR], tz[NR];
+        unsigned char ts[NR];
+        unsigned long long keepm[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int s0 = __builtin_amdgcn_readlane(seg_start, b + r), c0 = __builtin_amdgcn_readlane(seg_cnt, b + r);
+            tx[r] = ty[r] = tz[r] = 0.0;
+            ts[r] = 0;
+            if ((r % NW) == wv && lane < c0) {
+                tx[r] = ld_agent(a.sx + s0 + lane);
+                ty[r] = ld_agent(a.sy + s0 + lane);
+                if (D == 3) tz[r] = ld_agent(a.sz + s0 + lane);
+                if (MULTI) ts[r] = ld_agent(a.ssp + s0 + lane);
+            }
+        }
+        if (!have_box) {
+            const double ref[3] = {xr, yr, zr};
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                bc[q] = a.shift[q] + (mc_coord<D>(ref[q], a.shift[q], a.w[q]) + 0.5) * a.w[q];
+                bh[q] = 0.5 * a.w[q] * (1.0 + 1e-9);
+            }
+            have_box = true;
+        }
+        // which candidates are in another periodic image than the reference particle (see the no-wrap test of
+        // stage_neighbourhood); one that is not lies in the unfolded 3-cell span, where the minimum image below is the identity
+        bool wr[NR];
+        bool wrapped = false;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int c0 = __builtin_amdgcn_readlane(seg_cnt, b + r);
+            wr[r] = false;
+            if ((r % NW) == wv && lane < c0) {
+                wr[r] = rint((xr - tx[r]) * a.invL[0]) != 0.0 || rint((yr - ty[r]) * a.invL[1]) != 0.0 ||
+                        ((D == 3) ? (rint((zr - tz[r]) * a.invL[2]) != 0.0) : false);
+            }
+            wrapped = wrapped || wr[r];
+        }
+        const bool fold = __builtin_amdgcn_ballot_w64(wrapped) != 0ull;
+        wrapped_any = wrapped_any || fold;
+        int cnt[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int s0 = __builtin_amdgcn_readlane(seg_start, b + r), c0 = __builtin_amdgcn_readlane(seg_cnt, b + r);
+            bool keep = false;
+            if ((r % NW) == wv && lane < c0) {
+                double t0 = tx[r] - bc[0], t1 = ty[r] - bc[1], t2 = (D == 3) ? tz[r] - bc[2] : 0.0;
+                if (fold) {
+                    t0 -= rint(t0 * a.invL[0]) * a.L[0];
+                    t1 -= rint(t1 * a.invL[1]) * a.L[1];
+                    if (D == 3) t2 -= rint(t2 * a.invL[2]) * a.L[2];
+                }
+                const double ex = fmax(fabs(t0) - bh[0], 0.0);
+                const double ey = fmax(fabs(t1) - bh[1], 0.0);
+                double d2 = ex * ex + ey * ey;
+                if (D == 3) {
+                    const double ez = fmax(fabs(t2) - bh[2], 0.0);
+                    d2 += ez * ez;
+                }
+                const int g = s0 + lane;
+                keep = !a.filter || (g >= k0 && g < k1) || !(d2 > a.rc2pad);
+            }
+            keepm[r] = __builtin_amdgcn_ballot_w64(keep);
+            cnt[r] = __popcll(keepm[r]);
+        }
+        if (NW > 1) {
+            // every run belongs to one wavefront of the team: exchange the kept counts
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+                if ((r % NW) == wv && lane == 0) h.segoff[r] = cnt[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < NR; r++) cnt[r] = h.segoff[r];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int s0 = __builtin_amdgcn_readlane(seg_start, b + r);
+            const unsigned long long m = keepm[r];
+            if ((r % NW) == wv) {
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int pos = base + below;
+                if (((m >> lane) & 1ull) && pos < h.cap) {
+                    h.cx[pos] = tx[r];
+                    h.cy[pos] = ty[r];
+                    if (D == 3) h.cz[pos] = tz[r];
+                    if (MULTI) h.csp[pos] = ts[r];
+                    if (s0 + lane == k0) h.flag[1] = pos;     // LDS slot of the first centre particle
+                }
+            }
+            base += cnt[r];
+        }
+    }
+    if (NW > 1 && wrapped_any && lane == 0) atomicOr(&h.flag[0], 1);
+    __syncthreads();
+    h.kept = base;
+    if (base > h.cap) return false;
+    h.nowrap = (NW > 1) ? (h.flag[0] == 0) : !wrapped_any;
+    h.ctr = h.flag[1];
+    h.ncand = base;
+    h.nseg = 1;
+    if (lane == 0 && wv == 0) { h.segoff[0] = 0; h.segoff[1] = base; h.segsrc[0] = 0; }
+    h.compacted = true;
+    return true;
+}
+
 // Stage the 3^D neighbour cells of `cell` into LDS.
 //  * Fast path (the cell's last-dimension neighbours do not wrap): the 3 cells of one column are
 //    contiguous in the cell-sorted arrays, so the neighbourhood is 3^(D-1) runs; every run is
@@ -1265,9 +1398,11 @@ __device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
 // wait_colour > 0 (fused sweep): before the first coordinate is loaded the workgroup waits for the completion flags
 // of its lower-colour neighbour cells; the first poll is issued at the very top so that it
 // travels together with the loads of the CSR offsets instead of after them.
-template <int D, bool MULTI, int NW = 1>
+template <int D, bool MULTI, int NW = 1, bool FUSE = false>
 __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int cell[3], WaveNbh &h, int wait_colour = 0)
 {
+    h.compacted = false;
+    h.kept = 1 << 20;
     constexpr int NN = (D == 3) ? 27 : 9;
     constexpr int NR = (D == 3) ? 9 : 3;
     bool poll_need = false;
@@ -1300,13 +1435,15 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         if (tid == 0) h.flag[0] = 0;
         __syncthreads();
     }
-    bool runs_ok = (cell[LD] >= 1) && (cell[LD] + 1 < a.n[LD]);
+    const bool runs_shape = (cell[LD] >= 1) && (cell[LD] + 1 < a.n[LD]);
+    bool runs_ok = runs_shape;
     int seg_start = 0, seg_cnt = 0;
     int lin_c = 0;
 #pragma unroll
     for (int q = 0; q < D; q++) lin_c = lin_c * a.n[q] + cell[q];
     h.k0 = a.start[lin_c];
     h.nc = a.start[lin_c + 1] - h.k0;
+    int run_start = 0, run_cnt = 0;
     if (runs_ok) {
         // the run layout keeps the centre cell mid-buffer: only use it when everything fits in LDS
         int tot = 0;
@@ -1329,6 +1466,8 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         for (int sft = 1; sft < 16; sft <<= 1) tot += __shfl_xor(tot, sft, PMC_WAVE);
         tot = __shfl(tot, 0, PMC_WAVE);
         runs_ok = tot <= h.cap;
+        run_start = seg_start;
+        run_cnt = seg_cnt;
         if (!runs_ok) { seg_start = 0; seg_cnt = 0; }
     }
     if (runs_ok) {
@@ -1358,12 +1497,17 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         if (lane >= s) incl += v;
     }
     const int seg_off = incl - seg_cnt;
-    if (lane < h.nseg) {
-        h.segoff[lane] = seg_off;
-        h.segsrc[lane] = seg_start;
-    }
     h.ncand = __shfl(incl, h.nseg - 1, PMC_WAVE);
-    if (lane == 0) h.segoff[h.nseg] = h.ncand;
+    // (every wavefront of a team writes the same table.  Not before stage_compacted, which exchanges counts through segoff:
+    // a slow wavefront's late write of the table would overwrite a fast one's count)
+    const bool try_fused = FUSE && h.nc > 0;
+    if (!try_fused) {
+        if (lane < h.nseg) {
+            h.segoff[lane] = seg_off;
+            h.segsrc[lane] = seg_start;
+        }
+        if (lane == 0) h.segoff[h.nseg] = h.ncand;
+    }
     const int lim = min(h.ncand, h.cap);
     if (wait_colour > 0) {
         // a workgroup only ever waits for workgroups that already hold a ticket (see k_cb_pass): no deadlock; a bounded
@@ -1398,6 +1542,27 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
             h.p_dy = a.slot_dy[ks];
             if (D == 3) h.p_dz = a.slot_dz[ks];
         }
+    }
+    if (try_fused) {
+        const bool ok = runs_shape ? stage_compacted<D, MULTI, NW>(a, h, run_start, run_cnt, NR)
+                                   : stage_compacted<D, MULTI, NW>(a, h, seg_start, seg_cnt, NN);
+        if (ok) {
+            if (tid < min(h.nc, PMC_CFL)) {
+                h.cfl[0 * PMC_CFL + tid] = mc_coord<D>(h.cx[h.ctr + tid], a.shift[0], a.w[0]);
+                h.cfl[1 * PMC_CFL + tid] = mc_coord<D>(h.cy[h.ctr + tid], a.shift[1], a.w[1]);
+                if (D == 3) h.cfl[2 * PMC_CFL + tid] = mc_coord<D>(h.cz[h.ctr + tid], a.shift[2], a.w[2]);
+            }
+            __syncthreads();
+            return;
+        }
+        // (rare) a segment longer than a wavefront, or more survivors than the capacity: the old way, overflow loops and all
+        h.nseg = runs_ok ? NR : NN;
+        if (lane == 0) h.segoff[h.nseg] = h.ncand;
+        if (lane < h.nseg) {
+            h.segoff[lane] = seg_off;
+            h.segsrc[lane] = seg_start;
+        }
+        __syncthreads();
     }
     if (runs_ok) {
         // centre cell sits inside the middle run
@@ -1494,7 +1659,7 @@ __device__ __forceinline__ void compact_candidates(const CbArgs &a, WaveNbh &h)
     constexpr int MAXC = 8;                       // chunks of 64 candidates per wavefront held in registers
     const int lane = wave_lane(), wv = team_wave<NW>();
     const int nchunk = (h.ncand + PMC_WAVE - 1) / PMC_WAVE;
-    if (!a.filter || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW || nchunk > 32) return;   // segoff holds 32 chunk counts
+    if (h.compacted || !a.filter || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW || nchunk > 32) return;   // segoff holds 32 chunk counts
     // box centre (in the frame of the first centre particle) and padded half width; candidates in
     // another periodic image are brought to the box by the minimum image (|t| <= 2 w <= L/2)
     double bc[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
@@ -2223,7 +2388,10 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     decode_cell<D>(a, colour, aidx, cell, lin);
     h.lin = lin;
     PMC_T(t_1);
-    stage_neighbourhood<D, MULTI, NW>(a, cell, h, a.fused ? colour : 0);
+    // (teams of 4 and 8 are for small systems, where a visit is one latency chain and LDS is plentiful: the fused staging's
+    // count exchange costs them 5-8 %)
+    constexpr bool FUSE = PMC_FUSED_STAGE && NW <= 2;
+    stage_neighbourhood<D, MULTI, NW, FUSE>(a, cell, h, a.fused ? colour : 0);
     PMC_T(t_2);
     const int nc = h.nc;
     if (nc == 0) { if (a.fused) publish_done(a, lin, tid == 0); return; }
@@ -2232,13 +2400,16 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
         if (a.fused) publish_done(a, lin, tid == 0);
         return;
     }
+    // histogram of the box-filtered neighbourhood sizes, in steps of 64: the host sizes the LDS staging of the next call
+    // from it (pmc_hip.hip: cb_cap_sweep)
+    if (FUSE && tid == 0) atomicAdd(&st[PMC_STAT_KEPT + min((h.kept + 63) >> 6, 15)], 1ull);
     compact_candidates<D, MULTI, NW>(a, h);
     cell_bounds<D>(a, h);
     FRegs fr;
     prepare_filter<D>(a, h, fr);
     PMC_T(t_3);
 #ifdef PMC_DEBUG_COUNT   // profiling builds only
-    if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], (unsigned long long)h.bounds); atomicAdd(&st[24], (unsigned long long)h.nseg); }
+    if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], (unsigned long long)h.bounds); atomicAdd(&st[24], (unsigned long long)h.nseg); atomicAdd(&st[28], (unsigned long long)h.compacted); atomicAdd(&st[29], (unsigned long long)h.filt); atomicAdd(&st[30], (unsigned long long)h.ncand * (unsigned long long)h.ncand); }
 #endif
 
     // multi-move pools count per move in LDS (cnt[0..7] attempted, cnt[8..15] accepted); a
@@ -2635,8 +2806,8 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
 //    kernel from 84 to 188 VGPRs -- or 128 with scratch spills -- and chunks of tickets let workgroups run ahead by more
 //    than one colour, so cells stall on their neighbours: 1.65 ms against 1.41 ms at N = 10^6.)
 // ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
-template <int D, int KIND, bool MULTI, int NW, bool ONE>
-__global__ __launch_bounds__(NW * 64, (NW == 1 ? 3 : PMC_CB_MINWAVES)) void k_cb_pass(const CbArgs *__restrict__ args, int nrep)
+template <int D, int KIND, bool MULTI, int NW, bool ONE, int MW = PMC_CB_MINWAVES>   // MW: wavefronts per SIMD it is compiled for
+__global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restrict__ args, int nrep)
 {
     // The arguments of a launch live in DEVICE memory, one CbArgs per replica of the launch (one for a single system,
     // n for pmc_sweep_many), written once per call for all its sweeps.  They are only ever read through references:
