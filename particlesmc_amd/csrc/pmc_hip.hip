@@ -3,6 +3,24 @@
 #include "../../include/pmc.h"
 #include "pmc_kernels.h"
 
+// The instances of the sweep kernel are compiled in their own translation units (pmc_cb_inst.hip, one per dimension and
+// model kind, in parallel); here they are only declared.  -DPMC_SINGLE_TU (and the development builds) keep everything
+// in this file.
+#if !defined(PMC_SINGLE_TU) && !defined(PMC_DEV_BUILD)
+#define PMC_DECL_3_0(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<3, 0, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_3_1(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<3, 1, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_3_2(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<3, 2, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_3_3(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<3, 3, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_3_4(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<3, 4, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_2_0(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<2, 0, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_2_1(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<2, 1, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_2_2(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<2, 2, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_2_3(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<2, 3, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+#define PMC_DECL_2_4(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<2, 4, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
+PMC_CB_VARIANTS(PMC_DECL_3_0) PMC_CB_VARIANTS(PMC_DECL_3_1) PMC_CB_VARIANTS(PMC_DECL_3_2) PMC_CB_VARIANTS(PMC_DECL_3_3) PMC_CB_VARIANTS(PMC_DECL_3_4)
+PMC_CB_VARIANTS(PMC_DECL_2_0) PMC_CB_VARIANTS(PMC_DECL_2_1) PMC_CB_VARIANTS(PMC_DECL_2_2) PMC_CB_VARIANTS(PMC_DECL_2_3) PMC_CB_VARIANTS(PMC_DECL_2_4)
+#endif
+
 #include <rccl/rccl.h>     // types only: the library itself is opened with dlopen on first use
 #include <dlfcn.h>
 

@@ -19,6 +19,18 @@
 #ifndef PMC_CB_MINWAVES
 #define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget)
 #endif
+// The kernels that are not templates belong to pmc_hip.hip alone; the translation units that only instantiate k_cb_pass
+// (pmc_cb_inst.hip, compiled in parallel) see them as unused statics.
+#ifdef PMC_INST_ONLY
+#define PMC_GLOBAL static __global__
+#else
+#define PMC_GLOBAL __global__
+#endif
+// every k_cb_pass<D, KIND, ...> the host dispatches, for one (D, KIND): X(MULTI, NW, ONE, MW)
+#define PMC_CB_VARIANTS_NW(X, NW, MW) X(false, NW, false, MW) X(false, NW, true, MW) X(true, NW, false, MW) X(true, NW, true, MW)
+#define PMC_CB_VARIANTS(X)                                                                                   \
+    PMC_CB_VARIANTS_NW(X, 1, 3) PMC_CB_VARIANTS_NW(X, 1, 4) PMC_CB_VARIANTS_NW(X, 2, PMC_CB_MINWAVES)         \
+    PMC_CB_VARIANTS_NW(X, 4, PMC_CB_MINWAVES) PMC_CB_VARIANTS_NW(X, 8, PMC_CB_MINWAVES)
 #define PMC_REF_IDS 2048     // neighbourhood size (ids) the ordered-energy LDS buffer holds (8 KB: 20 wavefronts per CU)
 #define PMC_MAXNN 27
 #define PMC_REC 12           // doubles per slot record: old xyz, new xyz, dE, T ln u, LDS slot i, valid, LDS slot j, move
@@ -116,7 +128,7 @@ __global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, in
 }
 
 // pass B: place ids by ticket (order inside a cell still depends on atomic arrival)
-__global__ void k_mc_bin_b(const int *__restrict__ cell_of, const int *__restrict__ arrival, int N,
+PMC_GLOBAL void k_mc_bin_b(const int *__restrict__ cell_of, const int *__restrict__ arrival, int N,
                            const int *__restrict__ start, int *__restrict__ tmp_ids)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,7 +229,7 @@ __global__ void k_many_bin_a(int N, GridGeom g, const ManyRep *__restrict__ reps
 
 // exclusive scan of every replica's cell counts, one block per replica (grids of <= PMC_SCAN_SMALL_MAX cells)
 __device__ __forceinline__ int block_inclusive_scan_1024(int v, int *wsum);
-__global__ __launch_bounds__(1024) void k_many_scan(int ncell, const ManyRep *__restrict__ reps)
+PMC_GLOBAL __launch_bounds__(1024) void k_many_scan(int ncell, const ManyRep *__restrict__ reps)
 {
     __shared__ int wsum[16];
     __shared__ int last;
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(1024) void k_many_scan(int ncell, const ManyRep *__
     if (threadIdx.x == 0) start[ncell] = carry;
 }
 
-__global__ void k_many_bin_b(int N, const ManyRep *__restrict__ reps)
+PMC_GLOBAL void k_many_bin_b(int N, const ManyRep *__restrict__ reps)
 {
     const ManyRep &r = reps[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,7 +300,7 @@ __device__ __forceinline__ int block_inclusive_scan_1024(int v, int *wsum)
     return x + base;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_tiles(const int *__restrict__ count, int n, int *__restrict__ tile_sum)
+PMC_GLOBAL __launch_bounds__(1024) void k_scan_tiles(const int *__restrict__ count, int n, int *__restrict__ tile_sum)
 {
     __shared__ int wsum[16];
     int i = blockIdx.x * PMC_SCAN_TILE + threadIdx.x;
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int *__restrict__ cou
     if (threadIdx.x == 1023) tile_sum[blockIdx.x] = incl;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_tops(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total)
+PMC_GLOBAL __launch_bounds__(1024) void k_scan_tops(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total)
 {
     __shared__ int wsum[16];
     int carry = 0;
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_scan_tops(int *__restrict__ tile_sum, 
     if (threadIdx.x == 0) *total = carry;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_apply(int *__restrict__ count, int n, const int *__restrict__ tile_sum,
+PMC_GLOBAL __launch_bounds__(1024) void k_scan_apply(int *__restrict__ count, int n, const int *__restrict__ tile_sum,
                                                      const int *__restrict__ total, int *__restrict__ start, int zero)
 {
     __shared__ int wsum[16];
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(1024) void k_scan_apply(int *__restrict__ count, in
 // the whole exclusive scan in one launch for small grids: one block walks the counts tile by tile (coalesced),
 // carrying the running total; larger grids take the three-launch scan (one block would serialise them)
 #define PMC_SCAN_SMALL_MAX 8192
-__global__ __launch_bounds__(1024) void k_scan_small(int *__restrict__ count, int n, int *__restrict__ start, int zero)
+PMC_GLOBAL __launch_bounds__(1024) void k_scan_small(int *__restrict__ count, int n, int *__restrict__ start, int zero)
 {
     __shared__ int wsum[16];
     __shared__ int last;
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(256) void k_order_hist(const int *__restrict__ star
         if (lh[k]) atomicAdd(&hist[k], lh[k]);
 }
 
-__global__ void k_order_scan(int *__restrict__ hist, int ncol)   // one wave per colour, 256 buckets
+PMC_GLOBAL void k_order_scan(int *__restrict__ hist, int ncol)   // one wave per colour, 256 buckets
 {
     int col = blockIdx.x;
     if (col >= ncol) return;
@@ -425,13 +437,13 @@ __global__ __launch_bounds__(256) void k_order_fill(const int *__restrict__ star
     if (bin >= 0) order[col * nactive + lh[bin] + rank] = lin;
 }
 
-__global__ void k_count(const int *__restrict__ cell_of, int N, int *__restrict__ count)
+PMC_GLOBAL void k_count(const int *__restrict__ cell_of, int N, int *__restrict__ count)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) atomicAdd(&count[cell_of[i]], 1);
 }
 
-__global__ void k_scatter(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+PMC_GLOBAL void k_scatter(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
                           int *__restrict__ fill, int *__restrict__ tmp_ids)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,7 +455,7 @@ __global__ void k_scatter(const int *__restrict__ cell_of, int N, const int *__r
 
 // rank of each particle inside its cell by id -> deterministic order whatever
 // order the atomics of k_scatter ran in
-__global__ void k_rank(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+PMC_GLOBAL void k_rank(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
                        const int *__restrict__ tmp_ids, int *__restrict__ ids)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,7 +469,7 @@ __global__ void k_rank(const int *__restrict__ cell_of, int N, const int *__rest
 
 // head/list exactly as build_neighbour_list! leaves them (src/neighbours.jl:259-267):
 // every chain runs through the cell's particles in DESCENDING id.
-__global__ void k_ref_links(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
+PMC_GLOBAL void k_ref_links(const int *__restrict__ cell_of, int N, const int *__restrict__ start,
                             const int *__restrict__ ids, int ncell, int *__restrict__ head,
                             int *__restrict__ list, int *__restrict__ ccount)
 {
@@ -771,7 +783,7 @@ __device__ void ref_update_list(const RefArgs &a, int i, const double *x, int *l
 }
 
 // build_neighbour_list!(::CellList): cells[c] = ids in ascending order (push! in the loop over i)
-__global__ void k_ref_cellvec(int N, const int *__restrict__ cell_of, const int *__restrict__ start,
+PMC_GLOBAL void k_ref_cellvec(int N, const int *__restrict__ cell_of, const int *__restrict__ start,
                               const int *__restrict__ ids, int ncell, int *__restrict__ items, int cap,
                               int *__restrict__ ccount, int *__restrict__ err)
 {
@@ -1055,7 +1067,7 @@ struct BiasArgs {
 // One workgroup.  For each of the two species: w_k = exp(theta e_k) over sp_ids[species] in list order (parallel),
 // S = sum(w) in Julia's pairwise order (one thread: the order is the result), p_k = w_k / S (parallel), and either the
 // inverse-CDF pick `cp <= u` of rand(rng, Categorical(p)) (src/moves.jl:274-277) or nothing (log density of a given pair).
-__global__ __launch_bounds__(256) void k_energy_bias(BiasArgs a)
+PMC_GLOBAL __launch_bounds__(256) void k_energy_bias(BiasArgs a)
 {
     __shared__ double s_sum;
     __shared__ int s_pick;
@@ -2931,7 +2943,7 @@ __global__ __launch_bounds__(64) void k_delta_e(CbArgs a, int n, const int *__re
 
 // Sum the counter copies 1 .. PMC_NSHARD-1 into copy 0 and clear them: one block per counter, one thread per copy
 // (counter 17 holds error flags: OR).  Runs once per pmc_sweep call, after its last sweep.
-__global__ __launch_bounds__(PMC_NSHARD) void k_stats_fold(unsigned long long *__restrict__ stats)
+PMC_GLOBAL __launch_bounds__(PMC_NSHARD) void k_stats_fold(unsigned long long *__restrict__ stats)
 {
     __shared__ unsigned long long red[PMC_NSHARD / 64];
     const int idx = blockIdx.x, t = threadIdx.x;
@@ -2956,7 +2968,7 @@ __global__ __launch_bounds__(PMC_NSHARD) void k_stats_fold(unsigned long long *_
 }
 
 // test hook: the guard-free division against the IEEE one
-__global__ void k_debug_div(int n, const double *__restrict__ num, const double *__restrict__ den,
+PMC_GLOBAL void k_debug_div(int n, const double *__restrict__ num, const double *__restrict__ den,
                             double *__restrict__ q_ieee, double *__restrict__ q_fast)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2965,7 +2977,7 @@ __global__ void k_debug_div(int n, const double *__restrict__ num, const double 
     q_fast[i] = dev_div_inrange(num[i], den[i]);
 }
 
-__global__ void k_debug_rng(int n, const uint32_t *__restrict__ w1, const uint32_t *__restrict__ w2,
+PMC_GLOBAL void k_debug_rng(int n, const uint32_t *__restrict__ w1, const uint32_t *__restrict__ w2,
                             double *__restrict__ z0, double *__restrict__ z1, double *__restrict__ lnu)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
