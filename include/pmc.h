@@ -97,7 +97,8 @@ typedef struct {
     double sweep_kernel_ms; /* of which: the dE/Metropolis kernel alone */
     int64_t sweep_kernel_launches; /* its launches in the timed sweeps: one per sweep (all colours fused), 2^d with PMC_NO_FUSED=1 */
     /* work counters of the throughput engine, counted by the kernel (0 in PMC_SEQUENTIAL mode): */
-    int64_t pair_tests;       /* (slot, candidate, old|new position) distance tests */
+    int64_t pair_tests;       /* (slot, candidate, old|new position) distance tests: a WORK counter -- it depends on the LDS staging
+                                 capacity a launch was sized with (learnt from earlier sweeps), the results do not */
     int64_t pairs_in_range;   /* pair energies evaluated (r2 <= rcut2, src/atoms.jl:72) */
     int64_t null_moves;       /* attempted slots that evaluated no dE: Displacements that would leave their cell, swaps in a cell lacking a species */
 } pmc_stats;

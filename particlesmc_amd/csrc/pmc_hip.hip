@@ -1249,6 +1249,11 @@ static void cb_cap_learn(pmc_system *h, const unsigned long long *cum)
     int b = 15;
     while (b > 1 && above + bk[b] <= total / 500) above += bk[b--];
     h->cap_hint = b >= 15 ? PMC_CAP_MAX : 64 * b;
+    if (getenv("PMC_DEBUG_CAP")) {
+        fprintf(stderr, "[pmc cap] visits %llu:", total);
+        for (int q = 0; q < 16; q++) if (bk[q]) fprintf(stderr, " <=%d:%llu", 64 * q, bk[q]);
+        fprintf(stderr, " -> %d\n", h->cap_hint);
+    }
 }
 
 static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0, int cap = 0)

@@ -1456,6 +1456,7 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
     h.k0 = a.start[lin_c];
     h.nc = a.start[lin_c + 1] - h.k0;
     int run_start = 0, run_cnt = 0;
+    bool runs_long = false;    // a run of 3 cells longer than a wavefront: stage_compacted takes the 3^D single cells instead
     if (runs_ok) {
         // the run layout keeps the centre cell mid-buffer: only use it when everything fits in LDS
         int tot = 0;
@@ -1477,7 +1478,8 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
 #pragma unroll
         for (int sft = 1; sft < 16; sft <<= 1) tot += __shfl_xor(tot, sft, PMC_WAVE);
         tot = __shfl(tot, 0, PMC_WAVE);
-        runs_ok = tot <= h.cap;
+        runs_long = FUSE && __builtin_amdgcn_ballot_w64(lane < NR && seg_cnt > PMC_WAVE) != 0ull;
+        runs_ok = tot <= h.cap && !runs_long;
         run_start = seg_start;
         run_cnt = seg_cnt;
         if (!runs_ok) { seg_start = 0; seg_cnt = 0; }
@@ -1556,8 +1558,8 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         }
     }
     if (try_fused) {
-        const bool ok = runs_shape ? stage_compacted<D, MULTI, NW>(a, h, run_start, run_cnt, NR)
-                                   : stage_compacted<D, MULTI, NW>(a, h, seg_start, seg_cnt, NN);
+        const bool ok = (runs_shape && !runs_long) ? stage_compacted<D, MULTI, NW>(a, h, run_start, run_cnt, NR)
+                                                   : stage_compacted<D, MULTI, NW>(a, h, seg_start, seg_cnt, NN);
         if (ok) {
             if (tid < min(h.nc, PMC_CFL)) {
                 h.cfl[0 * PMC_CFL + tid] = mc_coord<D>(h.cx[h.ctr + tid], a.shift[0], a.w[0]);

@@ -19,7 +19,10 @@ def _same(a, b, sa, sb):
         assert np.array_equal(a[r].species, b[r].species), r
         assert sa[r].energy_fix == sb[r].energy_fix and np.array_equal(sa[r].accepted, sb[r].accepted), r
         assert np.array_equal(sa[r].attempted, sb[r].attempted)
-        assert (sa[r].pair_tests, sa[r].pairs_in_range, sa[r].null_moves) == (sb[r].pair_tests, sb[r].pairs_in_range, sb[r].null_moves)
+        assert (sa[r].pairs_in_range, sa[r].null_moves) == (sb[r].pairs_in_range, sb[r].null_moves)
+        # a work counter, not a result: how many distance tests it takes depends on the LDS staging capacity the launch was
+        # sized with (learnt per handle; one capacity for all the chains of a shared launch)
+        assert abs(sa[r].pair_tests - sb[r].pair_tests) <= 0.02 * sb[r].pair_tests
         assert a[r].total_energy()[1] == sa[r].energy_fix
 
 
