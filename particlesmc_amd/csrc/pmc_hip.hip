@@ -464,11 +464,12 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         // thousand cells per colour on, one wavefront per cell wastes nothing on the resolution step.  Measured on
         // MI355X (r02, 3-D LJ, moves/s for teams of 1 / 2 / 4 / 8): N=32768 (216 cells per colour) 0.54 / 0.85 / 1.21 /
         // 1.30e8; N=110592 (729) 1.7 / 2.7 / 3.5 / 2.9e8; N=262144 (1728) 3.9 / 5.5 / 5.0 / 3.1e8; N=10^6 (6859)
-        // 7.6 / 7.1 / 5.3 / 3.3e8.  Multi-species kernels carry more registers and a larger LDS footprint per cell:
-        // there two wavefronts per cell stay ahead at every size measured (Kob-Andersen N=10^6: 4.0 vs 5.9e8).
+        // 7.6 / 7.1 / 5.3 / 3.3e8.  Multi-species systems follow the same rule since the box filter is applied while staging
+        // (Kob-Andersen N=10^6, 5832 cells per colour, Displacement only: 7.1 / 5.9 / 4.6e8 for teams of 1 / 2 / 4; before
+        // that change two wavefronts per cell were ahead there, 4.0 vs 5.9e8).
         long long nact = 1;
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
-        h->team = (nact <= 512) ? 8 : ((nact <= 900) ? 4 : ((nact <= 3000 || h->S > 1) ? 2 : 1));
+        h->team = (nact <= 512) ? 8 : ((nact <= 900) ? 4 : ((nact <= 3000) ? 2 : 1));
         // 2-d neighbourhoods hold ~70-100 candidates (two filter trips): N=65536 binary soft spheres (1600 cells per
         // colour) 3.5 / 3.9 / 3.6e8 for teams of 1 / 2 / 4
         if (h->D == 2 && nact > 512) h->team = 2;
@@ -1223,12 +1224,26 @@ static int cb_cap(const pmc_system *h)
 // about 73 % of the 3^d-cell population at w ~ rcut.  How many that is depends on the state (a liquid: 343 +- 9 at
 // N = 10^6; the jittered lattice it started from: 343 .. 512), so the kernel counts the visits by survivor count
 // (stats[PMC_STAT_KEPT..]) and the next launches are sized for all but 0.2 % of them.  Those stage the old way, their
-// overflow read from L2: results never depend on the capacity.  Before the first histogram: the full population.
+// overflow read from L2: results never depend on the capacity.
 static int cb_cap_sweep(const pmc_system *h)
 {
     if (const char *e = getenv("PMC_CAP")) return std::min(std::max(atoi(e) / 64 * 64, 128), PMC_CAP_MAX);   // experiments
-    if (!h->use_filter || !PMC_FUSED_STAGE || h->team > 2 || h->cap_hint <= 0) return cb_cap(h);   // (teams of 4 and 8 stage the old way)
-    return std::min(std::max(h->cap_hint, 128), cb_cap(h));
+    if (!h->use_filter || !PMC_FUSED_STAGE || h->team > 2) return cb_cap(h);   // (teams of 4 and 8 stage the old way)
+    int cap = h->cap_hint;
+    if (cap <= 0) {
+        // nothing learnt yet: the expected population of the centre cell's box grown by the largest cutoff (Steiner's
+        // formula) plus 6 % + 16
+        const double r = h->maxcut * (1.0 + 1e-9), pi = 3.14159265358979323846;
+        const double *w = h->grid.w;
+        double vol = 1.0, v;
+        for (int q = 0; q < h->D; q++) vol *= h->p.box[q];
+        if (h->D == 3)
+            v = w[0] * w[1] * w[2] + 2.0 * r * (w[0] * w[1] + w[1] * w[2] + w[2] * w[0]) + pi * r * r * (w[0] + w[1] + w[2]) + 4.0 / 3.0 * pi * r * r * r;
+        else
+            v = w[0] * w[1] + 2.0 * r * (w[0] + w[1]) + pi * r * r;
+        cap = (int)(((double)h->N / vol * v * 1.06 + 16.0 + 63.0) / 64.0) * 64;
+    }
+    return std::min(std::max(cap, 128), cb_cap(h));
 }
 
 static bool cb_cap_sweep_adapts(const pmc_system *h)
@@ -1712,9 +1727,10 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
         // shader-clock cycles per cell visit, by phase (wavefront 0 of every workgroup; s_memtime)
         const double v = (double)st[47];
         static const char *names[] = {"ticket", "stage+poll", "compact+bounds+fcopy", "slot loop", "writeback+publish",
-                                      "  slot prologue", "  filter", "  dense", "  reduce+accept", "  (slots evaluated)"};
+                                      "  slot prologue", "  filter", "  dense", "  reduce+accept", "  (slots evaluated)",
+                                      "  stage: offsets", "  stage: flags of lower colours", "  stage: coordinates arrive", "  stage: box test + LDS"};
         fprintf(stderr, "[pmc time] visits=%.0f\n", v);
-        for (int k = 0; k < 10; k++) fprintf(stderr, "[pmc time] %-24s %12.1f cycles/visit\n", names[k], (double)st[32 + k] / v);
+        for (int k = 0; k < 14; k++) fprintf(stderr, "[pmc time] %-24s %12.1f cycles/visit\n", names[k], (double)st[32 + k] / v);
     }
 #endif
 #ifdef PMC_DEBUG_COUNT
