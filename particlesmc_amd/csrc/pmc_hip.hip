@@ -1228,7 +1228,7 @@ static int cb_cap(const pmc_system *h)
 static int cb_cap_sweep(const pmc_system *h)
 {
     if (const char *e = getenv("PMC_CAP")) return std::min(std::max(atoi(e) / 64 * 64, 128), PMC_CAP_MAX);   // experiments
-    if (!h->use_filter || !PMC_FUSED_STAGE || h->team > 2) return cb_cap(h);   // (teams of 4 and 8 stage the old way)
+    if (!h->use_filter || !PMC_FUSED_STAGE || h->team > 1) return cb_cap(h);   // (teams stage the old way)
     int cap = h->cap_hint;
     if (cap <= 0) {
         // nothing learnt yet: the expected population of the centre cell's box grown by the largest cutoff (Steiner's
@@ -1248,7 +1248,7 @@ static int cb_cap_sweep(const pmc_system *h)
 
 static bool cb_cap_sweep_adapts(const pmc_system *h)
 {
-    return h->use_filter && PMC_FUSED_STAGE && h->team <= 2 && !getenv("PMC_CAP");
+    return h->use_filter && PMC_FUSED_STAGE && h->team == 1 && !getenv("PMC_CAP");
 }
 
 // `cum`: the call's histogram so far; what was already looked at (kept_seen) is subtracted

@@ -1240,8 +1240,6 @@ struct WaveNbh {
     int k0;        // CSR offset of the centre cell
     int lin;
     bool nowrap;   // every staged candidate is in the same periodic image as the centre cell
-    bool bounds;   // lo/hi below are valid: "stays in the cell" is  lo_a <= x_a < hi_a
-    double lo[3], hi[3];
     double *part;  // [8] per-wavefront partial sums (workgroups of several wavefronts)
     // FP32 pre-filter (wave_delta_e_filtered)
     unsigned short *queue;   // [max(NW,1)][PMC_QCAP] survivor queues, one per wavefront
@@ -1781,41 +1779,6 @@ __device__ __forceinline__ void compact_candidates(const CbArgs &a, WaveNbh &h)
     }
 }
 
-// Exact cell boundaries: g(x) = floor((x - shift) / w) is monotone, so {x : g(x) == f} is an
-// interval [lo, hi) of doubles.  lanes 0..D-1 search lo (target f), lanes 3..3+D-1 search hi
-// (target f + 1) by stepping single ulps from shift + f w; a final check guards the result.
-// Valid only when all centre particles share one unfolded cell (WaveNbh::nowrap).
-template <int D>
-__device__ __forceinline__ void cell_bounds(const CbArgs &a, WaveNbh &h)
-{
-    const int lane = wave_lane();
-    h.bounds = false;
-    if (!h.nowrap) return;
-    const int q = (lane < 3) ? lane : lane - 3;
-    bool ok = true;
-    double x = 0.0;
-    if (lane < 6 && q < D) {
-        const double s = (q == 0) ? a.shift[0] : ((q == 1) ? a.shift[1] : a.shift[2]);
-        const double w = (q == 0) ? a.w[0] : ((q == 1) ? a.w[1] : a.w[2]);
-        const double f = h.cfl[q * PMC_CFL] + ((lane >= 3) ? 1.0 : 0.0);
-        x = s + f * w;
-        for (int it = 0; it < 8; it++) {            // walk down while still inside [f, ...)
-            double xd = nextafter(x, -INFINITY);
-            if (floor((xd - s) / w) >= f) x = xd; else break;
-        }
-        for (int it = 0; it < 8; it++) {            // walk up until inside
-            if (floor((x - s) / w) < f) x = nextafter(x, INFINITY); else break;
-        }
-        ok = (floor((x - s) / w) >= f) && (floor((nextafter(x, -INFINITY) - s) / w) < f);
-    }
-    h.bounds = (__ballot(!ok) == 0ull);
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        h.lo[d] = readlane_double(x, d);
-        h.hi[d] = readlane_double(x, 3 + d);
-    }
-}
-
 template <int D, bool MULTI>
 __device__ __forceinline__ void nbh_load(const CbArgs &a, const WaveNbh &h, int k, double &xj, double &yj,
                                          double &zj, int &sj)
@@ -1975,6 +1938,49 @@ __device__ __forceinline__ void prepare_filter(const CbArgs &a, WaveNbh &h, FReg
     h.filt = (h.nc > 0) && (h.ncand <= h.cap) && (h.ncand <= PMC_FTRIPS * PMC_WAVE);
     if (!h.filt) return;
     if (h.nowrap) load_fregs<D, true>(a, h, f); else load_fregs<D, false>(a, h, f);
+}
+
+// "The proposal stays in its cell": floor((x_new - shift) / w) == floor((x_old - shift) / w) in every dimension.
+// Decided from the FP32 coordinate of the new position relative to the cell's centre (the one the pre-filter uses, folded
+// into the centre's periodic image): |t| < w/2 - e is inside, |t| > w/2 + e is outside, and only in the band between
+// (e = 2^-12 w; the float is within 2^-22 w of the exact offset, the FP64 divisions of the exact test within 2^-50 of
+// their real quotients) -- about one slot in 1500 -- the divisions themselves decide.  This replaced exact cell
+// boundaries found per visit by stepping ulps through that division (~500 instructions per visit).
+template <int D>
+__device__ __forceinline__ bool stays_in_cell(const CbArgs &a, const WaveNbh &h, int p, double xo, double yo, double zo, double xn, double yn,
+                                              double zn, double my_shift, double my_w)
+{
+    const int lane = wave_lane();
+    float t[3] = {0.0f, 0.0f, 0.0f};
+    if (h.nowrap) {
+        t[0] = rel_float<true>(xn, h.bc[0], a.L[0], a.invL[0]);
+        t[1] = rel_float<true>(yn, h.bc[1], a.L[1], a.invL[1]);
+        if (D == 3) t[2] = rel_float<true>(zn, h.bc[2], a.L[2], a.invL[2]);
+    } else {
+        t[0] = rel_float<false>(xn, h.bc[0], a.L[0], a.invL[0]);
+        t[1] = rel_float<false>(yn, h.bc[1], a.L[1], a.invL[1]);
+        if (D == 3) t[2] = rel_float<false>(zn, h.bc[2], a.L[2], a.invL[2]);
+    }
+    // (the fold maps a displacement of about a whole box back onto the cell: such a proposal takes the exact test)
+    bool in = h.nowrap || (fabs(xn - xo) < 0.25 * a.L[0] && fabs(yn - yo) < 0.25 * a.L[1] && (D == 2 || fabs(zn - zo) < 0.25 * a.L[2]));
+    bool out = false;
+    const bool sane = in;
+#pragma unroll
+    for (int q = 0; q < D; q++) {
+        const float hw = (float)(0.5 * a.w[q]), e = hw * (1.0f / 2048.0f);
+        in = in && (fabsf(t[q]) < hw - e);
+        out = out || (fabsf(t[q]) > hw + e);
+    }
+    if (__builtin_amdgcn_ballot_w64(in) != 0ull) return true;       // (every lane holds the same values)
+    if (__builtin_amdgcn_ballot_w64(out && sane) != 0ull) return false;
+    bool bad = false;
+    if (lane < D) {
+        const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
+        const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
+        const double fo = (p < PMC_CFL) ? h.cfl[lane * PMC_CFL + p] : mc_coord<D>(xs_o, my_shift, my_w);
+        bad = mc_coord<D>(xs_n, my_shift, my_w) != fo;
+    }
+    return __ballot(bad) == 0ull;
 }
 
 // an accepted move of the particle in LDS slot pc: the owning lane replaces its float copy
@@ -2436,9 +2442,9 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     decode_cell<D>(a, colour, aidx, cell, lin);
     h.lin = lin;
     PMC_T(t_1);
-    // (teams of 4 and 8 are for small systems, where a visit is one latency chain and LDS is plentiful: the fused staging's
-    // count exchange costs them 5-8 %)
-    constexpr bool FUSE = PMC_FUSED_STAGE && NW <= 2;
+    // (teams are for small and medium systems, where a visit is one latency chain and LDS is plentiful: the fused staging's
+    // count exchange between the wavefronts costs them 2-9 %)
+    constexpr bool FUSE = PMC_FUSED_STAGE && NW == 1;
     stage_neighbourhood<D, MULTI, NW, FUSE>(a, cell, h, a.fused ? colour : 0);
     PMC_T(t_2);
     const int nc = h.nc;
@@ -2452,13 +2458,12 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     // from it (pmc_hip.hip: cb_cap_sweep)
     if (FUSE && tid == 0) atomicAdd(&st[PMC_STAT_KEPT + min((h.kept + 63) >> 6, 15)], 1ull);
     compact_candidates<D, MULTI, NW>(a, h);
-    cell_bounds<D>(a, h);
     FRegs fr;
     prepare_filter<D>(a, h, fr);
     PMC_T(t_3);
     if (NW == 1) __builtin_amdgcn_s_setprio(0);
 #ifdef PMC_DEBUG_COUNT   // profiling builds only
-    if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], (unsigned long long)h.bounds); atomicAdd(&st[24], (unsigned long long)h.nseg); atomicAdd(&st[28], (unsigned long long)h.compacted); atomicAdd(&st[29], (unsigned long long)h.filt); atomicAdd(&st[30], (unsigned long long)h.ncand * (unsigned long long)h.ncand); }
+    if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], 0ull); atomicAdd(&st[24], (unsigned long long)h.nseg); atomicAdd(&st[28], (unsigned long long)h.compacted); atomicAdd(&st[29], (unsigned long long)h.filt); atomicAdd(&st[30], (unsigned long long)h.ncand * (unsigned long long)h.ncand); }
 #endif
 
     // multi-move pools count per move in LDS (cnt[0..7] attempted, cnt[8..15] accepted); a
@@ -2549,19 +2554,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     const double xn = xo + readlane_double(g_dx, my);
                     const double yn = yo + readlane_double(g_dy, my);
                     const double zn = (D == 3) ? zo + readlane_double(g_dz, my) : 0.0;
-                    bool inside;
-                    if (h.bounds) {
-                        inside = (xn >= h.lo[0]) && (xn < h.hi[0]) && (yn >= h.lo[1]) && (yn < h.hi[1]);
-                        if (D == 3) inside = inside && (zn >= h.lo[2]) && (zn < h.hi[2]);
-                    } else {
-                        bool bad = false;
-                        if (lane < D) {
-                            const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
-                            const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
-                            bad = mc_coord<D>(xs_n, my_shift, my_w) != mc_coord<D>(xs_o, my_shift, my_w);
-                        }
-                        inside = (__ballot(bad) == 0ull);
-                    }
+                    const bool inside = stays_in_cell<D>(a, h, pc - h.ctr, xo, yo, zo, xn, yn, zn, my_shift, my_w);
                     double de = 0.0;
                     if (inside) {
                         const int si = MULTI ? (int)h.csp[pc] : 0;
@@ -2731,21 +2724,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                 const double xn = xo + readlane_double(g_dx, s);
                 const double yn = yo + readlane_double(g_dy, s);
                 const double zn = (D == 3) ? zo + readlane_double(g_dz, s) : 0.0;
-                // "stays in its cell"  <=>  floor((x_new - shift)/w) == floor((x_old - shift)/w)
-                bool inside;
-                if (h.bounds) {
-                    inside = (xn >= h.lo[0]) && (xn < h.hi[0]) && (yn >= h.lo[1]) && (yn < h.hi[1]);
-                    if (D == 3) inside = inside && (zn >= h.lo[2]) && (zn < h.hi[2]);
-                } else {
-                    bool bad = false;
-                    if (lane < D) {
-                        const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
-                        const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
-                        const double fo = (p < PMC_CFL) ? h.cfl[lane * PMC_CFL + p] : mc_coord<D>(xs_o, my_shift, my_w);
-                        bad = mc_coord<D>(xs_n, my_shift, my_w) != fo;
-                    }
-                    inside = (__ballot(bad) == 0ull);
-                }
+                const bool inside = stays_in_cell<D>(a, h, p, xo, yo, zo, xn, yn, zn, my_shift, my_w);
                 if (inside) {
                     // one wavefront per cell here (teams of NW >= 2 take the batch branch above)
                     const int si = MULTI ? (int)h.csp[pc] : 0;

@@ -20,18 +20,40 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
+TIMED = 4      # the PMC passes run `bench.py --steps 4`: the last 4 launches of the sweep kernel are the timed region
+
+
 def counters(sub):
+    """kernel -> counter -> values per launch; for the sweep kernel only the launches of the timed region (the last TIMED
+    dispatches: the run starts from the lattice and equilibrates first, see bench.py)"""
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     files = sorted(glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     for f in files[-1:]:                      # newest run only
+        rows = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rows[r["Kernel_Name"]][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        for k, v in rows.items():
+            for c, vals in v.items():
+                vals.sort()
+                out[k][c] = [x for _, x in (vals[-TIMED:] if "k_cb_pass" in k else vals)]
     return out
 
 
 stats = sorted(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if stats:
     shutil.copy(stats[-1], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+# the same run's per-dispatch trace, averaged over the timed region only (the last 20 launches of `bench.py --steps 20`)
+traces = sorted(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+if traces:
+    d = sorted((int(r["Dispatch_Id"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+               for r in csv.DictReader(open(traces[-1])) if "k_cb_pass" in r["Kernel_Name"])
+    timed = [x for _, x in d[-20:]]
+    json.dump({"kernel": "k_cb_pass", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu",
+               "launches_in_run": len(d), "all_launches_avg_ms": sum(x for _, x in d) / max(1, len(d)),
+               "timed_region_launches": len(timed), "timed_region_avg_ms": sum(timed) / max(1, len(timed)),
+               "note": "the --stats summary averages all launches (lattice start + 1000 equilibration sweeps + timed steps); the timed "
+                       "region is the last 20 dispatches of the same trace"},
+              open(os.path.join(ROOT, "profiles", f"{tag}_timed_region.json"), "w"), indent=1)
 summary = {}
 for sub in ("fetch", "write", "sq", "sq2"):
     for k, v in counters(sub).items():
@@ -43,7 +65,8 @@ for k, v in summary.items():
         fetch_kib, write_kib = v["FETCH_SIZE"]["mean"], v["WRITE_SIZE"]["mean"]
         traffic = {
             "kernel": k, "round": tag, "lattice": 100,
-            "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 1 --no-cpu`, builder's lease)",
+            "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 1 --equilibrate 600 --no-cpu`, "
+                      "the 4 timed launches, builder's lease)",
             "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
             "k_cb_pass_hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
             "moves_per_launch": 1000000,
@@ -54,7 +77,8 @@ for k, v in summary.items():
         }
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
         print(traffic)
-for src, dst in (("bench_full.json", f"{tag}_bench.json"), ("bench_equilibrated.json", f"{tag}_bench_equilibrated.json")):
+for src, dst in (("bench_full.json", f"{tag}_bench.json"), ("bench_equilibrated.json", f"{tag}_bench_equilibrated.json"),
+                 ("bench_lattice.json", f"{tag}_bench_lattice.json")):
     bj = os.path.join(SRC, src)
     if os.path.exists(bj):
         line = [l for l in open(bj) if l.startswith('{"metric"')]
