@@ -88,6 +88,7 @@ struct pmc_system {
     unsigned long long *d_ticket = nullptr;
     unsigned int epoch = 0;
     unsigned long long ticket_next = 0;
+    int ticket_lanes = PMC_TICKET_LANES;   // 8: one ticket counter per XCD, zeroed every sweep; 1: one monotonic counter (PMC_TICKETS=1)
     int team = 1;                // wavefronts that share one cell in k_cb_pass (1, 2 or 4)
     double maxcut = 0.0;
     bool use_filter = true;
@@ -489,8 +490,9 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         CR(hipMalloc(&h->d_slot_m, N));
         CR(hipMalloc(&h->d_done, (size_t)h->ncell_mc * sizeof(unsigned int)));
         CR(hipMemset(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int)));
-        CR(hipMalloc(&h->d_ticket, 16));
-        CR(hipMemset(h->d_ticket, 0, 16));
+        CR(hipMalloc(&h->d_ticket, PMC_TICKET_LANES * PMC_TICKET_STRIDE * sizeof(unsigned long long)));
+        CR(hipMemset(h->d_ticket, 0, PMC_TICKET_LANES * PMC_TICKET_STRIDE * sizeof(unsigned long long)));
+        if (const char *e = getenv("PMC_TICKETS")) h->ticket_lanes = atoi(e) == 1 ? 1 : PMC_TICKET_LANES;
         if (const char *e = getenv("PMC_NO_FUSED")) h->use_fused = !(e[0] == '1');
         if (const char *e = getenv("PMC_FUSED_LPT")) h->fused_lpt = (e[0] == '1') ? 1 : 0;
     }
@@ -1149,8 +1151,9 @@ static int mc_bin(pmc_system *h, const double shift[3], const SlotGen *slots = n
     if (slots) gen = *slots;
     // the scan of the previous throughput binning left the counters zeroed (k_scan_*: zero = 1)
     if (!h->count_is_zero) HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)h->ncell_mc + 1) * sizeof(int), h->stream));
-    if (h->D == 3) hipLaunchKernelGGL(k_mc_bin_a<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival);
-    else hipLaunchKernelGGL(k_mc_bin_a<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival);
+    unsigned long long *const t8 = h->ticket_lanes == PMC_TICKET_LANES ? h->d_ticket : nullptr;
+    if (h->D == 3) hipLaunchKernelGGL(k_mc_bin_a<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival, t8);
+    else hipLaunchKernelGGL(k_mc_bin_a<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival, t8);
     if (int rc = scan_counts(h, h->ncell_mc, h->d_start, 1)) return rc;
     h->count_is_zero = true;
     hipLaunchKernelGGL(k_mc_bin_b, dim3(nb), dim3(256), 0, h->stream, h->d_cell_of, h->d_arrival, N, h->d_start, h->d_tmp_ids);
@@ -1193,6 +1196,7 @@ static CbArgs cb_args(pmc_system *h)
         a.shift[q] = h->grid.shift[q];
         a.L[q] = q < h->D ? h->p.box[q] : 1.0;
         a.invL[q] = 1.0 / a.L[q];
+        a.invw[q] = 1.0 / a.w[q];
     }
     a.temperature = h->p.temperature;
     a.start = h->d_start; a.ids = h->d_ids;
@@ -1635,9 +1639,10 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
                 a.epoch = ++h->epoch;
                 a.done = h->d_done;
                 a.ticket = h->d_ticket;
+                a.ticket_lanes = h->ticket_lanes;
                 a.ticket_base = h->ticket_next;
                 a.colour = 0;
-                h->ticket_next += (unsigned long long)(ncol * nactive);
+                if (h->ticket_lanes == 1) h->ticket_next += (unsigned long long)(ncol * nactive);
                 tabh[(size_t)k] = a;
             } else {
                 for (int col = 0; col < ncol; col++) {
@@ -1958,6 +1963,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
                 a.epoch = st.epoch;
                 a.done = h->d_done;
                 a.ticket = m->d_ticket;
+                a.ticket_lanes = m->ticket_lanes;
                 a.ticket_base = m->ticket_next + (unsigned long long)sw * (unsigned long long)grid;
                 a.colour = 0;
                 argsh[(size_t)(sw * n + r)] = a;
@@ -1969,8 +1975,9 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         for (int64_t sw = 0; sw < ns; sw++) {
             const ManyRep *dr = d_reps.as<ManyRep>();
             const ManyStep *ds = d_steps.as<ManyStep>() + sw * n;
-            if (m->D == 3) hipLaunchKernelGGL(k_many_bin_a<3>, dim3(nb, n), dim3(256), 0, m->stream, N, m->grid, dr, ds);
-            else hipLaunchKernelGGL(k_many_bin_a<2>, dim3(nb, n), dim3(256), 0, m->stream, N, m->grid, dr, ds);
+            unsigned long long *const t8 = m->ticket_lanes == PMC_TICKET_LANES ? m->d_ticket : nullptr;
+            if (m->D == 3) hipLaunchKernelGGL(k_many_bin_a<3>, dim3(nb, n), dim3(256), 0, m->stream, N, m->grid, dr, ds, t8);
+            else hipLaunchKernelGGL(k_many_bin_a<2>, dim3(nb, n), dim3(256), 0, m->stream, N, m->grid, dr, ds, t8);
             hipLaunchKernelGGL(k_many_scan, dim3(n), dim3(1024), 0, m->stream, m->ncell_mc, dr);
             hipLaunchKernelGGL(k_many_bin_b, dim3(nb, n), dim3(256), 0, m->stream, N, dr);
             if (m->D == 3) hipLaunchKernelGGL(k_many_bin_c<3>, dim3(nb, n), dim3(256), 0, m->stream, N, mp, dr, ds);
@@ -1979,7 +1986,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             DISPATCH_CB(m, grid, lds, args);
             HIPCHK(m, hipGetLastError());
         }
-        m->ticket_next += (unsigned long long)ns * (unsigned long long)grid;
+        if (m->ticket_lanes == 1) m->ticket_next += (unsigned long long)ns * (unsigned long long)grid;
     }
     HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
     for (int r = 0; r < n; r++) {

@@ -120,10 +120,15 @@ __device__ __forceinline__ void mc_bin_a_body(const double *__restrict__ pos, in
     arrival[i] = base + (lane - my_head);
 }
 
+#define PMC_TICKET_LANES 8     // ticket counters of a fused sweep (k_cb_pass), one per XCD
+#define PMC_TICKET_STRIDE 16   // ... 128 B apart
+
+// (ticket8: the fused sweep's ticket counters start every sweep at 0 -- this is the first kernel of a sweep)
 template <int D>
 __global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of,
-                           int *__restrict__ count, int *__restrict__ arrival)
+                           int *__restrict__ count, int *__restrict__ arrival, unsigned long long *__restrict__ ticket8)
 {
+    if (ticket8 && blockIdx.x == 0 && threadIdx.x < PMC_TICKET_LANES) ticket8[threadIdx.x * PMC_TICKET_STRIDE] = 0ull;
     mc_bin_a_body<D>(pos, N, g, cell_of, count, arrival);
 }
 
@@ -218,8 +223,10 @@ struct ManyStep {
 };
 
 template <int D>
-__global__ void k_many_bin_a(int N, GridGeom g, const ManyRep *__restrict__ reps, const ManyStep *__restrict__ steps)
+__global__ void k_many_bin_a(int N, GridGeom g, const ManyRep *__restrict__ reps, const ManyStep *__restrict__ steps,
+                             unsigned long long *__restrict__ ticket8)
 {
+    if (ticket8 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < PMC_TICKET_LANES) ticket8[threadIdx.x * PMC_TICKET_STRIDE] = 0ull;
     const ManyRep &r = reps[blockIdx.y];
     const ManyStep &st = steps[blockIdx.y];
 #pragma unroll
@@ -1155,6 +1162,7 @@ struct CbArgs {
     int n[3];
     int half[3];
     double w[3], shift[3], L[3], invL[3];
+    double invw[3];            // 1 / w, for estimates only (cell_coord_fast): the reference arithmetic divides by w
     double temperature;
     const int *start;
     const int *ids;
@@ -1185,8 +1193,14 @@ struct CbArgs {
     int fused;                 // 1: grid = 2^d * nactive workgroups, colour taken from the ticket
     unsigned int epoch;        // value a cell's flag takes when its visit of this sweep is complete
     unsigned int *done;        // [ncell] completion flags (agent-scope stores / polls)
-    unsigned long long *ticket;    // monotonic workgroup ticket; this launch owns [ticket_base, ticket_base + grid)
+    // Workgroup tickets.  ticket_lanes == 8 (default): eight counters, 128 B apart, zeroed by the first kernel of every sweep;
+    // workgroup b draws from counter b mod 8 -- its XCD's, workgroups being dealt round-robin to the XCDs -- and ticket t of
+    // counter x is visit 8 t + x.  One counter took 11 ns per atomic from the whole chip: 0.62 ms for the 54 872 visits of a
+    // sweep at N = 10^6, the floor the kernel was within 30 % of.  ticket_lanes == 1 (PMC_TICKETS=1): that single counter,
+    // monotonic across launches, this launch owning [ticket_base, ticket_base + grid).
+    unsigned long long *ticket;
     unsigned long long ticket_base;
+    int ticket_lanes;
 };
 
 // Agent-scope accesses of the data that workgroups of one fused launch hand to each other (the
@@ -1228,7 +1242,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 
 struct WaveNbh {
     double *cx, *cy, *cz;
-    double *cfl;   // [D][PMC_CFL]: floor((x - shift) / w) of the first centre-cell particles
+    double *cfl;   // [D][PMC_CFL]: floor((x - shift) / w) of the first centre-cell particles (have_cfl; not after stage_compacted)
+    bool have_cfl;
+    double fc[3];  // floor((x - shift) / w) of the first centre-cell particle
     int cap;
     unsigned char *csp;
     int *segoff;   // nseg + 1 prefix offsets of the staged segments
@@ -1276,6 +1292,17 @@ __device__ __forceinline__ int nbh_find(const WaveNbh &h, int k)
     return h.segsrc[lo] + (k - h.segoff[lo]);
 }
 
+// floor((x - shift) / w) for a wave-uniform x: the product with 1/w decides unless it lands within 2^-30 of an integer (its
+// error is below 2^-45 for any grid this engine accepts), where the division of the reference arithmetic (mc_coord) does.
+template <int D>
+__device__ __forceinline__ double cell_coord_fast(double x, double shift, double w, double invw)
+{
+    const double q = (x - shift) * invw, f = floor(q), r = q - f;
+    const bool unsure = !(r > 0x1p-30 && r < 1.0 - 0x1p-30);
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) return mc_coord<D>(x, shift, w);
+    return f;
+}
+
 // Fused staging: the segments of the neighbourhood (runs of 3 cells, or single cells) go from global memory to registers,
 // are tested against the centre cell's box there (the test of compact_candidates below, same arithmetic), and only the
 // survivors are written to LDS, already compacted.  The staging capacity then only has to hold the ~73 % of a 3^d-cell
@@ -1319,7 +1346,8 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
             const double ref[3] = {xr, yr, zr};
 #pragma unroll
             for (int q = 0; q < D; q++) {
-                bc[q] = a.shift[q] + (mc_coord<D>(ref[q], a.shift[q], a.w[q]) + 0.5) * a.w[q];
+                h.fc[q] = cell_coord_fast<D>(ref[q], a.shift[q], a.w[q], a.invw[q]);
+                bc[q] = a.shift[q] + (h.fc[q] + 0.5) * a.w[q];
                 bh[q] = 0.5 * a.w[q] * (1.0 + 1e-9);
             }
             have_box = true;
@@ -1586,12 +1614,8 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         const bool ok = (runs_shape && !runs_long) ? stage_compacted<D, MULTI, NW>(a, h, run_start, run_cnt, NR)
                                                    : stage_compacted<D, MULTI, NW>(a, h, seg_start, seg_cnt, NN);
         if (ok) {
-            if (tid < min(h.nc, PMC_CFL)) {
-                h.cfl[0 * PMC_CFL + tid] = mc_coord<D>(h.cx[h.ctr + tid], a.shift[0], a.w[0]);
-                h.cfl[1 * PMC_CFL + tid] = mc_coord<D>(h.cy[h.ctr + tid], a.shift[1], a.w[1]);
-                if (D == 3) h.cfl[2 * PMC_CFL + tid] = mc_coord<D>(h.cz[h.ctr + tid], a.shift[2], a.w[2]);
-            }
-            __syncthreads();
+            h.have_cfl = false;        // (h.fc is set; the rare exact 'stays in its cell' test divides for itself)
+            __syncthreads();           // the segment table of the compacted layout is visible
 #ifdef PMC_DEBUG_TIME
             h.ts[4] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1687,6 +1711,9 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         if (D == 3) h.cfl[2 * PMC_CFL + tid] = mc_coord<D>(h.cz[h.ctr + tid], a.shift[2], a.w[2]);
     }
     __syncthreads();
+    h.have_cfl = true;
+#pragma unroll
+    for (int q = 0; q < 3; q++) h.fc[q] = (q < D && h.nc > 0) ? h.cfl[q * PMC_CFL] : 0.0;
 }
 
 // Box filter.  A candidate farther than the largest cutoff from the centre cell's box is out of
@@ -1707,7 +1734,7 @@ __device__ __forceinline__ void compact_candidates(const CbArgs &a, WaveNbh &h)
     double bc[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < D; q++) {
-        const double f = h.cfl[q * PMC_CFL];
+        const double f = h.fc[q];
         bc[q] = a.shift[q] + (f + 0.5) * a.w[q];
         bh[q] = 0.5 * a.w[q] * (1.0 + 1e-9);
     }
@@ -1934,7 +1961,7 @@ template <int D>
 __device__ __forceinline__ void prepare_filter(const CbArgs &a, WaveNbh &h, FRegs &f)
 {
 #pragma unroll
-    for (int q = 0; q < 3; q++) h.bc[q] = (q < D) ? a.shift[q] + (h.cfl[q * PMC_CFL] + 0.5) * a.w[q] : 0.0;
+    for (int q = 0; q < 3; q++) h.bc[q] = (q < D) ? a.shift[q] + (h.fc[q] + 0.5) * a.w[q] : 0.0;
     h.filt = (h.nc > 0) && (h.ncand <= h.cap) && (h.ncand <= PMC_FTRIPS * PMC_WAVE);
     if (!h.filt) return;
     if (h.nowrap) load_fregs<D, true>(a, h, f); else load_fregs<D, false>(a, h, f);
@@ -1977,7 +2004,7 @@ __device__ __forceinline__ bool stays_in_cell(const CbArgs &a, const WaveNbh &h,
     if (lane < D) {
         const double xs_n = (lane == 0) ? xn : ((lane == 1) ? yn : zn);
         const double xs_o = (lane == 0) ? xo : ((lane == 1) ? yo : zo);
-        const double fo = (p < PMC_CFL) ? h.cfl[lane * PMC_CFL + p] : mc_coord<D>(xs_o, my_shift, my_w);
+        const double fo = (h.have_cfl && p < PMC_CFL) ? h.cfl[lane * PMC_CFL + p] : mc_coord<D>(xs_o, my_shift, my_w);
         bad = mc_coord<D>(xs_n, my_shift, my_w) != fo;
     }
     return __ballot(bad) == 0ull;
@@ -2865,7 +2892,14 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     if (a0.fused) {
         // ticket -> (colour, replica, cell), colour slowest: a cell's lower-colour neighbours -- cells of the SAME replica --
         // hold lower tickets, i.e. belong to workgroups that are resident or finished: no deadlock
-        if (tid == 0) h.flag[2] = (int)(atomicAdd(a0.ticket, 1ull) - a0.ticket_base);
+        if (tid == 0) {
+            if (a0.ticket_lanes == PMC_TICKET_LANES) {
+                const int x = (int)(blockIdx.x & (PMC_TICKET_LANES - 1));
+                h.flag[2] = (int)atomicAdd(a0.ticket + x * PMC_TICKET_STRIDE, 1ull) * PMC_TICKET_LANES + x;
+            } else {
+                h.flag[2] = (int)(atomicAdd(a0.ticket, 1ull) - a0.ticket_base);
+            }
+        }
         __syncthreads();
         const int t = h.flag[2];
         const int per_colour = nrep * a0.nactive;

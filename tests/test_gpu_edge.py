@@ -281,6 +281,33 @@ def test_dilute_gas_empty_cells_and_tiny_systems(gpu):
         assert st3.attempted[0] == 5 * n
 
 
+@pytest.mark.parametrize("sigma", [0.02, 1.3, 5.5, 30.0])
+def test_proposals_that_leave_the_cell_or_the_box(gpu, sigma):
+    """'Stays in its cell' (floor((x - shift) / w) of the old and the new position) is decided from an FP32 offset to the
+    cell's centre, with the exact divisions only near a boundary.  Displacements of every size -- inside the cell, across
+    cells, half a box (where folding the new position into the centre's image would alias it back onto the cell), several
+    boxes -- on particles scattered over several periodic images: same decisions as the oracle, bit for bit."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(12, jitter=0.05, seed=5)
+    L = (len(pos) / rho) ** (1.0 / 3.0)
+    pos = pos + np.random.default_rng(8).integers(-2, 3, size=pos.shape) * L
+    g = pmc.System(pos, sp, rho, 1.5, pmc.LennardJones(1.0, 1.0), seed=21)
+    o = O.System(pos, sp, rho, 1.5, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    cb = O.Checkerboard(pos, sp, o.box, 1.5, o.models, seed=21)
+    for team in ("1", "4"):
+        os.environ["PMC_TEAM"] = team
+        try:
+            g2 = pmc.System(g.position, sp, rho, 1.5, pmc.LennardJones(1.0, 1.0), seed=21)
+        finally:
+            del os.environ["PMC_TEAM"]
+        st = pmc.mc_sweep(g2, [_disp(pmc, sigma)], nsweeps=6)
+        if team == "1":
+            att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": sigma}]), 0, 6)
+        assert st.attempted[0] == att[0] and st.accepted[0] == acc[0]
+        assert np.array_equal(g2.position, cb.positions()) and st.energy_fix == cb.energy_fix
+
+
 def test_eight_million_particles(gpu):
     """Maximum-size case: N = 8 * 10^6 (720 MB of device state).  Cell membership against numpy,
     exact energy bookkeeping across sweeps, reproducibility."""
