@@ -12,7 +12,7 @@
 #include <type_traits>
 
 #define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
-#define PMC_CFL 16           // centre-cell particles whose cell coordinates are cached (cells without exact bounds)
+#define PMC_CFL 8            // centre-cell particles whose cell coordinates are cached (the staging of the teams; stays_in_cell)
 #ifndef PMC_FUSED_STAGE
 #define PMC_FUSED_STAGE true  // k_cb_pass applies the box filter while staging (stage_compacted)
 #endif
@@ -39,8 +39,8 @@
                              // was 2.3 ms per sweep at N = 10^6)
 #define PMC_NSTATS 64        // counters of one sweep call (CbArgs::stats); [32..47] are used by -DPMC_DEBUG_TIME builds only
 #define PMC_STAT_KEPT 48     // [48..63]: cell visits by box-filtered neighbourhood size, bucket b = sizes in (64 (b-1), 64 b]
-#define PMC_QCAP 640         // entries of a wavefront's survivor queue (2 B each); a filter trip adds at most 128, so the
-                             // first five trips cannot overflow it and one check after the fifth covers the rest
+#define PMC_QCAP 320         // entries of a wavefront's survivor queue (2 B each: the candidate's LDS slot); a pair of filter trips
+                             // adds at most 128, a typical slot ends with ~70, and a slot that would overflow takes the direct loop
 #ifdef PMC_DEBUG_TIME   // profiling builds only: shader-clock stamps of wavefront 0, summed per phase into stats[32..]
 #define PMC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
@@ -2044,17 +2044,21 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
 #ifdef PMC_DEBUG_NODENSE   // profiling builds only: price the filter alone
     qn = 0;
 #endif
-    for (int e0 = 0; e0 < qn; e0 += PMC_WAVE) {
+    // An entry is a candidate that passed the filter at the old OR the new position; it is evaluated at both, by two
+    // neighbouring lanes: even lanes take the old position (and subtract), odd lanes the new one (and add).  Which of the
+    // two a lane takes never changes, so the position is picked once per slot instead of once per trip, and the exact test
+    // `r2 > rcut2` below drops the half of a pair that only rode along.
+    const bool isnew = (lane & 1) != 0;
+    const double xi = isnew ? xn : xo, yi = isnew ? yn : yo, zi = isnew ? zn : zo;
+    const int qe = 2 * qn;
+    for (int e0 = 0; e0 < qe; e0 += PMC_WAVE) {
         // lanes behind the last entry re-read it (no branch around the loads) and are masked out of the range test
-        const int e = min(e0 + lane, qn - 1);
-        const unsigned q = queue[e];
-        const bool isnew = (q & 1u) != 0u;
-        const int k = (int)(q >> 3);
+        const int e = min(e0 + lane, qe - 1);
+        const int k = (int)queue[e >> 1];
         const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
-        const double xi = isnew ? xn : xo, yi = isnew ? yn : yo, zi = isnew ? zn : zo;
         const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
         const double r2 = NOWRAP ? dist2_nowrap<D>(xi, yi, zi, xj, yj, zj) : dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
-        const bool inr = (e0 + lane < qn) && (k != pc) && !(r2 > mm.rcut2);     // k == pc: the particle itself
+        const bool inr = (e0 + lane < qe) && (k != pc) && !(r2 > mm.rcut2);     // k == pc: the particle itself
         pcnt.energies += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(inr));
         if (inr) {
             const double u = dev_quant(pot_kind<KIND>(r2, mm));
@@ -2079,7 +2083,6 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
     // SGPRs so that the trip guards, the ballot masks and the queue cursor stay on the scalar unit
     const int ncand = __builtin_amdgcn_readfirstlane(h.ncand);
     const float thr = a.rc2f;
-    const unsigned lane8 = (unsigned)lane << 3;
     unsigned qn = 0;
     int nrun = ncand;
 #ifdef PMC_DEBUG_NOFILTER   // profiling builds only: price the slot prologue / reduction alone
@@ -2113,28 +2116,25 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
                 r2[t] = __builtin_elementwise_fma(dz, dz, r2[t]);
             }
         }
-        unsigned long long m[4];
-        const bool b0 = r2[0].x <= thr, b1 = r2[0].y <= thr, b2 = r2[1].x <= thr, b3 = r2[1].y <= thr;
-        m[0] = __builtin_amdgcn_ballot_w64(b0); m[1] = __builtin_amdgcn_ballot_w64(b1);
-        m[2] = __builtin_amdgcn_ballot_w64(b2); m[3] = __builtin_amdgcn_ballot_w64(b3);
-        // queue entry: (k << 3) | new-position flag; slots behind the last candidate hold NaN and never pass
-        const unsigned k0 = lane8 + (unsigned)(J * PMC_WAVE * 8), k1 = k0 + (unsigned)(PMC_WAVE * 8);
-        const unsigned q0 = qn, q1 = q0 + (unsigned)__popcll(m[0]), q2 = q1 + (unsigned)__popcll(m[1]), q3 = q2 + (unsigned)__popcll(m[2]);
-        if (b0) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[0], q0))] = (unsigned short)k0;
-        if (b1) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[1], q1))] = (unsigned short)(k0 | 1u);
-        if (b2) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[2] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[2], q2))] = (unsigned short)k1;
-        if (b3) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m[3] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[3], q3))] = (unsigned short)(k1 | 1u);
-        qn = q3 + (unsigned)__popcll(m[3]);
+        // one queue entry per candidate that passes at either position: its LDS slot
+        const bool b0 = (r2[0].x <= thr) | (r2[0].y <= thr), b1 = (r2[1].x <= thr) | (r2[1].y <= thr);
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0), m1 = __builtin_amdgcn_ballot_w64(b1);
+        // slots behind the last candidate hold NaN and never pass
+        const unsigned k0 = (unsigned)lane + (unsigned)(J * PMC_WAVE), k1 = k0 + (unsigned)PMC_WAVE;
+        const unsigned q0 = qn, q1 = q0 + (unsigned)__popcll(m0);
+        if (b0) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, q0))] = (unsigned short)k0;
+        if (b1) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, q1))] = (unsigned short)k1;
+        qn = q1 + (unsigned)__popcll(m1);
     };
-    static_assert(PMC_FTRIPS == 8 && PMC_QCAP >= 4 * 2 * PMC_WAVE, "the first four trips must fit the queue unchecked");
+    static_assert(PMC_FTRIPS == 8 && PMC_QCAP >= 2 * 2 * PMC_WAVE, "the first two pairs of trips must fit the queue unchecked");
     if (nrun > 0) trips2(std::integral_constant<int, 0>{});
     if (nrun > 2 * PMC_WAVE) trips2(std::integral_constant<int, 2>{});
     if (nrun > 4 * PMC_WAVE) {
-        // four trips cannot overflow the queue (512 <= PMC_QCAP); each further pair adds at most 256 entries
-        if (qn > (unsigned)(PMC_QCAP - 4 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 4>{});
+        // each further pair adds at most 128 entries
+        if (qn > (unsigned)(PMC_QCAP - 2 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 4>{});
     }
     if (nrun > 6 * PMC_WAVE && !overflow) {
-        if (qn > (unsigned)(PMC_QCAP - 4 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 6>{});
+        if (qn > (unsigned)(PMC_QCAP - 2 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 6>{});
     }
     if (overflow) return 0.0;
     pcnt.tests += 2u * (unsigned)ncand;
