@@ -308,6 +308,58 @@ def test_proposals_that_leave_the_cell_or_the_box(gpu, sigma):
         assert np.array_equal(g2.position, cb.positions()) and st.energy_fix == cb.energy_fix
 
 
+def test_fused_staging_on_small_multi_species_and_two_dimensional_systems(gpu, monkeypatch):
+    """One wavefront per cell applies the box filter while staging and learns its LDS capacity from a histogram; systems
+    this small normally run in teams, which stage the old way.  Forced to one wavefront per cell -- with the capacity pinned
+    below the survivor count of most visits, and left to be learnt -- the chains must be the ones the teams produce."""
+    pmc = gpu
+
+    def ka():
+        pos, sp, rho = binary_lattice(8000, frac_b=0.2, rho=1.2, jitter=0.05, seed=3)
+        mk = lambda: pmc.System(pos, sp, rho, 0.9, pmc.KobAndersen(), seed=11)
+        pool = lambda s: [_disp(pmc, 0.05, 0.85), pmc.Move(pmc.DiscreteSwap([1, 2], s), pmc.DoubleUniform(), [], 0.15)]
+        return mk, pool
+
+    def ss2d():
+        n = 48
+        N, rho2 = n * n, 0.8
+        L = (N / rho2) ** 0.5
+        g = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float64)
+        p2 = (g + 0.5) * (L / n) + np.random.default_rng(1).uniform(-0.05, 0.05, (N, 2))
+        s2 = np.ones(N, dtype=np.int32)
+        s2[np.random.default_rng(2).permutation(N)[: N // 2]] = 2
+        mm = [[pmc.SoftSpheres(1.0, sg, 14) for sg in row] for row in ([1.0, 1.2], [1.2, 1.4])]
+        mk = lambda: pmc.System(p2, s2, rho2, 1.0, mm, seed=5)
+        pool = lambda s: [_disp(pmc, 0.065)]
+        return mk, pool
+
+    def lj_images():
+        pos, sp, rho = lj_lattice(16, jitter=0.05, seed=2)
+        L = (len(pos) / rho) ** (1.0 / 3.0)
+        pos = pos + np.random.default_rng(4).integers(-1, 2, size=pos.shape) * L
+        mk = lambda: pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=9)
+        pool = lambda s: [_disp(pmc, 0.06)]
+        return mk, pool
+
+    for make in (ka, ss2d, lj_images):
+        mk, pool = make()
+        monkeypatch.setenv("PMC_TEAM", "4")
+        ref = mk()
+        sr = [pmc.mc_sweep(ref, pool(ref), nsweeps=3) for _ in range(2)][-1]
+        for cap in (None, "128"):
+            monkeypatch.setenv("PMC_TEAM", "1")
+            if cap:
+                monkeypatch.setenv("PMC_CAP", cap)
+            else:
+                monkeypatch.delenv("PMC_CAP", raising=False)
+            s = mk()
+            st = [pmc.mc_sweep(s, pool(s), nsweeps=3) for _ in range(2)][-1]     # the second call runs with the learnt capacity
+            assert np.array_equal(s.position, ref.position) and np.array_equal(s.species, ref.species), (make.__name__, cap)
+            assert st.energy_fix == sr.energy_fix and np.array_equal(st.accepted, sr.accepted), (make.__name__, cap)
+            assert s.total_energy()[1] == st.energy_fix
+        monkeypatch.delenv("PMC_CAP", raising=False)
+
+
 def test_eight_million_particles(gpu):
     """Maximum-size case: N = 8 * 10^6 (720 MB of device state).  Cell membership against numpy,
     exact energy bookkeeping across sweeps, reproducibility."""
