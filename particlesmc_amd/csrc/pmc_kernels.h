@@ -2469,11 +2469,17 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     decode_cell<D>(a, colour, aidx, cell, lin);
     h.lin = lin;
     PMC_T(t_1);
+#if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 1   // profiling builds only: price the visit's phases one by one (not a valid chain)
+    { if (a.fused) publish_done(a, lin, tid == 0); return; }
+#endif
     // (teams are for small and medium systems, where a visit is one latency chain and LDS is plentiful: the fused staging's
     // count exchange between the wavefronts costs them 2-9 %)
     constexpr bool FUSE = PMC_FUSED_STAGE && NW == 1;
     stage_neighbourhood<D, MULTI, NW, FUSE>(a, cell, h, a.fused ? colour : 0);
     PMC_T(t_2);
+#if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 2
+    { if (a.fused) publish_done(a, lin, tid == 0); return; }
+#endif
     const int nc = h.nc;
     if (nc == 0) { if (a.fused) publish_done(a, lin, tid == 0); return; }
     if (h.ctr + nc > h.cap) {
@@ -2488,6 +2494,9 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     FRegs fr;
     prepare_filter<D>(a, h, fr);
     PMC_T(t_3);
+#if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 3
+    { if (a.fused) publish_done(a, lin, tid == 0); if (fr.x[0] == 1234.5f) st[40] = 1; return; }
+#endif
     if (NW == 1) __builtin_amdgcn_s_setprio(0);
 #ifdef PMC_DEBUG_COUNT   // profiling builds only
     if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], 0ull); atomicAdd(&st[24], (unsigned long long)h.nseg); atomicAdd(&st[28], (unsigned long long)h.compacted); atomicAdd(&st[29], (unsigned long long)h.filt); atomicAdd(&st[30], (unsigned long long)h.ncand * (unsigned long long)h.ncand); }

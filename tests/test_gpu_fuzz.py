@@ -92,9 +92,11 @@ def _draw_configuration(pmc, O, case):
         T = float(rng.uniform(0.5, 2.0))
         seed, chain = int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 8))
         env = {}
-        for var, p in (("PMC_TEAM", 0.6), ("PMC_NO_FILTER", 0.25), ("PMC_NO_ORDER", 0.25)):
+        for var, p in (("PMC_TEAM", 0.6), ("PMC_NO_FILTER", 0.25), ("PMC_NO_ORDER", 0.25), ("PMC_TICKETS", 0.25), ("PMC_CAP", 0.25)):
             if rng.random() < p:
-                env[var] = str(int(rng.choice([1, 2, 4, 8]))) if var == "PMC_TEAM" else "1"
+                # (PMC_CAP: a staging capacity below most neighbourhoods -- the overflow paths; PMC_TICKETS=1: one ticket counter)
+                env[var] = (str(int(rng.choice([1, 2, 4, 8]))) if var == "PMC_TEAM" else
+                            str(int(rng.choice([128, 192, 256]))) if var == "PMC_CAP" else "1")
         mm, mo = _models(pmc, O, rng, S)
         if _oracle_accepts(O, pos, sp, rho, T, mo):
             return rng, d, S, pos, sp, rho, T, seed, chain, env, mm, mo
@@ -106,7 +108,7 @@ def test_random_configuration_both_engines(gpu, case, monkeypatch):
     from oracle import oracle as O
     pmc = gpu
     rng, d, S, pos, sp, rho, T, seed, chain, env, mm, mo = _draw_configuration(pmc, O, case)
-    for var in ("PMC_TEAM", "PMC_NO_FILTER", "PMC_NO_ORDER"):
+    for var in ("PMC_TEAM", "PMC_NO_FILTER", "PMC_NO_ORDER", "PMC_TICKETS", "PMC_CAP"):
         monkeypatch.delenv(var, raising=False)
     for var, val in env.items():
         monkeypatch.setenv(var, val)
