@@ -2296,8 +2296,13 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
 // two wavefronts needs <= 13 312 B for twelve workgroups (six wavefronts per SIMD) per CU.
 __host__ __device__ inline size_t pmc_lds_wave_bytes(int cap, bool multi, int batch_nw)
 {
+    // one wavefront per cell (batch_nw == 0): no partial sums, and the segment tables share the survivor queue's bytes -- a visit
+    // either reads candidates beyond the LDS capacity through the tables (direct loop, no queue) or queues survivors
+    // (everything staged, tables never read): 10 224 B at cap = 384, the 16th workgroup of a CU
+    if (batch_nw == 0)
+        return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 4 * 4 + 16 * 4 + 24 * 4 + (size_t)PMC_QCAP * 2 + (multi ? cap : 0);
     return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (size_t)(2 * PMC_REC * batch_nw + batch_nw * batch_nw) * 8 + 4 * 4 + 16 * 4 +
-           24 * 4 + 2 * 32 * 4 + (size_t)(batch_nw > 0 ? batch_nw : 1) * PMC_QCAP * 2 + (multi ? cap : 0);
+           24 * 4 + 2 * 32 * 4 + (size_t)batch_nw * PMC_QCAP * 2 + (multi ? cap : 0);
 }
 
 template <int D, bool MULTI, int BATCH = 0>   // BATCH: team size of the speculative slot batches (0: none)
@@ -2309,14 +2314,21 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cz = h.cy + h.cap;
     h.cfl = h.cz + h.cap;
     h.part = h.cfl + 3 * PMC_CFL;
-    h.rec = h.part + 8;
+    h.rec = h.part + (BATCH > 0 ? 8 : 0);
     h.cmat = h.rec + 2 * PMC_REC * BATCH;      // two record buffers, used by alternate batches
     h.flag = reinterpret_cast<int *>(h.cmat + BATCH * BATCH);
     h.cnt = h.flag + 4;
     h.ptab = h.cnt + 16;
-    h.segoff = h.ptab + 24;
-    h.segsrc = h.segoff + 32;
-    h.queue = reinterpret_cast<unsigned short *>(h.segsrc + 32);
+    static_assert(PMC_QCAP * 2 >= 2 * 32 * 4, "the segment tables fit into a survivor queue");
+    if (BATCH > 0) {
+        h.segoff = h.ptab + 24;
+        h.segsrc = h.segoff + 32;
+        h.queue = reinterpret_cast<unsigned short *>(h.segsrc + 32);
+    } else {
+        h.segoff = h.ptab + 24;                // (see pmc_lds_wave_bytes: shared with the queue)
+        h.segsrc = h.segoff + 32;
+        h.queue = reinterpret_cast<unsigned short *>(h.segoff);
+    }
     h.csp = reinterpret_cast<unsigned char *>(h.queue + (BATCH > 0 ? BATCH : 1) * PMC_QCAP);
     h.filt = false;
     DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap, MULTI, BATCH) + 15) & ~(size_t)15));
