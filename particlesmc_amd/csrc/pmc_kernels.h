@@ -2121,9 +2121,10 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
         const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0), m1 = __builtin_amdgcn_ballot_w64(b1);
         // slots behind the last candidate hold NaN and never pass
         const unsigned k0 = (unsigned)lane + (unsigned)(J * PMC_WAVE), k1 = k0 + (unsigned)PMC_WAVE;
+        // (the running count goes into the uniform base pointer, not into the lane count: one instruction less per push)
         const unsigned q0 = qn, q1 = q0 + (unsigned)__popcll(m0);
-        if (b0) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, q0))] = (unsigned short)k0;
-        if (b1) queue[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, q1))] = (unsigned short)k1;
+        if (b0) (queue + q0)[__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = (unsigned short)k0;
+        if (b1) (queue + q1)[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)k1;
         qn = q1 + (unsigned)__popcll(m1);
     };
     static_assert(PMC_FTRIPS == 8 && PMC_QCAP >= 2 * 2 * PMC_WAVE, "the first two pairs of trips must fit the queue unchecked");
