@@ -470,7 +470,9 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         // that change two wavefronts per cell were ahead there, 4.0 vs 5.9e8).
         long long nact = 1;
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
-        h->team = (nact <= 512) ? 8 : ((nact <= 900) ? 4 : ((nact <= 3000) ? 2 : 1));
+        // End of round 2 (10^8 moves/s in the liquid, teams of 1 / 2 / 4 / 8): 343 cells per colour 1.3 / 1.5 / 2.0 / 2.1; 729:
+        // 2.5 / 2.9 / 3.7 / 2.9; 1331: 4.2 / 4.8 / 4.7 / 2.9; 1728: 5.3 / 6.1 / 5.2 / 3.1; 2197: 6.7 / 6.9; 3375: 9.7 / 7.5 / 5.5 / 3.3.
+        h->team = (nact <= 512) ? 8 : ((nact <= 900) ? 4 : ((nact <= 2400) ? 2 : 1));
         // 2-d neighbourhoods hold ~70-100 candidates (two filter trips): N=65536 binary soft spheres (1600 cells per
         // colour) 3.5 / 3.9 / 3.6e8 for teams of 1 / 2 / 4
         if (h->D == 2 && nact > 512) h->team = 2;
