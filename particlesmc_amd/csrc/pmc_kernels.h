@@ -1321,7 +1321,7 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
     const double xr = ld_agent(a.sx + k0), yr = ld_agent(a.sy + k0), zr = (D == 3) ? ld_agent(a.sz + k0) : 0.0;
     double bc[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
     bool have_box = false;
-    int base = 0;
+    int base = h.nc;           // the centre cell first, the compacted neighbours behind it
     bool wrapped_any = false;
     for (int b = 0; b < nseg; b += NR) {
         double tx[NR], ty[NR], tz[NR];
@@ -1394,7 +1394,8 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
                     d2 += ez * ez;
                 }
                 const int g = s0 + lane;
-                keep = !a.filter || (g >= k0 && g < k1) || !(d2 > a.rc2pad);
+                // the centre cell's own particles go first (slots 0 .. nc-1, below): they are not part of the compaction
+                keep = !(g >= k0 && g < k1) && (!a.filter || !(d2 > a.rc2pad));
             }
             keepm[r] = __builtin_amdgcn_ballot_w64(keep);
             cnt[r] = __popcll(keepm[r]);
@@ -1418,13 +1419,15 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
             const unsigned long long m = keepm[r];
             if ((r % NW) == wv) {
                 const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                const int pos = base + below;
-                if (((m >> lane) & 1ull) && pos < h.cap) {
+                const int c0 = __builtin_amdgcn_readlane(seg_cnt, b + r);
+                const int g = s0 + lane;
+                const bool centre = lane < c0 && g >= k0 && g < k1;
+                const int pos = centre ? g - k0 : base + below;
+                if ((centre || ((m >> lane) & 1ull)) && pos < h.cap) {
                     h.cx[pos] = tx[r];
                     h.cy[pos] = ty[r];
                     if (D == 3) h.cz[pos] = tz[r];
                     if (MULTI) h.csp[pos] = ts[r];
-                    if (s0 + lane == k0) h.flag[1] = pos;     // LDS slot of the first centre particle
                 }
             }
             base += cnt[r];
@@ -1438,7 +1441,7 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
     h.kept = base;
     if (base > h.cap) return false;
     h.nowrap = (NW > 1) ? (h.flag[0] == 0) : !wrapped_any;
-    h.ctr = h.flag[1];
+    h.ctr = 0;
     h.ncand = base;
     h.nseg = 1;
     if (lane == 0 && wv == 0) { h.segoff[0] = 0; h.segoff[1] = base; h.segsrc[0] = 0; }
@@ -2012,9 +2015,17 @@ __device__ __forceinline__ bool stays_in_cell(const CbArgs &a, const WaveNbh &h,
 
 // an accepted move of the particle in LDS slot pc: the owning lane replaces its float copy
 template <int D>
-__device__ __forceinline__ void update_fregs(FRegs &f, int pc, float fx, float fy, float fz)
+__device__ __forceinline__ void update_fregs(FRegs &f, int pc, float fx, float fy, float fz, bool first_trip_only = false)
 {
     const int rel = pc - wave_lane();
+    if (first_trip_only) {
+        // the fused staging puts the centre cell first (LDS slots 0 .. nc-1, nc <= 64): a moved particle is in trip 0
+        const bool mine = (rel == 0);
+        f.x[0] = mine ? fx : f.x[0];
+        f.y[0] = mine ? fy : f.y[0];
+        if (D == 3) f.z[0] = mine ? fz : f.z[0];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < PMC_FTRIPS; j++) {
         const bool mine = (rel == j * PMC_WAVE);
@@ -2176,13 +2187,29 @@ __device__ __forceinline__ double wave_delta_e(const CbArgs &a, const WaveNbh &h
         float fxo, fyo, fzo = 0.0f;
         fzn = 0.0f;
         if (h.nowrap) {
-            fxo = rel_float<true>(xo, h.bc[0], a.L[0], a.invL[0]);  fxn = rel_float<true>(xn, h.bc[0], a.L[0], a.invL[0]);
-            fyo = rel_float<true>(yo, h.bc[1], a.L[1], a.invL[1]);  fyn = rel_float<true>(yn, h.bc[1], a.L[1], a.invL[1]);
-            if (D == 3) { fzo = rel_float<true>(zo, h.bc[2], a.L[2], a.invL[2]); fzn = rel_float<true>(zn, h.bc[2], a.L[2], a.invL[2]); }
+            fxn = rel_float<true>(xn, h.bc[0], a.L[0], a.invL[0]);
+            fyn = rel_float<true>(yn, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) fzn = rel_float<true>(zn, h.bc[2], a.L[2], a.invL[2]);
         } else {
-            fxo = rel_float<false>(xo, h.bc[0], a.L[0], a.invL[0]); fxn = rel_float<false>(xn, h.bc[0], a.L[0], a.invL[0]);
-            fyo = rel_float<false>(yo, h.bc[1], a.L[1], a.invL[1]); fyn = rel_float<false>(yn, h.bc[1], a.L[1], a.invL[1]);
-            if (D == 3) { fzo = rel_float<false>(zo, h.bc[2], a.L[2], a.invL[2]); fzn = rel_float<false>(zn, h.bc[2], a.L[2], a.invL[2]); }
+            fxn = rel_float<false>(xn, h.bc[0], a.L[0], a.invL[0]);
+            fyn = rel_float<false>(yn, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) fzn = rel_float<false>(zn, h.bc[2], a.L[2], a.invL[2]);
+        }
+        if (h.compacted && h.nc <= PMC_WAVE) {
+            // centre cell first: the particle's own float copy sits in trip 0 of lane pc (the same bits: load_fregs computed it
+            // by rel_float from the same double, update_fregs stores the fxn of an accepted move)
+            const int pl = __builtin_amdgcn_readfirstlane(pc);
+            fxo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.x[0]), pl));
+            fyo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.y[0]), pl));
+            if (D == 3) fzo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.z[0]), pl));
+        } else if (h.nowrap) {
+            fxo = rel_float<true>(xo, h.bc[0], a.L[0], a.invL[0]);
+            fyo = rel_float<true>(yo, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) fzo = rel_float<true>(zo, h.bc[2], a.L[2], a.invL[2]);
+        } else {
+            fxo = rel_float<false>(xo, h.bc[0], a.L[0], a.invL[0]);
+            fyo = rel_float<false>(yo, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) fzo = rel_float<false>(zo, h.bc[2], a.L[2], a.invL[2]);
         }
         bool overflow;
         const double de = wave_delta_e_filtered<D, KIND, MULTI>(a, h, tab, queue, f, pc, si, xo, yo, zo, xn, yn, zn,
@@ -2795,7 +2822,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                             if (D == 3) h.cz[pc] = zn;
                         }
                         __syncthreads();
-                        if (h.filt) update_fregs<D>(fr, pc, fxn, fyn, fzn);
+                        if (h.filt) update_fregs<D>(fr, pc, fxn, fyn, fzn, h.compacted && nc <= PMC_WAVE);
                         efix += (long long)(de * PMC_FIX);
                         dirty = true;
                     }
