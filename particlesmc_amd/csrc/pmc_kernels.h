@@ -2535,7 +2535,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     prepare_filter<D>(a, h, fr);
     PMC_T(t_3);
 #if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 3
-    { if (a.fused) publish_done(a, lin, tid == 0); if (fr.x[0] == 1234.5f) st[40] = 1; return; }
+    { asm volatile("" :: "v"(fr.x[0]), "v"(fr.y[7]), "v"(fr.z[3])); if (a.fused) publish_done(a, lin, tid == 0); return; }   // (keeps the float copy alive)
 #endif
     if (NW == 1) __builtin_amdgcn_s_setprio(0);
 #ifdef PMC_DEBUG_COUNT   // profiling builds only
