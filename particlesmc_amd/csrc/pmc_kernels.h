@@ -2043,10 +2043,13 @@ struct PairCount {
 };
 
 // the FP64 evaluation of the queued survivors [0, qn) of one slot; returns this lane's partial sum
-template <int D, int KIND, bool MULTI, bool NOWRAP>
+// SWAP (DiscreteSwap of the particles in LDS slots pc and pj, species sa <-> sb; `si` carries sa): the two "positions" are the
+// two particles, which do not move; a lane adds the pair energy with the species its particle takes and subtracts the one with
+// the species it has (the terms of src/moves.jl:189-207 = swap_delta below, candidate by candidate).
+template <int D, int KIND, bool MULTI, bool NOWRAP, bool SWAP = false>
 __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h, const DevModel *tab, const unsigned short *queue,
                                               int qn, int pc, int si, double xo, double yo, double zo, double xn, double yn, double zn,
-                                              PairCount &pcnt)
+                                              PairCount &pcnt, int pj = 0, int sb = 0)
 {
     const int lane = wave_lane();
     double acc = 0.0;
@@ -2067,13 +2070,24 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
         const int e = min(e0 + lane, qe - 1);
         const int k = (int)queue[e >> 1];
         const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
-        const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
         const double r2 = NOWRAP ? dist2_nowrap<D>(xi, yi, zi, xj, yj, zj) : dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
-        const bool inr = (e0 + lane < qe) && (k != pc) && !(r2 > mm.rcut2);     // k == pc: the particle itself
-        pcnt.energies += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(inr));
-        if (inr) {
-            const double u = dev_quant(pot_kind<KIND>(r2, mm));
-            acc += isnew ? u : -u;
+        if (SWAP && MULTI) {
+            const int sk = (int)h.csp[k];
+            // even lanes: particle pc (species sa = si) becomes sb; odd lanes: particle pj (species sb) becomes sa
+            const DevModel &mplus = tab[(isnew ? si : sb) * a.S + sk], &mminus = tab[(isnew ? sb : si) * a.S + sk];
+            const bool valid = (e0 + lane < qe) && (k != pc) && (k != pj);
+            const bool inp = valid && !(r2 > mplus.rcut2), inm = valid && !(r2 > mminus.rcut2);
+            pcnt.energies += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(inp)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(inm));
+            if (inp) acc += dev_quant(pot_kind<KIND>(r2, mplus));
+            if (inm) acc -= dev_quant(pot_kind<KIND>(r2, mminus));
+        } else {
+            const DevModel &mm = MULTI ? tab[si * a.S + (int)h.csp[k]] : a.m0;
+            const bool inr = (e0 + lane < qe) && (k != pc) && !(r2 > mm.rcut2);     // k == pc: the particle itself
+            pcnt.energies += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(inr));
+            if (inr) {
+                const double u = dev_quant(pot_kind<KIND>(r2, mm));
+                acc += isnew ? u : -u;
+            }
         }
     }
     return acc;
@@ -2083,11 +2097,12 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
 // wavefront, result in every lane.  f = this wavefront's register copy; fo* / fn* = float images of the old and new
 // position (rel_float).  Requires h.filt.  `overflow` is set (and nothing returned) when the survivor queue cannot hold
 // the next trip: the caller then takes the direct loop for this slot (dense clusters only).
-template <int D, int KIND, bool MULTI>
+template <int D, int KIND, bool MULTI, bool SWAP = false>
 __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
                                                         const FRegs &f, int pc, int si, double xo, double yo, double zo,
                                                         double xn, double yn, double zn, float fxo, float fyo, float fzo,
-                                                        float fxn, float fyn, float fzn, PairCount &pcnt, bool &overflow)
+                                                        float fxn, float fyn, float fzn, PairCount &pcnt, bool &overflow,
+                                                        int pj = 0, int sb = 0)
 {
     const int lane = wave_lane();
     // wave-uniform values the compiler cannot prove uniform (they come from loads and cross-lane moves): pin them to
@@ -2154,8 +2169,8 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PMC_T(tf_1);
-    double acc = h.nowrap ? queue_flush<D, KIND, MULTI, true>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt)
-                          : queue_flush<D, KIND, MULTI, false>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt);
+    double acc = h.nowrap ? queue_flush<D, KIND, MULTI, true, SWAP>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb)
+                          : queue_flush<D, KIND, MULTI, false, SWAP>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2317,6 +2332,34 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
         term(k, xk, yk, zk, sk);
     }
     return team_sum_exact<NW>(h, d);
+}
+
+// dE of one DiscreteSwap slot by one wavefront: through the pre-filter and the survivor queue where they apply (the two
+// particles play the part of the old and the new position: neither moves, so the register copy holds both), the direct loop
+// of swap_delta otherwise.  A swap used to cost 3.4 Displacement slots -- and a team's batch waits for its slowest slot.
+template <int D, int KIND, bool MULTI>
+__device__ __forceinline__ double wave_swap_delta(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
+                                                  const FRegs &f, int pi, int pj, int sa, int sb, PairCount &pcnt)
+{
+    if (MULTI && h.filt) {
+        const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
+        const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
+        float fxi, fyi, fzi = 0.0f, fxj, fyj, fzj = 0.0f;
+        if (h.nowrap) {
+            fxi = rel_float<true>(xi, h.bc[0], a.L[0], a.invL[0]); fxj = rel_float<true>(xj, h.bc[0], a.L[0], a.invL[0]);
+            fyi = rel_float<true>(yi, h.bc[1], a.L[1], a.invL[1]); fyj = rel_float<true>(yj, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) { fzi = rel_float<true>(zi, h.bc[2], a.L[2], a.invL[2]); fzj = rel_float<true>(zj, h.bc[2], a.L[2], a.invL[2]); }
+        } else {
+            fxi = rel_float<false>(xi, h.bc[0], a.L[0], a.invL[0]); fxj = rel_float<false>(xj, h.bc[0], a.L[0], a.invL[0]);
+            fyi = rel_float<false>(yi, h.bc[1], a.L[1], a.invL[1]); fyj = rel_float<false>(yj, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) { fzi = rel_float<false>(zi, h.bc[2], a.L[2], a.invL[2]); fzj = rel_float<false>(zj, h.bc[2], a.L[2], a.invL[2]); }
+        }
+        bool overflow;
+        const double de = wave_delta_e_filtered<D, KIND, MULTI, true>(a, h, tab, queue, f, pi, sa, xi, yi, zi, xj, yj, zj,
+                                                                      fxi, fyi, fzi, fxj, fyj, fzj, pcnt, overflow, pj, sb);
+        if (!overflow) return de;
+    }
+    return swap_delta<D, KIND, MULTI, 1>(a, h, tab, pi, pj, sa, sb);
 }
 
 // LDS bytes of one workgroup: coordinates, cached cell coordinates, partial sums, [batch records],
@@ -2613,7 +2656,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         if (valid) {
                             pi = h.ctr + kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
                             pj = h.ctr + kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
-                            de = swap_delta<D, KIND, MULTI, 1>(a, h, tab, pi, pj, sa, sb);
+                            de = wave_swap_delta<D, KIND, MULTI>(a, h, tab, my_queue, fr, pi, pj, sa, sb, pcnt);
                         }
                         if (lane == 0) {
                             double *r = recs + wv * PMC_REC;
@@ -2839,7 +2882,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                 if (na > 0 && nb > 0 && sa != sb) {
                     const int pi = h.ctr + kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
                     const int pj = h.ctr + kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
-                    const double de = swap_delta<D, KIND, MULTI, NW>(a, h, tab, pi, pj, sa, sb);
+                    const double de = wave_swap_delta<D, KIND, MULTI>(a, h, tab, my_queue, fr, pi, pj, sa, sb, pcnt);
                     ok = tlnu < -de;
                     if (ok) {
                         __syncthreads();
