@@ -2660,6 +2660,9 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         }
                         if (lane == 0) {
                             double *r = recs + wv * PMC_REC;
+                            // (the positions of the two particles: what an earlier accepted Displacement of the batch corrects against)
+                            r[0] = h.cx[pi]; r[1] = h.cy[pi]; r[2] = (D == 3) ? h.cz[pi] : 0.0;
+                            r[3] = h.cx[pj]; r[4] = h.cy[pj]; r[5] = (D == 3) ? h.cz[pj] : 0.0;
                             r[6] = de;
                             r[7] = readlane_double(g_tlnu, my);
                             r[8] = (double)pi;
@@ -2716,8 +2719,27 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         const int pi = pr - ((pj * (pj - 1)) >> 1);
                         const int pjc = min(pj, NW - 1);
                         double v = 0.0;
-                        // record[10] >= 0 marks a DiscreteSwap slot (its second particle); pair terms exist between Displacement slots only
-                        const bool both_disp = ONE || (recs[pi * PMC_REC + 10] < 0.0 && recs[pjc * PMC_REC + 10] < 0.0);
+                        // record[10] >= 0 marks a DiscreteSwap slot (its second particle)
+                        const bool i_disp = ONE || recs[pi * PMC_REC + 10] < 0.0, j_disp = ONE || recs[pjc * PMC_REC + 10] < 0.0;
+                        const bool both_disp = i_disp && j_disp;
+                        if (!ONE && MULTI && pr < NP && pj < K && i_disp && !j_disp) {
+                            // Displacement i before DiscreteSwap j (particles A = rj[8] <-> B = rj[10], species sa <-> sb): the swap was
+                            // evaluated with particle i at its old position.  One lane per (position of i, particle of the swap):
+                            // the pair energy with the species that particle takes minus the one with the species it has;
+                            // + at i's new position, - at its old one.
+                            const double *ri = recs + pi * PMC_REC, *rj = recs + pj * PMC_REC;
+                            const int oi = (tt & 2) ? 0 : 3, oj = (tt & 1) ? 3 : 0;     // i: old or new; swap: particle B or A
+                            const double xi_ = ri[oi], yi_ = ri[oi + 1], zi_ = ri[oi + 2];
+                            const double xj_ = rj[oj], yj_ = rj[oj + 1], zj_ = rj[oj + 2];
+                            const int sci = (int)h.csp[(int)ri[8]];
+                            const int mj = (int)rj[11];
+                            const int sa_ = h.ptab[8 + mj], sb_ = h.ptab[16 + mj];
+                            const DevModel &mplus = tab[((tt & 1) ? sa_ : sb_) * a.S + sci], &mminus = tab[((tt & 1) ? sb_ : sa_) * a.S + sci];
+                            const double r2 = h.nowrap ? dist2_nowrap<D>(xj_, yj_, zj_, xi_, yi_, zi_) : dist2_fast<D>(a, xj_, yj_, zj_, xi_, yi_, zi_);
+                            if (!(r2 > mplus.rcut2)) v += dev_quant(pot_kind<KIND>(r2, mplus));
+                            if (!(r2 > mminus.rcut2)) v -= dev_quant(pot_kind<KIND>(r2, mminus));
+                            if (tt & 2) v = -v;
+                        }
                         if (pr < NP && pj < K && both_disp) {
                             const double *ri = recs + pi * PMC_REC, *rj = recs + pj * PMC_REC;
                             const int oi = (tt & 2) ? 0 : 3, oj = (tt & 1) ? 0 : 3;   // old or new coordinates
@@ -2742,7 +2764,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     for (int i = 0; i < NW - 1; i++) creg[i] = h.cmat[i * NW + jl];
                     // decisions in slot order; lanes > i accumulate what an accepted slot i does to them
                     double corr = 0.0;
-                    bool conf = false, any_acc = false, stop = false;
+                    bool conf = false, stop = false;
                     int nres = 0;
                     unsigned accmask = 0;
 #pragma unroll
@@ -2751,9 +2773,9 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                             const double dei = readlane_double(l_de + corr, i);
                             const bool swapi = (__ballot(l_swap && lane == i) != 0ull);
                             const bool confi = (__ballot(conf && lane == i) != 0ull);
-                            // a slot that re-selects a moved particle, or a swap slot after any accepted move (it was evaluated
-                            // against the species of the state before the batch), ends the batch and is evaluated again
-                            if (confi || (swapi && any_acc)) {
+                            // a slot that re-selects a moved particle ends the batch and is evaluated again (a swap after accepted
+                            // Displacements of OTHER particles is corrected like a Displacement: c(i,j) above)
+                            if (confi) {
                                 stop = true;
                             } else {
                                 const bool ini = (__ballot(l_in && lane == i) != 0ull);
@@ -2763,14 +2785,13 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                                     accmask |= 1u << i;
                                     acc1 += 1;
                                     efix += (long long)(dei * PMC_FIX);
-                                    any_acc = true;
                                     if (swapi) {
                                         stop = true;            // later slots saw the old species: next batch
                                     } else if (i < NW - 1) {
                                         const int pci = __builtin_amdgcn_readlane(l_pc, i);
                                         if (lane > i) {
                                             corr += creg[i < NW - 1 ? i : 0];
-                                            conf = conf || (l_pc == pci);
+                                            conf = conf || (l_pc == pci) || (l_swap && l_pj == pci);
                                         }
                                     }
                                 }
