@@ -1874,9 +1874,19 @@ __device__ __forceinline__ double wave_sum_exact(double v)
     v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
     v = dpp_add<0x141>(v);   // row_half_mirror
     v = dpp_add<0x140>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
-    double r0 = readlane_double(v, 0), r1 = readlane_double(v, 16);
-    double r2 = readlane_double(v, 32), r3 = readlane_double(v, 48);
-    return (r0 + r1) + (r2 + r3);
+    // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 ends with the total (rows a DPP move does
+    // not write keep the 0 given as their old value)
+    {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
+        int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+        v = v + __hiloint2double(hi2, lo2);
+        lo = __double2loint(v); hi = __double2hiint(v);
+        lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);
+        hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+        v = v + __hiloint2double(hi2, lo2);
+    }
+    return readlane_double(v, 63);
 }
 
 // exact sum over all lanes of the NW wavefronts of a team; result in every lane (2 barriers when NW > 1)
