@@ -3,7 +3,7 @@
 one replica per GPU, the exchange step over torch.distributed (RCCL with nccl, gloo when ranks
 share a GPU).
 
-  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/tempering.py
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/tempering.py [--rccl]
   python examples/tempering.py --local 8            # 8 replicas on one GPU, no process group
 
 The reference has no replica exchange (README.md:33), so there is nothing to compare against; the
@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--sweeps", type=int, default=400)
     ap.add_argument("--exchange-every", type=int, default=10)
     ap.add_argument("--local", type=int, default=0, help="run this many replicas in one process on one GPU")
+    ap.add_argument("--rccl", action="store_true",
+                    help="one replica per rank: exchange through the library's own RCCL entry point (pmc_replica_exchange_rccl, "
+                         "the path a Julia host takes) instead of torch.distributed's gather")
     ap.add_argument("--tmin", type=float, default=1.0)
     ap.add_argument("--tmax", type=float, default=1.02,
                     help="with N = 65536 adjacent temperatures must differ by ~1/sqrt(N) for exchanges to be accepted; "
@@ -74,9 +77,10 @@ def main():
     tdev = f"cuda:{dev}" if (dist is not None and ndev >= world) else "cpu"
     ladder = np.geomspace(args.tmin, args.tmax, world)
     system = make_system(pmc, args.side, 0.8, ladder[rank], 5, rank, dev)
+    comm = tempering.rccl_comm_from_env(dev) if args.rccl else None
     t0 = time.perf_counter()
     rex, trace = tempering.run_tempering(system, pool, ladder, args.sweeps, args.exchange_every, seed=9, rank=rank,
-                                         world=world, device=tdev)
+                                         world=world, device=tdev, comm=comm)
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dist, tdev)
     if rank == 0:
         print(json.dumps({"replicas": world, "mode": "one per rank", "moves_per_s": world * system.N * args.sweeps / dt,
