@@ -360,6 +360,39 @@ def test_fused_staging_on_small_multi_species_and_two_dimensional_systems(gpu, m
         monkeypatch.delenv("PMC_CAP", raising=False)
 
 
+def test_many_accepted_swaps_give_one_chain_whatever_the_team_width(gpu, monkeypatch):
+    """A 50:50 mixture at T = 2 with 40 % DiscreteSwap slots accepts thousands of swaps per sweep.  In a team, a swap slot that
+    follows accepted Displacements of other particles in its batch is corrected by eight exact pair terms instead of being
+    evaluated again; an accepted swap ends its batch.  Whatever the team width -- including one wavefront per cell, which has no
+    batches -- the chain (positions, species, exact energy, both accept counts) must be the same, the running energy must
+    equal a recomputation, and the oracle must agree."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = binary_lattice(8000, frac_b=0.5, rho=1.0, jitter=0.05, seed=7)
+
+    def pool(s):
+        return [_disp(pmc, 0.05, 0.6), pmc.Move(pmc.DiscreteSwap([1, 2], s), pmc.DoubleUniform(), [], 0.4)]
+
+    ref = None
+    for team in ("8", "4", "2", "1"):
+        monkeypatch.setenv("PMC_TEAM", team)
+        s = pmc.System(pos, sp, rho, 2.0, pmc.KobAndersen(), seed=3)
+        st = None
+        for _ in range(2):
+            st = pmc.mc_sweep(s, pool(s), nsweeps=10)
+            assert s.total_energy()[1] == st.energy_fix
+        sig = (s.position.tobytes(), s.species.tobytes(), int(st.energy_fix), tuple(int(v) for v in st.accepted[:2]))
+        if ref is None:
+            ref = sig
+            assert st.accepted[1] > 2000
+        assert sig == ref, team
+    o = O.System(pos, sp, rho, 2.0, O.kob_andersen(), O.LINKEDLIST)
+    cb = O.Checkerboard(pos, sp, o.box, 2.0, o.models, seed=3)
+    att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.6},
+                                      {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.4}]), 0, 20)
+    assert np.array_equal(np.frombuffer(ref[0], dtype=np.float64).reshape(-1, 3), cb.positions()) and ref[2] == cb.energy_fix
+
+
 def test_eight_million_particles(gpu):
     """Maximum-size case: N = 8 * 10^6 (720 MB of device state).  Cell membership against numpy,
     exact energy bookkeeping across sweeps, reproducibility."""
