@@ -154,6 +154,7 @@ int pmc_build_cells(pmc_system *h);                             /* build_neighbo
 int pmc_get_cells(pmc_system *h, int64_t *cs);                  /* neighbour_list.cs, 1-based */
 int pmc_get_linked_list(pmc_system *h, int64_t *head, int64_t *list); /* .head (-1 = empty), .list */
 int pmc_get_neighbour_cells(pmc_system *h, int64_t c, int64_t *out, int32_t *n); /* .neighbour_cells[c] src/neighbours.jl:94-111 */
+int pmc_neighbours_of(pmc_system *h, int64_t i, int64_t *out, int64_t cap, int64_t *n);  /* collect(L(system, i)): (L::LinkedList)(system, i) + LinkedIterator, src/neighbours.jl:316-377 (includes i; n = needed size) */
 int pmc_energy_particle(pmc_system *h, int64_t i, double *e);   /* compute_energy_particle src/atoms.jl:81-88 */
 int pmc_energy_particles(pmc_system *h, double *e);             /* [compute_energy_particle(i) for i] src/atoms.jl:51 */
 int pmc_init_energy(pmc_system *h, double *e);                  /* build list + sum(local)/2 + Inf/NaN guard, src/atoms.jl:50-56 */
@@ -192,6 +193,15 @@ int pmc_energy_particles_exact(pmc_system *h, double *e);         /* all compute
 int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const double *delta,
                 double *e1, double *e2);                          /* independent batch of Displacement dE */
 int pmc_grid(pmc_system *h, int64_t *n_mc, double *w);            /* checkerboard grid geometry */
+
+/* Schedule parameter m of the throughput engine ("rounds per cell visit"; no reference counterpart: the
+ * reference chain is sequential).  The sweeps of a call are taken in passes of min(m, sweeps left) sweeps: a pass draws ONE
+ * grid shift, bins once, and every cell visit runs that many rounds of n_c proposal slots against the neighbourhood it staged
+ * once.  m = 1 (default): the grid is re-shifted every N attempted moves.  1 <= m <= PMC_MAX_ROUNDS.  A pass never spans
+ * calls, so the chain depends on how sweeps are grouped into calls when m > 1 (oracle: orc_cb_sweeps_rounds). */
+#define PMC_MAX_ROUNDS 16
+int pmc_set_rounds(pmc_system *h, int32_t rounds);
+int pmc_get_rounds(pmc_system *h, int32_t *rounds);
 
 /* mc_sweep!(system, pool, rng; mc_steps = nsweeps * N) -- the Arianna entry
  * the reference reaches from run!(Simulation) (src/ParticlesMC.jl:246,294-297;

@@ -85,8 +85,31 @@ function ParticlesMC.build_neighbour_list!(system::ParticlesMC.Particles, L::HIP
         check(ccall((:pmc_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}), L.handle, pos, sp), L.handle)
     end
     check(ccall((:pmc_build_cells, LIB), Cint, (Ptr{Cvoid},), L.handle), L.handle)
-    check(ccall((:pmc_set_energy, LIB), Cint, (Ptr{Cvoid}, Float64), L.handle, system.energy[1]), L.handle)
+    # NOT here: system.energy[1].  System() calls this function at src/atoms.jl:50 while `energy` is still
+    # Vector{T}(undef, 1) (:44); the value only exists after :51-56.  The running energy is handed over on every use
+    # instead (handover! below): the Julia-side system.energy[1] is the authority between calls, exactly as in the
+    # reference, whose wrapper (src/moves.jl:11-20) and revert_action! (:76-81, :201-207) keep it on the host.
     return nothing
+end
+
+# system.energy[1] -> the handle's running energy.  One host-side store in the library (no device work); called at the top
+# of every entry point whose result depends on the running energy.
+handover!(system) = check(ccall((:pmc_set_energy, LIB), Cint, (Ptr{Cvoid}, Float64), system.neighbour_list.handle, system.energy[1]),
+                          system.neighbour_list.handle)
+
+# `neighbour_list(system, i)` (src/neighbours.jl:371-377): the ids the reference's LinkedIterator (:316-365) yields for
+# particle i, materialised -- i itself included, as in the reference.  Compatibility path for code that iterates the list
+# itself (e.g. the generic compute_energy_particle of src/atoms.jl:81-88); the overloads below never go through it.
+function (L::HIPLinkedList)(system::ParticlesMC.Particles, i::Int)
+    n = Ref{Int64}(0)
+    out = Vector{Int64}(undef, 1024)
+    rc = ccall((:pmc_neighbours_of, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ref{Int64}), L.handle, i, out, length(out), n)
+    if rc != 0 && n[] > length(out)                                  # a denser neighbourhood than the first guess
+        resize!(out, n[])
+        rc = ccall((:pmc_neighbours_of, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ref{Int64}), L.handle, i, out, length(out), n)
+    end
+    check(rc, L.handle)
+    return resize!(out, n[])
 end
 
 function Base.getproperty(L::HIPLinkedList, s::Symbol)              # neighbour_list.cs (src/neighbours.jl:49-51)
@@ -103,7 +126,8 @@ function ParticlesMC.compute_energy_particle(system::ParticlesMC.Atoms, i, L::HI
 end
 
 function ParticlesMC.perform_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.Displacement) where {D,V}
-    e1, e2, de = Ref(0.0), Ref(0.0), Ref(0.0)                        # replaces src/moves.jl:57-67 (+ wrapper :11-20 bookkeeping on the device)
+    e1, e2, de = Ref(0.0), Ref(0.0), Ref(0.0)                        # replaces src/moves.jl:57-67; the wrapper (:11-20) then adds δe to
+    handover!(system)                                                # system.energy[1] on the host, the library does the same on its copy
     δ = collect(Float64, action.δ)
     check(ccall((:pmc_displacement_perform, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ref{Float64}, Ref{Float64}, Ref{Float64}),
                 system.neighbour_list.handle, action.i, δ, e1, e2, de), system.neighbour_list.handle)
@@ -115,15 +139,18 @@ end
 
 struct HIPMetropolis <: Arianna.Algorithm
     pool::Vector{CMove}; mode::Int32            # 0 = sequential (reference chain), 1 = checkerboard (throughput)
-end
+    sweeps_per_step::Int64                      # sweeps per scheduler tick: one library call (one sync, one counter fold) per tick,
+end                                             # so coarse schedulers should tick in blocks (INTEGRATION.md section 4)
+HIPMetropolis(pool, mode) = HIPMetropolis(pool, mode, 1)
 cmove(m::Arianna.Move{<:ParticlesMC.Displacement}) = CMove(0, (0, 0), m.weight, m.parameters.σ)
 cmove(m::Arianna.Move{<:ParticlesMC.DiscreteSwap}) = CMove(1, Int32.(m.action.species), m.weight, 0.0)
 
 function Arianna.make_step!(sim::Arianna.Simulation, alg::HIPMetropolis)          # one scheduler tick = one sweep
     for system in sim.chains                                                      # parallel=true: Threads.@threads, one handle per chain
         st = Ref{Stats}()
+        handover!(system)
         check(ccall((:pmc_sweep, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{CMove}, Int32, Int64, Ref{Stats}),
-                    system.neighbour_list.handle, alg.mode, alg.pool, length(alg.pool), 1, st), system.neighbour_list.handle)
+                    system.neighbour_list.handle, alg.mode, alg.pool, length(alg.pool), alg.sweeps_per_step, st), system.neighbour_list.handle)
         system.energy[1] = st[].energy                                             # energy callback, src/utils.jl:51-53
         # st[].attempted / .accepted feed StoreAcceptance
     end
@@ -134,13 +161,16 @@ end
 function Arianna.revert_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.Displacement) where {D,V}
     h = system.neighbour_list.handle                                # action.δ was inverted by invert_action! (src/moves.jl:88-90)
     δ = collect(Float64, action.δ)
+    handover!(system)
     check(ccall((:pmc_displacement_revert, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Float64), h, action.i, δ, action.δe), h)
+    system.energy[1] -= action.δe                                   # src/moves.jl:79 (the library subtracts it from its copy too)
     return nothing
 end
 
 function ParticlesMC.perform_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.DiscreteSwap) where {D,V}
     h = system.neighbour_list.handle
     e1, e2, de = Ref(0.0), Ref(0.0), Ref(0.0)
+    handover!(system)
     check(ccall((:pmc_swap_perform, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Float64}, Ref{Float64}, Ref{Float64}),
                 h, action.i, action.j, e1, e2, de), h)
     action.δe = de[]
@@ -149,7 +179,9 @@ end
 
 function Arianna.revert_action!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}, action::ParticlesMC.DiscreteSwap) where {D,V}
     h = system.neighbour_list.handle                                # called with the inverted action (src/moves.jl:212-214)
+    handover!(system)
     check(ccall((:pmc_swap_revert, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Float64), h, action.i, action.j, action.δe), h)
+    system.energy[1] -= action.δe                                   # src/moves.jl:206
     return nothing
 end
 
@@ -169,8 +201,19 @@ function refresh!(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}) where {D,V}
     return system
 end
 
+# Temperature.  `Atoms` is an immutable struct (src/atoms.jl:18): `system.temperature = T` does not exist, in the reference or
+# here.  A tempering run changes temperatures, so the CURRENT temperature of a HIP-backed chain lives on its handle
+# (system.temperature stays the value the chain was created with) and the two target-density functions of
+# src/utils.jl:4-10 read it from there.
 set_temperature!(system, T) = check(ccall((:pmc_set_temperature, LIB), Cint, (Ptr{Cvoid}, Float64), system.neighbour_list.handle, T),
                                     system.neighbour_list.handle)
+function temperature(system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}) where {D,V}
+    T = Ref(0.0)
+    check(ccall((:pmc_get_temperature, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), system.neighbour_list.handle, T), system.neighbour_list.handle)
+    return T[]
+end
+Arianna.unnormalised_log_target_density(e, system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}) where {D,V} = -e / temperature(system)
+Arianna.delta_log_target_density(e1, e2, system::ParticlesMC.Atoms{D,V,<:HIPLinkedList}) where {D,V} = -(e2 - e1) ./ temperature(system)
 
 # ---- the reference's other list types on the device's reference-order engine --------------------------------------
 # Construct HIPLinkedList with the geometry of that list (pmc_cell_list_geometry / pmc_verlet_list_geometry) and call
@@ -182,6 +225,7 @@ set_list_type!(L::HIPLinkedList, list_type::Integer, dr::Real=0.0) =
 # Chains of one shape (same N, box, models) share every kernel launch; anything else runs as one stream per handle.
 
 function sweep_many!(systems, pool::Vector{CMove}, nsweeps::Integer; mode::Integer=1)
+    foreach(handover!, systems)
     hs = Ptr{Cvoid}[s.neighbour_list.handle for s in systems]
     stats = Vector{Stats}(undef, length(systems))
     GC.@preserve hs stats pool begin
@@ -198,15 +242,14 @@ end
 # label[r] = index (0-based) of the temperature replica r holds; the library reads the handles' running energies,
 # decides, and sets every handle's temperature.  Replicas of one process (one GPU, or one handle per device):
 function replica_exchange!(systems, ladder::Vector{Float64}, seed::Integer, round::Integer, label::Vector{Int32})
+    foreach(handover!, systems)
     hs = Ptr{Cvoid}[s.neighbour_list.handle for s in systems]
     nacc = Ref{Int32}(0)
     GC.@preserve hs ladder label begin
         check(ccall((:pmc_replica_exchange, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, UInt64, UInt64, Ptr{Int32}, Ref{Int32}),
                     hs, length(hs), ladder, seed, round, label, nacc), hs[1])
     end
-    for (r, s) in enumerate(systems)
-        s.temperature = ladder[label[r] + 1]
-    end
+    # (the library has set every handle's temperature to ladder[label[r] + 1]: temperature(systems[r]) returns it)
     return nacc[]
 end
 # One process per GPU: `comm` from pmc_rccl_comm_create (rank 0 calls pmc_rccl_unique_id and ships the 128 bytes, e.g. with
@@ -215,13 +258,13 @@ function replica_exchange_rccl!(system, comm::Ptr{Cvoid}, rank::Integer, world::
                                 round::Integer, label::Vector{Int32})
     h = system.neighbour_list.handle
     nacc = Ref{Int32}(0)
+    handover!(system)
     GC.@preserve ladder label begin
         check(ccall((:pmc_replica_exchange_rccl, LIB), Cint,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, UInt64, UInt64, Ptr{Int32}, Ref{Int32}),
                     h, comm, rank, world, ladder, seed, round, label, nacc), h)
     end
-    system.temperature = ladder[label[rank + 1] + 1]
-    return nacc[]
+    return nacc[]                                                   # temperature(system) == ladder[label[rank + 1] + 1] from here on
 end
 
 # ---- EnergyBias on the device (src/moves.jl:246-280): nothing of size N crosses the bus ------------------------------

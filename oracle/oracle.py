@@ -125,6 +125,7 @@ def lib():
     L.orc_cb_destroy.argtypes = [vp]
     L.orc_cb_grid.argtypes = [vp, lp, dp]
     L.orc_cb_sweeps.argtypes = [vp, C.POINTER(Move), C.c_int32, C.c_uint64, C.c_int64, C.POINTER(Stats)]
+    L.orc_cb_sweeps_rounds.argtypes = [vp, C.POINTER(Move), C.c_int32, C.c_uint64, C.c_int64, C.c_int32, C.POINTER(Stats)]
     L.orc_cb_get_positions.argtypes = [vp, dp]
     L.orc_cb_get_species.argtypes = [vp, ip]
     L.orc_cb_energy_fix.restype = C.c_int64
@@ -374,9 +375,10 @@ class Checkerboard:
         lib().orc_cb_grid(self.h, _lp(n), _dp(w))
         return n[: self.d].copy(), w[: self.d].copy()
 
-    def sweeps(self, pool, sweep0, nsweeps):
+    def sweeps(self, pool, sweep0, nsweeps, rounds=1):
+        """`rounds` = m of the schedule: passes of m sweeps share one grid shift and one staged neighbourhood per cell."""
         st = Stats()
-        lib().orc_cb_sweeps(self.h, pool, len(pool), sweep0, nsweeps, C.byref(st))
+        lib().orc_cb_sweeps_rounds(self.h, pool, len(pool), sweep0, nsweeps, rounds, C.byref(st))
         return np.array(st.attempted[: len(pool)]), np.array(st.accepted[: len(pool)])
 
     def positions(self):

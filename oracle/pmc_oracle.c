@@ -1273,9 +1273,22 @@ double orc_cb_energy_at(const orc_cb *cc, int64_t i, const double *x, int32_t sp
 void orc_cb_sweeps(orc_cb *c, const orc_move *pool, int32_t npool, uint64_t sweep0,
                    int64_t nsweeps, orc_stats *stats)
 {
+    orc_cb_sweeps_rounds(c, pool, npool, sweep0, nsweeps, 1, stats);
+}
+
+/* The schedule with `rounds` m >= 1 ("rounds per visit"): the sweeps of a call are taken in PASSES of
+ * k = min(m, sweeps left) sweeps.  A pass that starts at sweep counter g draws ONE grid shift (keyed by g), bins once, and
+ * every cell visit of the pass runs k n_c proposal slots t = 0 .. k n_c - 1 (keyed (cell, t, g)) against the same staged
+ * neighbourhood; the counter then advances by k.  m = 1 is the schedule of orc_cb_sweeps.  Every slot is an attempted
+ * move: a pass is k N attempted moves. */
+void orc_cb_sweeps_rounds(orc_cb *c, const orc_move *pool, int32_t npool, uint64_t sweep0,
+                          int64_t nsweeps, int32_t rounds, orc_stats *stats)
+{
     int d = c->d;
     int64_t *cand = (int64_t *)malloc(sizeof(int64_t) * (size_t)c->N);
-    for (int64_t sw = 0; sw < nsweeps; sw++) {
+    if (rounds < 1) rounds = 1;
+    for (int64_t sw = 0, kr = 0; sw < nsweeps; sw += kr) {
+        kr = nsweeps - sw < rounds ? nsweeps - sw : rounds;
         uint64_t g = sweep0 + (uint64_t)sw;
         uint32_t s_lo = (uint32_t)g, s_hi = (uint32_t)(g >> 32) & 0xffffffu;
         uint32_t cs[4] = {0, 0, s_lo, s_hi | ((uint32_t)TAG_SHIFT << 24)}, W[4];
@@ -1297,7 +1310,7 @@ void orc_cb_sweeps(orc_cb *c, const orc_move *pool, int32_t npool, uint64_t swee
                 int64_t nc = c->cell_start[lin + 1] - k0;
                 if (nc == 0) continue;
                 int64_t ncand = cb_gather(c, lin, cand);
-                for (int64_t t = 0; t < nc; t++) {
+                for (int64_t t = 0; t < kr * nc; t++) {
                     uint32_t c0[4] = {(uint32_t)lin, (uint32_t)t, s_lo, s_hi | ((uint32_t)TAG_SLOT0 << 24)};
                     uint32_t c1[4] = {(uint32_t)lin, (uint32_t)t, s_lo, s_hi | ((uint32_t)TAG_SLOT1 << 24)};
                     uint32_t R[4], Q[4];

@@ -129,6 +129,8 @@ void orc_cb_destroy(orc_cb *c);
 void orc_cb_grid(const orc_cb *c, int64_t *n_mc, double *w);
 void orc_cb_sweeps(orc_cb *c, const orc_move *pool, int32_t npool, uint64_t sweep0,
                    int64_t nsweeps, orc_stats *stats);
+void orc_cb_sweeps_rounds(orc_cb *c, const orc_move *pool, int32_t npool, uint64_t sweep0,
+                          int64_t nsweeps, int32_t rounds, orc_stats *stats);   /* rounds per cell visit (m) */
 void orc_cb_get_positions(const orc_cb *c, double *pos);
 void orc_cb_get_species(const orc_cb *c, int32_t *species);
 int64_t orc_cb_energy_fix(const orc_cb *c);         /* running energy, units of 2^-32 */

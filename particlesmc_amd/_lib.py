@@ -84,6 +84,7 @@ SYMBOLS = {
     "pmc_get_cells": (C.c_int, [_h, _lp]),
     "pmc_get_linked_list": (C.c_int, [_h, _lp, _lp]),
     "pmc_get_neighbour_cells": (C.c_int, [_h, C.c_int64, _lp, _ip]),
+    "pmc_neighbours_of": (C.c_int, [_h, C.c_int64, _lp, C.c_int64, _lp]),
     "pmc_energy_particle": (C.c_int, [_h, C.c_int64, _dp]),
     "pmc_energy_particles": (C.c_int, [_h, _dp]),
     "pmc_init_energy": (C.c_int, [_h, _dp]),
@@ -100,6 +101,8 @@ SYMBOLS = {
     "pmc_energy_particles_exact": (C.c_int, [_h, _dp]),
     "pmc_delta_e": (C.c_int, [_h, C.c_int64, _lp, _dp, _dp, _dp]),
     "pmc_grid": (C.c_int, [_h, _lp, _dp]),
+    "pmc_set_rounds": (C.c_int, [_h, C.c_int32]),
+    "pmc_get_rounds": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pmc_sweep": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64, C.POINTER(Stats)]),
     "pmc_sweep_begin": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64]),
     "pmc_sweep_end": (C.c_int, [_h, C.POINTER(Stats)]),

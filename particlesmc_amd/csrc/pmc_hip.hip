@@ -77,9 +77,11 @@ struct pmc_system {
     int cap_hint = 0;       // LDS staging capacity learnt from the last sweeps' histogram (cb_cap_learn); 0: none yet
     unsigned long long kept_seen[16] = {0};   // the part of the current call's histogram cb_cap_learn has already used
     // proposal slots of the current sweep (k_mc_slots)
-    double *d_slot_f = nullptr;          // [4][N]: T ln u, dx, dy, dz
-    uint32_t *d_slot_w = nullptr;        // [2][N]: particle word, second swap word
-    unsigned char *d_slot_m = nullptr;   // [N]: move index
+    double *d_slot_f = nullptr;          // [4][rounds N]: T ln u, dx, dy, dz
+    uint32_t *d_slot_w = nullptr;        // [2][rounds N]: particle word, second swap word
+    unsigned char *d_slot_m = nullptr;   // [rounds N]: move index
+    int rounds = 1;                      // schedule parameter m (pmc_set_rounds): sweeps per pass = proposal rounds per cell visit
+    int slot_rounds = 1;                 // rounds the slot arrays are allocated for
     // fused sweep (all colours in one launch, per-cell completion flags): flags, ticket, epoch
     bool use_fused = true;
     int fused_lpt = 0;           // longest-first order inside a fused launch (PMC_FUSED_LPT=1): measured equal pass
@@ -497,6 +499,10 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         if (const char *e = getenv("PMC_TICKETS")) h->ticket_lanes = atoi(e) == 1 ? 1 : PMC_TICKET_LANES;
         if (const char *e = getenv("PMC_NO_FUSED")) h->use_fused = !(e[0] == '1');
         if (const char *e = getenv("PMC_FUSED_LPT")) h->fused_lpt = (e[0] == '1') ? 1 : 0;
+        if (const char *e = getenv("PMC_ROUNDS")) {      // experiments; the API is pmc_set_rounds
+            const int rc = pmc_set_rounds(h, atoi(e));
+            if (rc) { g_err = h->err; pmc_destroy(h); return rc; }
+        }
     }
     CR(hipMalloc(&h->d_stats, (size_t)PMC_NSHARD * PMC_NSTATS * sizeof(unsigned long long)));
     CR(hipMemset(h->d_stats, 0, (size_t)PMC_NSHARD * PMC_NSTATS * sizeof(unsigned long long)));
@@ -599,6 +605,42 @@ extern "C" int pmc_download(pmc_system *h, double *pos, int32_t *species)
         HIPCHK(h, hipMemcpy(sp0.data(), h->d_species, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost));
         for (int i = 0; i < h->N; i++) species[i] = sp0[i] + 1;
     }
+    return PMC_OK;
+}
+
+// Schedule parameter m of the throughput engine: the sweeps of a call are taken in passes of min(m, sweeps
+// left) sweeps; a pass draws one grid shift, bins once, and every cell visit runs that many rounds of n_c proposal slots
+// against the neighbourhood it staged once.  m = 1 (default) re-shifts the grid every N attempted moves.
+extern "C" int pmc_set_rounds(pmc_system *h, int32_t rounds)
+{
+    if (!h || rounds < 1 || rounds > PMC_MAX_ROUNDS) return fail(h, PMC_ERR_BADARG, "pmc_set_rounds: rounds must be 1..16");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    if (!h->mc_ok) return fail(h, PMC_ERR_UNSUPPORTED, "checkerboard grid needs >= 4 cells of width >= rcut per side");
+    if ((long long)h->N * rounds > 0x7fffffffLL) return fail(h, PMC_ERR_BADARG, "pmc_set_rounds: N * rounds exceeds the 32-bit slot index");
+    if (rounds > h->slot_rounds) {
+        int rc = set_device(h);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const size_t n = (size_t)h->N * (size_t)rounds;
+        double *f = nullptr; uint32_t *w = nullptr; unsigned char *m = nullptr;
+        if (hipMalloc(&f, 4 * n * sizeof(double)) != hipSuccess || hipMalloc(&w, 2 * n * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc(&m, n) != hipSuccess) {
+            if (f) (void)hipFree(f);
+            if (w) (void)hipFree(w);
+            if (m) (void)hipFree(m);
+            return fail(h, PMC_ERR_HIP, "pmc_set_rounds: out of device memory for the proposal slots");
+        }
+        (void)hipFree(h->d_slot_f); (void)hipFree(h->d_slot_w); (void)hipFree(h->d_slot_m);
+        h->d_slot_f = f; h->d_slot_w = w; h->d_slot_m = m;
+        h->slot_rounds = rounds;
+    }
+    h->rounds = rounds;
+    return PMC_OK;
+}
+extern "C" int pmc_get_rounds(pmc_system *h, int32_t *rounds)
+{
+    if (!h || !rounds) return fail(h, PMC_ERR_BADARG, "pmc_get_rounds: null argument");
+    *rounds = h->rounds;
     return PMC_OK;
 }
 
@@ -873,6 +915,37 @@ extern "C" int pmc_get_neighbour_cells(pmc_system *h, int64_t c, int64_t *out, i
     for (int k = 0; k < cnt; k++) out[k] = (int64_t)h->h_nbr[(size_t)(c - 1) * h->nn + k] + 1;
     *n = cnt;
     return PMC_OK;
+}
+
+// (L::LinkedList)(system, i) (src/neighbours.jl:371-377) materialised: the ids the LinkedIterator (:316-365) yields for
+// particle i -- the chains of the neighbour cells of the cell that holds i, in table order, every chain from its head;
+// i itself is among them, as in the reference.  Compatibility path of hosts that iterate the list themselves (two
+// device-to-host copies of size N per call): the energy loops of this library never materialise it.
+extern "C" int pmc_neighbours_of(pmc_system *h, int64_t i, int64_t *out, int64_t cap, int64_t *n)
+{
+    if (!h || !n || i < 1 || i > h->N || (cap > 0 && !out)) return fail(h, PMC_ERR_BADARG, "pmc_neighbours_of: bad argument");
+    if (h->list_type != 1) return fail(h, PMC_ERR_UNSUPPORTED, "pmc_neighbours_of: the list type is not LinkedList");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    if (!h->cells_built) {
+        int rb = pmc_build_cells(h);
+        if (rb) return rb;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<int> head(h->ncell_ref), list(h->N);
+    int c = 0;
+    HIPCHK(h, hipMemcpy(head.data(), h->d_head, (size_t)h->ncell_ref * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(list.data(), h->d_list, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&c, h->d_cs + (i - 1), sizeof(int), hipMemcpyDeviceToHost));   // the list is current: cs[i] is the cell of x_i
+    int64_t cnt = 0;
+    for (int k = 0; k < h->h_nbrcnt[c]; k++) {
+        for (int j = head[h->h_nbr[(size_t)c * h->nn + k]]; j >= 0; j = list[j]) {
+            if (cnt < cap) out[cnt] = (int64_t)j + 1;
+            cnt++;
+        }
+    }
+    *n = cnt;
+    return cnt > cap ? fail(h, PMC_ERR_BADARG, "pmc_neighbours_of: the output buffer is too small (n holds the needed size)") : PMC_OK;
 }
 
 static RefArgs ref_args(pmc_system *h)
@@ -1214,6 +1287,7 @@ static CbArgs cb_args(pmc_system *h)
     // threshold of the FP32 pre-filter: rcut_max^2 (1 + 2^-12), rounded UP to float (pmc_kernels.h: error bound 2^-19)
     a.rc2f = std::nextafter((float)(h->maxcut * h->maxcut * (1.0 + 1.0 / 4096.0)), INFINITY);
     a.filter = h->use_filter ? 1 : 0;
+    a.rounds = 1;
     return a;
 }
 
@@ -1587,7 +1661,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     // long calls: the staging capacity is fitted again (cb_cap_learn) to what the last chunk of sweeps saw -- a first call on
     // a handle after 16 sweeps already
     const bool learn = cb_cap_sweep_adapts(h);
-    const bool learn_early = learn && h->cap_hint <= 0 && nsweeps > 48;
+    const bool learn_early = learn && h->cap_hint <= 0 && (nsweeps + h->rounds - 1) / h->rounds > 48;
     memset(h->kept_seen, 0, sizeof h->kept_seen);
     // The launch arguments of the sweep kernel live in device memory (k_cb_pass): all the sweeps of a chunk are prepared
     // here and uploaded at once.
@@ -1595,12 +1669,16 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     if (!h->d_cbtab) HIPCHK(h, hipMalloc(&h->d_cbtab, (size_t)PMC_ARGS_CHUNK * per_sweep * sizeof(CbArgs)));   // use_fused is fixed per handle
     std::vector<CbArgs> tabh;
     std::vector<std::array<double, 3>> shifts;
-    const size_t Ns = (size_t)h->N;
+    const size_t Ns = (size_t)h->N * (size_t)h->slot_rounds;
     const SlotOut slots{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
+    // the passes of this call (pmc_set_rounds): pass j covers the sweeps [pass_off[j], pass_off[j] + pass_k[j])
+    const int64_t npass = (nsweeps + h->rounds - 1) / h->rounds;
+    auto pass_off = [&](int64_t j) { return j * (int64_t)h->rounds; };
+    auto pass_k = [&](int64_t j) { return (int)std::min<int64_t>(h->rounds, nsweeps - j * (int64_t)h->rounds); };
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     h->cb_started = nsweeps > 0;
-    for (int64_t s0 = 0, ns = 0; s0 < nsweeps; s0 += ns) {
-        ns = std::min<int64_t>(learn_early && s0 == 0 ? 16 : chunk, nsweeps - s0);
+    for (int64_t s0 = 0, ns = 0; s0 < npass; s0 += ns) {
+        ns = std::min<int64_t>(learn_early && s0 == 0 ? 16 : chunk, npass - s0);
         if (learn && s0 > 0) {
             unsigned long long buckets[16];
             hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, h->stream, h->d_stats);
@@ -1616,7 +1694,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
         shifts.assign((size_t)ns, std::array<double, 3>{0.0, 0.0, 0.0});
         bool reset_flags = false;
         for (int64_t k = 0; k < ns; k++) {
-            const uint64_t g = h->sweep_ctr + (uint64_t)(s0 + k);
+            const uint64_t g = h->sweep_ctr + (uint64_t)pass_off(s0 + k);
             const uint32_t s_lo = (uint32_t)g, s_hi = (uint32_t)(g >> 32) & 0xffffffu;
             uint32_t W[4];
             philox4x32(0, 0, s_lo, s_hi | ((uint32_t)TAG_SHIFT << 24), h->key[0], h->key[1], W);
@@ -1628,6 +1706,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
             a.slot_tlnu = slots.tlnu; a.slot_dx = slots.dx; a.slot_dy = slots.dy; a.slot_dz = slots.dz;
             a.slot_w1 = slots.w1; a.slot_w2 = slots.w2; a.slot_m = slots.m;
             a.s_lo = s_lo; a.s_hi = s_hi;
+            a.rounds = pass_k(s0 + k);
             a.pool = mp;
             a.all_cells = 0;
             a.nactive = nactive;
@@ -1662,6 +1741,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
             SlotGen sg;
             memset(&sg, 0, sizeof sg);
             sg.enabled = 1;
+            sg.rounds = a0.rounds;
             sg.s_lo = a0.s_lo; sg.s_hi = a0.s_hi; sg.key0 = h->key[0]; sg.key1 = h->key[1];
             sg.temperature = h->p.temperature;
             sg.pool = mp;
@@ -1669,7 +1749,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
             rc = mc_bin(h, shifts[(size_t)k].data(), fuse_slots ? &sg : nullptr);
             if (rc) return rc;
             if (!fuse_slots) {      // large systems: own launch (coalesced stores)
-                const int nbs = nblk(h->N, 256);
+                const int nbs = (int)(((long long)h->N * sg.rounds + 255) / 256);
                 if (h->D == 3) hipLaunchKernelGGL(k_mc_slots<3>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
                 else hipLaunchKernelGGL(k_mc_slots<2>, dim3(nbs), dim3(256), 0, h->stream, h->N, h->d_ids, h->d_cell_of, h->d_start, sg);
             }
@@ -1679,7 +1759,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
             }
             // HIP events bracket the colour passes of every sweep on this stream; they are
             // read back after the final synchronize so the host never stalls the queue
-            const bool timed = out && sw < 4096;
+            const bool timed = out && sw < 4096;      // (sw: index of the pass)
             if (timed) {
                 while ((int64_t)h->pass_ev.size() < 2 * (sw + 1)) {
                     hipEvent_t e;
@@ -1704,7 +1784,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     hipLaunchKernelGGL(k_stats_fold, dim3(PMC_NSTATS), dim3(PMC_NSHARD), 0, h->stream, h->d_stats);   // counter copies -> copy 0
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, PMC_NSTATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    h->pending_launches_per_sweep = nsweeps > 0 ? (int)(launches / nsweeps) : ncol;
+    h->pending_launches_per_sweep = npass > 0 ? (int)(launches / npass) : ncol;    // (per pass)
     h->pending = true;
     h->pending_mode = PMC_CHECKERBOARD;
     h->pending_nsweeps = nsweeps;
@@ -1843,7 +1923,7 @@ static bool many_compatible(pmc_system **hs, int n)
         if (h == m) return false;
         for (int q = 0; q < r; q++) if (hs[q] == h) return false;
         if (h->p.device != m->p.device || h->D != m->D || h->N != m->N || h->S != m->S || h->kind != m->kind || h->team != m->team ||
-            h->use_filter != m->use_filter || !h->mc_ok || !h->use_fused || h->ncell_mc != m->ncell_mc)
+            h->use_filter != m->use_filter || !h->mc_ok || !h->use_fused || h->ncell_mc != m->ncell_mc || h->rounds != m->rounds)
             return false;
         for (int a = 0; a < 3; a++)
             if (h->grid.n[a] != m->grid.n[a] || h->grid.w[a] != m->grid.w[a] || h->p.box[a] != m->p.box[a]) return false;
@@ -1909,7 +1989,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     std::vector<ManyRep> reps((size_t)n);
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
-        const size_t Ns = (size_t)h->N;
+        const size_t Ns = (size_t)h->N * (size_t)h->slot_rounds;
         ManyRep &q = reps[(size_t)r];
         memset(&q, 0, sizeof q);
         q.pos_ro = h->d_pos; q.pos = h->d_pos; q.species = h->d_species;
@@ -1920,8 +2000,11 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         q.temperature = h->p.temperature;
         q.stats = h->d_stats; q.done = h->d_done;
     }
+    // the passes of this call (pmc_set_rounds; many_compatible: one value for all the handles)
+    const int rounds = m->rounds;
+    const int64_t npass = (nsweeps + rounds - 1) / rounds;
     const int64_t chunk = PMC_ARGS_CHUNK;
-    const int64_t cmax = std::min<int64_t>(chunk, nsweeps);
+    const int64_t cmax = std::min<int64_t>(chunk, npass);
     DevTmp d_reps, d_steps, d_args;
     HIPCHK(m, d_reps.alloc(reps.size() * sizeof(ManyRep)));
     HIPCHK(m, d_steps.alloc((size_t)cmax * n * sizeof(ManyStep)));
@@ -1934,15 +2017,16 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     const int mw_ = cb_minwaves(m, lds);
     const int grid = ncol * n * nactive;
     HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
-    for (int64_t s0 = 0; s0 < nsweeps; s0 += chunk) {
-        const int64_t ns = std::min<int64_t>(chunk, nsweeps - s0);
+    for (int64_t s0 = 0; s0 < npass; s0 += chunk) {
+        const int64_t ns = std::min<int64_t>(chunk, npass - s0);
         steps.assign((size_t)(ns * n), ManyStep{});
         argsh.assign((size_t)(ns * n), CbArgs{});
         for (int64_t sw = 0; sw < ns; sw++) {
             for (int r = 0; r < n; r++) {
                 pmc_system *h = hs[r];
-                const uint64_t g = h->sweep_ctr + (uint64_t)(s0 + sw);
+                const uint64_t g = h->sweep_ctr + (uint64_t)((s0 + sw) * rounds);
                 ManyStep &st = steps[(size_t)(sw * n + r)];
+                st.rounds = (int)std::min<int64_t>(rounds, nsweeps - (s0 + sw) * rounds);
                 st.s_lo = (uint32_t)g;
                 st.s_hi = (uint32_t)(g >> 32) & 0xffffffu;
                 uint32_t W[4];
@@ -1953,11 +2037,12 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
                 for (int q = 0; q < 3; q++) h->grid.shift[q] = st.shift[q];
                 CbArgs a = cb_args(h);
                 a.cap = cap_sweep;
-                const size_t Ns = (size_t)h->N;
+                const size_t Ns = (size_t)h->N * (size_t)h->slot_rounds;
                 a.order = nullptr;
                 a.slot_tlnu = h->d_slot_f; a.slot_dx = h->d_slot_f + Ns; a.slot_dy = h->d_slot_f + 2 * Ns; a.slot_dz = h->d_slot_f + 3 * Ns;
                 a.slot_w1 = h->d_slot_w; a.slot_w2 = h->d_slot_w + Ns; a.slot_m = h->d_slot_m;
                 a.s_lo = st.s_lo; a.s_hi = st.s_hi;
+                a.rounds = st.rounds;
                 a.pool = mp;
                 a.all_cells = 0;
                 a.nactive = nactive;
@@ -2004,7 +2089,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         pmc_system *h = hs[r];
         const unsigned long long *st = h->h_stats;
         h->sweep_ctr += (uint64_t)nsweeps;
-        h->epoch += (unsigned int)nsweeps;
+        h->epoch += (unsigned int)npass;
         h->cells_built = false;
         h->mc_binned = true;
         const int rcf = check_kernel_flags(h, st);
@@ -2020,7 +2105,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             for (int k = 0; k < PMC_MAX_MOVES; k++) { o.attempted[k] = (int64_t)st[k]; o.accepted[k] = (int64_t)st[8 + k]; }
             o.kernel_ms = ms;
             o.sweep_kernel_ms = 0.0;
-            o.sweep_kernel_launches = nsweeps;
+            o.sweep_kernel_launches = npass;
             o.energy = h->energy;
             o.energy_fix = h->e_fix;
             o.pair_tests = (int64_t)st[25];

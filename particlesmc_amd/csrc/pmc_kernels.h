@@ -156,6 +156,7 @@ struct MovePool {
 };
 struct SlotGen {
     int enabled;
+    int rounds;               // k of this pass: every cell has k n_c proposal slots, stored at index k start[c] + t (t < k n_c)
     uint32_t s_lo, s_hi, key0, key1;
     double temperature;
     MovePool pool;
@@ -183,7 +184,10 @@ __device__ __forceinline__ void mc_bin_c_body(const double *__restrict__ pos, co
     sy[dst] = pos[(size_t)i * D + 1];
     if (D == 3) sz[dst] = pos[(size_t)i * D + 2];
     ssp[dst] = (unsigned char)species[i];
-    if (gen.enabled) generate_slot<D>(gen, c, r, dst);
+    if (gen.enabled) {
+        const int nc = hi - lo;
+        for (int rr = 0; rr < gen.rounds; rr++) generate_slot<D>(gen, c, rr * nc + r, gen.rounds * lo + rr * nc + r);
+    }
 }
 
 template <int D>
@@ -219,7 +223,7 @@ struct ManyStep {
     double shift[3];
     uint32_t s_lo, s_hi;
     unsigned int epoch;
-    unsigned int pad;
+    int rounds;                // k of this pass (SlotGen::rounds)
 };
 
 template <int D>
@@ -272,6 +276,7 @@ __global__ void k_many_bin_c(int N, MovePool pool, const ManyRep *__restrict__ r
     const ManyStep &st = steps[blockIdx.y];
     SlotGen gen;
     gen.enabled = 1;
+    gen.rounds = st.rounds;
     gen.s_lo = st.s_lo; gen.s_hi = st.s_hi; gen.key0 = r.key0; gen.key1 = r.key1;
     gen.temperature = r.temperature;
     gen.pool = pool;
@@ -1152,10 +1157,14 @@ template <int D>
 __global__ __launch_bounds__(256) void k_mc_slots(int N, const int *__restrict__ ids, const int *__restrict__ cell_of,
                                                   const int *__restrict__ start, SlotGen g)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
+    // (grid: rounds * N threads, round slowest: the threads of one cell and round store to consecutive slots)
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (long long)N * g.rounds) return;
+    const int rr = (int)(j / N), k = (int)(j - (long long)rr * N);
     const int lin = cell_of[ids[k]];
-    generate_slot<D>(g, lin, k - start[lin], k);
+    const int lo = start[lin], nc = start[lin + 1] - lo;
+    const int t = rr * nc + (k - lo);
+    generate_slot<D>(g, lin, t, g.rounds * lo + t);
 }
 
 struct CbArgs {
@@ -1172,6 +1181,7 @@ struct CbArgs {
     int *species;
     int N, S;
     uint32_t key0, key1, s_lo, s_hi;
+    int rounds;                // k of this pass: a cell visit runs k n_c proposal slots (slot t of cell c: index k start[c] + t)
     int colour;
     int nactive;               // cells handled by this launch
     int all_cells;             // 1: every cell (total energy), 0: one colour
@@ -1602,8 +1612,8 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         h.p_tlnu = h.p_dx = h.p_dy = h.p_dz = 0.0;
         h.p_w1 = h.p_w2 = 0u;
         h.p_m = 0;
-        if (t < h.nc) {
-            const int ks = h.k0 + t;
+        if (t < h.nc * a.rounds) {
+            const int ks = a.rounds * h.k0 + t;
             h.p_m = (int)a.slot_m[ks];
             h.p_tlnu = a.slot_tlnu[ks];
             h.p_w1 = a.slot_w1[ks];
@@ -2605,7 +2615,8 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     const double my_shift = (lane == 0) ? a.shift[0] : ((lane == 1) ? a.shift[1] : a.shift[2]);
     const double my_w = (lane == 0) ? a.w[0] : ((lane == 1) ? a.w[1] : a.w[2]);
 
-    for (int chunk = 0; chunk < nc; chunk += PMC_WAVE) {
+    const int nsl = nc * a.rounds;     // proposal slots of this visit
+    for (int chunk = 0; chunk < nsl; chunk += PMC_WAVE) {
         // lanes generate the slots of this chunk in parallel
         int t = chunk + lane;
         int g_m = 0;
@@ -2619,8 +2630,8 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
             g_dx = h.p_dx;
             g_dy = h.p_dy;
             g_dz = h.p_dz;
-        } else if (t < nc) {
-            const int ks = h.k0 + t;
+        } else if (t < nsl) {
+            const int ks = a.rounds * h.k0 + t;
             g_m = ONE ? 0 : (int)a.slot_m[ks];
             g_tlnu = a.slot_tlnu[ks];
             g_w1 = a.slot_w1[ks];
@@ -2629,7 +2640,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
             g_dy = a.slot_dy[ks];
             if (D == 3) g_dz = a.slot_dz[ks];
         }
-        int nslots = min(PMC_WAVE, nc - chunk);
+        int nslots = min(PMC_WAVE, nsl - chunk);
 #ifdef PMC_DEBUG_NOSLOTS   // profiling builds only: price the staging alone
         nslots = 0;
 #endif

@@ -49,6 +49,10 @@ class LinkedList(NeighbourList):
     def neighbour_cells(self, c):
         return self._system.get_neighbour_cells(c)
 
+    def __call__(self, system, i):
+        """`linked_list(system, i)` (src/neighbours.jl:371-377): the neighbours of particle i in LinkedIterator order."""
+        return system.neighbours_of(i)
+
 
 class CellList(LinkedList):
     """CellList(box, rcut, N) -- src/neighbours.jl:61-217: per-cell vectors of ids (`cells`), iterated in vector

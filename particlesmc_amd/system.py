@@ -188,6 +188,18 @@ class Atoms(Particles):
         _lib.check(_lib.lib().pmc_get_verlet_neighbours(self._h, int(i), _lp(out), len(out), C.byref(n)), self._h)
         return out[: n.value].copy()
 
+    def neighbours_of(self, i):
+        """collect(neighbour_list(system, i)): the ids the reference's LinkedIterator yields for particle i
+        (src/neighbours.jl:316-377; 1-based, includes i itself)."""
+        out = np.zeros(1024, dtype=np.int64)
+        n = C.c_int64()
+        rc = _lib.lib().pmc_neighbours_of(self._h, int(i), _lp(out), len(out), C.byref(n))
+        if rc != 0 and n.value > len(out):
+            out = np.zeros(n.value, dtype=np.int64)
+            rc = _lib.lib().pmc_neighbours_of(self._h, int(i), _lp(out), len(out), C.byref(n))
+        _lib.check(rc, self._h)
+        return out[: n.value].copy()
+
     def get_neighbour_cells(self, c):
         out = np.zeros(27, dtype=np.int64)
         n = C.c_int32()
@@ -235,6 +247,18 @@ class Atoms(Particles):
         a, b = C.c_uint64(), C.c_uint64()
         _lib.check(_lib.lib().pmc_get_counters(self._h, C.byref(a), C.byref(b)), self._h)
         return a.value, b.value
+
+    # --- schedule parameter of the throughput engine (no reference counterpart) -----------------
+    @property
+    def rounds(self):
+        """m: sweeps per pass = rounds of n_c proposal slots a cell visit runs against its staged neighbourhood."""
+        r = C.c_int32()
+        _lib.check(_lib.lib().pmc_get_rounds(self._h, C.byref(r)), self._h)
+        return r.value
+
+    @rounds.setter
+    def rounds(self, m):
+        _lib.check(_lib.lib().pmc_set_rounds(self._h, int(m)), self._h)
 
 
 def get_position(system, i):                 # src/ParticlesMC.jl:41

@@ -46,6 +46,18 @@ static void layout(void)
 #undef F
 }
 
+/* sum(::Vector{Float64}) as the oracle restates it (oracle/pmc_oracle.c pairwise_sum: blocks of 1024, sequential leaves) */
+static double pairwise_sum(const double *v, int64_t lo, int64_t hi)
+{
+    if (hi - lo < 1024) {
+        double a = v[lo];
+        for (int64_t k = lo + 1; k <= hi; k++) a += v[k];
+        return a;
+    }
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    return pairwise_sum(v, lo, mid) + pairwise_sum(v, mid + 1, hi);
+}
+
 int main(int argc, char **argv)
 {
     pmc_system *h = NULL;
@@ -79,13 +91,23 @@ int main(int argc, char **argv)
     CHECK(pmc_box_from_density(N, rho, d, &box1));
     for (int a = 0; a < d; a++) p.box[a] = box1;
     CHECK(pmc_linked_list_geometry(d, p.box, rcut, p.cell, p.ncells));
+    /* System(...) in the reference's own order (src/atoms.jl:44-56):
+     *   :44 energy = Vector{T}(undef, 1)                          -- NOTHING to hand over yet
+     *   :47 list_type(box, maxcut, N)                             -- HIPLinkedList ctor (geometry above)
+     *   :50 build_neighbour_list!(system)                         -- create + upload + build; no pmc_set_energy here
+     *   :51 [compute_energy_particle(system, i, nl) for i]        -- N calls through the glue's overload
+     *   :52 sum(local_energy) / 2                                 -- on the host (Julia's pairwise sum)
+     *   :56 system.energy[1] = energy                             -- a plain store in a Julia Vector: the glue never sees it
+     * The library's running energy is garbage-in-waiting until the first handover!() (top of every entry point below). */
     CHECK(pmc_create(&p, &h));
     CHECK(pmc_upload(h, pos, sp));
     CHECK(pmc_build_cells(h));
-    double e_init;
-    CHECK(pmc_init_energy(h, &e_init));        /* System(...) computes it once (src/atoms.jl:50-56) ... */
-    CHECK(pmc_set_energy(h, e_init));          /* ... and the glue hands system.energy[1] over */
-    fprintf(fo, "energy0 %.17g\n", e_init);
+    double *local = malloc((size_t)N * sizeof(double));
+    for (int64_t i = 1; i <= N; i++) CHECK(pmc_energy_particle(h, i, &local[i - 1]));
+    double system_energy = pairwise_sum(local, 0, N - 1) / 2.0;     /* the Julia-side system.energy[1] from here on */
+    free(local);
+    fprintf(fo, "energy0 %.17g\n", system_energy);
+#define HANDOVER() CHECK(pmc_set_energy(h, system_energy))          /* PMCHip.handover!(system) */
 
     /* ---- getproperty(L, :cs) ------------------------------------------------------------------------------------ */
     int64_t *cs = malloc((size_t)N * sizeof(int64_t));
@@ -93,6 +115,23 @@ int main(int argc, char **argv)
     fprintf(fo, "cs");
     for (int64_t i = 0; i < N; i++) fprintf(fo, " %lld", (long long)cs[i]);
     fprintf(fo, "\n");
+
+    /* ---- (L::HIPLinkedList)(system, i): the LinkedIterator's ids, first with the glue's 1024-entry buffer ------------ */
+    for (int64_t i = 1; i <= N; i += N / 3 + 1) {
+        int64_t nb[1024], nn = 0;
+        CHECK(pmc_neighbours_of(h, i, nb, 1024, &nn));
+        fprintf(fo, "neighbours %lld", (long long)i);
+        for (int64_t k = 0; k < nn; k++) fprintf(fo, " %lld", (long long)nb[k]);
+        fprintf(fo, "\n");
+    }
+    {   /* a buffer that is too small: status != 0, n = the needed size, and the retry with that size succeeds */
+        int64_t tiny[4], nn = 0;
+        if (pmc_neighbours_of(h, 1, tiny, 4, &nn) == 0 || nn <= 4) { fprintf(stderr, "pmc_neighbours_of accepted a short buffer\n"); return 2; }
+        int64_t *big = malloc((size_t)nn * sizeof(int64_t)), n2 = 0;
+        CHECK(pmc_neighbours_of(h, 1, big, nn, &n2));
+        fprintf(fo, "neighbours_retry %lld %lld\n", (long long)nn, (long long)n2);
+        free(big);
+    }
 
     /* ---- compute_energy_particle(system, i, L): 1-based id, Ref{Float64} out ---------------------------------------- */
     for (int64_t i = 1; i <= N; i += N / 7 + 1) {
@@ -105,13 +144,17 @@ int main(int argc, char **argv)
     {
         const int64_t i = 5;
         double delta[3] = {0.031, -0.017, 0.044}, e1 = 0, e2 = 0, de = 0, en = 0;
+        HANDOVER();                                                 /* the FIRST use of the running energy after System() */
         CHECK(pmc_displacement_perform(h, i, delta, &e1, &e2, &de));
+        system_energy += de;                                        /* the reference's wrapper, on the host (src/moves.jl:11-20) */
         CHECK(pmc_get_energy(h, &en));
-        fprintf(fo, "disp_perform %.17g %.17g %.17g %.17g\n", e1, e2, de, en);
+        fprintf(fo, "disp_perform %.17g %.17g %.17g %.17g %.17g\n", e1, e2, de, en, system_energy);
         double minus[3] = {-delta[0], -delta[1], -delta[2]};       /* invert_action! negated it (src/moves.jl:88-90) */
+        HANDOVER();
         CHECK(pmc_displacement_revert(h, i, minus, de));
+        system_energy -= de;                                        /* src/moves.jl:79, in the glue's revert_action! */
         CHECK(pmc_get_energy(h, &en));
-        fprintf(fo, "disp_revert %.17g\n", en);
+        fprintf(fo, "disp_revert %.17g %.17g\n", en, system_energy);
     }
 
     /* ---- perform_action!(DiscreteSwap) / revert_action! ------------------------------------------------------------- */
@@ -119,12 +162,16 @@ int main(int argc, char **argv)
         int64_t i = 0, j = 0;
         for (int64_t k = 0; k < N && (!i || !j); k++) { if (sp[k] == 1 && !i) i = k + 1; if (sp[k] == 2 && !j) j = k + 1; }
         double e1 = 0, e2 = 0, de = 0, en = 0;
+        HANDOVER();
         CHECK(pmc_swap_perform(h, i, j, &e1, &e2, &de));
+        system_energy += de;
         CHECK(pmc_get_energy(h, &en));
-        fprintf(fo, "swap_perform %lld %lld %.17g %.17g %.17g %.17g\n", (long long)i, (long long)j, e1, e2, de, en);
+        fprintf(fo, "swap_perform %lld %lld %.17g %.17g %.17g %.17g %.17g\n", (long long)i, (long long)j, e1, e2, de, en, system_energy);
+        HANDOVER();
         CHECK(pmc_swap_revert(h, j, i, de));                       /* the inverted action swaps the roles of i and j */
+        system_energy -= de;                                        /* src/moves.jl:206 */
         CHECK(pmc_get_energy(h, &en));
-        fprintf(fo, "swap_revert %.17g\n", en);
+        fprintf(fo, "swap_revert %.17g %.17g\n", en, system_energy);
     }
 
     /* ---- make_step!(sim, HIPMetropolis): one scheduler tick = pmc_sweep(h, mode, pool, npool, 1, Ref{Stats}) --------- */
@@ -136,7 +183,9 @@ int main(int argc, char **argv)
     for (int mode = 0; mode <= 1; mode++) {                         /* 0 = the reference's sequential chain, 1 = checkerboard */
         pmc_stats st;
         memset(&st, 0, sizeof st);
+        HANDOVER();
         CHECK(pmc_sweep(h, mode, pool, npool, 1, &st));
+        system_energy = st.energy;                                  /* make_step!: system.energy[1] = st[].energy */
         fprintf(fo, "sweep %d %lld %lld %lld %lld %.17g %lld\n", mode, (long long)st.attempted[0], (long long)st.accepted[0],
                 (long long)st.attempted[1], (long long)st.accepted[1], st.energy, (long long)st.energy_fix);
     }
@@ -144,8 +193,10 @@ int main(int argc, char **argv)
     /* ---- sweep_many!: begin on every handle, then end on every handle (here: one handle, two rounds) ----------------- */
     for (int round = 0; round < 2; round++) {
         pmc_stats st;
+        HANDOVER();
         CHECK(pmc_sweep_begin(h, PMC_CHECKERBOARD, pool, npool, 2));
         CHECK(pmc_sweep_end(h, &st));
+        system_energy = st.energy;
         fprintf(fo, "sweep_many %lld %lld %.17g %lld\n", (long long)st.attempted[0], (long long)st.accepted[0], st.energy, (long long)st.energy_fix);
     }
 
@@ -184,8 +235,9 @@ int main(int argc, char **argv)
         CHECK(pmc_create(&p2, &h2));
         CHECK(pmc_upload(h2, pos, sp));       /* pos / sp: the first chain's current state (refresh! above) */
         double e2 = 0;
-        CHECK(pmc_init_energy(h2, &e2));
-        CHECK(pmc_set_energy(h2, e2));
+        CHECK(pmc_init_energy(h2, &e2));      /* (the second chain's System(): the same steps as above, in one call) */
+        CHECK(pmc_set_energy(h2, e2));        /* handover!(systems[2]) */
+        HANDOVER();                           /* handover!(systems[1]) */
         CHECK(pmc_set_temperature(h, T));
         pmc_system *hs[2] = {h, h2};
         pmc_stats st2[2];

@@ -74,6 +74,76 @@ def test_c2_lj_32768_against_oracle_one_sweep(gpu):
     assert st.accepted[0] == acc[0] and np.array_equal(g.position, cb.positions()) and st.energy_fix == cb.energy_fix
 
 
+def test_benchmarked_kernel_instance_against_oracle_at_a_million(gpu):
+    """bench.py's workload, kernel instance and state, compared with the oracle where it is benchmarked: N = 10^6 on the
+    default path (one wavefront per cell, fused staging, learnt LDS capacity, fused colour launch).  (1) the first sweep
+    from the jittered lattice; (2) the sweep after 1000 GPU sweeps -- the liquid bench.py times -- restated by
+    `orc_cb_sweeps` from the downloaded state at the same sweep counter.  Positions, accept count and the exact energy
+    must be bit-equal.  (Reference chain: src/moves.jl:57-81; schedule: DESIGN.md 2.2.)"""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(100, jitter=0.05, seed=42)
+    N = len(pos)
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.05}])
+    g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+    box = np.asarray(g.box, dtype=np.float64)
+    models = O.single(O.lennard_jones(1.0, 1.0))
+    cb = O.Checkerboard(pos, sp, box, 1.0, models, seed=42)
+    _, fix0 = g.total_energy()
+    assert fix0 == cb.energy_fix
+    st = pmc.mc_sweep(g, _pool(pmc), nsweeps=1)
+    att, acc = cb.sweeps(opool, 0, 1)
+    assert st.attempted[0] == att[0] == N and st.accepted[0] == acc[0]
+    assert st.energy_fix == cb.energy_fix
+    assert np.array_equal(g.position, cb.positions())
+    del cb
+    # the liquid: 999 more sweeps on the GPU (the capacity of the LDS staging is learnt on the way), then sweep 1000
+    st = pmc.mc_sweep(g, _pool(pmc), nsweeps=999)
+    assert g.get_counters()[1] == 1000
+    liquid = g.position.copy()
+    assert st.energy / N < -5.0 and 0.38 < st.accepted[0] / st.attempted[0] < 0.43
+    cb = O.Checkerboard(liquid, sp, box, 1.0, models, seed=42)
+    assert cb.energy_fix == st.energy_fix                       # running energy after 10^9 moves == oracle from scratch
+    st = pmc.mc_sweep(g, _pool(pmc), nsweeps=1)
+    att, acc = cb.sweeps(opool, 1000, 1)
+    assert st.accepted[0] == acc[0] and st.energy_fix == cb.energy_fix
+    assert np.array_equal(g.position, cb.positions())
+    assert st.pair_tests > 0 and st.null_moves > 0              # the filtered (not the direct) path did the work
+
+
+def test_c3_kob_andersen_100k_against_oracle(gpu):
+    """Config 3 at its benchmark size and pool (N = 10^5 KA 80:20, rho = 1.2, 90 % Displacement + 10 % DiscreteSwap):
+    two sweeps from the lattice and one sweep from the state after 300 GPU sweeps, bit-equal to `orc_cb_sweeps`
+    (positions, species, per-move accept counts, exact energy)."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = binary_lattice(100000, frac_b=0.2, rho=1.2, jitter=0.05, seed=42)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.KobAndersen(), seed=42)
+    pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.05}, 0.9),
+            pmc.Move(pmc.DiscreteSwap([1, 2], g), pmc.DoubleUniform(), [], 0.1)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.9},
+                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}])
+    box = np.asarray(g.box, dtype=np.float64)
+    models = O.kob_andersen()
+    cb = O.Checkerboard(pos, sp, box, 1.0, models, seed=42)
+    st = pmc.mc_sweep(g, pool, nsweeps=2)
+    att, acc = cb.sweeps(opool, 0, 2)
+    assert list(st.attempted[:2]) == list(att) and list(st.accepted[:2]) == list(acc)
+    assert st.energy_fix == cb.energy_fix
+    assert np.array_equal(g.position, cb.positions()) and np.array_equal(g.species, cb.species())
+    del cb
+    st = pmc.mc_sweep(g, pool, nsweeps=298)
+    p1, s1 = g.position.copy(), g.species.copy()
+    assert st.accepted[1] > 1000 and not np.array_equal(s1, sp)
+    cb = O.Checkerboard(p1, s1, box, 1.0, models, seed=42)
+    assert cb.energy_fix == st.energy_fix
+    st = pmc.mc_sweep(g, pool, nsweeps=1)
+    att, acc = cb.sweeps(opool, 300, 1)
+    assert list(st.attempted[:2]) == list(att) and list(st.accepted[:2]) == list(acc)
+    assert st.energy_fix == cb.energy_fix
+    assert np.array_equal(g.position, cb.positions()) and np.array_equal(g.species, cb.species())
+
+
 def test_c3_kob_andersen_100k_properties(gpu):
     """Config 3: N = 10^5 KA 80:20 at rho = 1.2 with 90 % Displacement + 10 % DiscreteSwap."""
     pmc = gpu

@@ -88,6 +88,63 @@ def test_julia_struct_layouts_equal_the_c_header_and_the_ctypes_mirror(harness):
             assert fname == cf == ctname, (fname, cf, ctname)
 
 
+def _jl_functions():
+    """{first line: body} of every `function ... end` block and one-line method of the glue (column-0 definitions)."""
+    txt = open(JL).read()
+    out = {}
+    for m in re.finditer(r"^function ([^\n]*)\n(.*?)^end", txt, re.S | re.M):
+        out[m.group(1)] = m.group(2)
+    for m in re.finditer(r"^([A-Za-z_.!]+\([^\n]*\)(?: where \{[^}]*\})?) = ([^\n]*(?:\n {8,}[^\n]*)*)", txt, re.M):
+        out[m.group(1)] = m.group(2)
+    return out
+
+
+def test_glue_never_assigns_to_a_field_of_the_immutable_atoms_struct():
+    """`Atoms` is an immutable struct (reference src/atoms.jl:18): `system.<field> = ...` throws.  Elements of its
+    arrays (`system.energy[1] = `, `system.species .= `) are fine.  Also: nothing of the glue may read system.energy
+    inside build_neighbour_list! (undef at src/atoms.jl:50), and every entry point that depends on the running energy
+    hands it over first."""
+    txt = open(JL).read()
+    code = "\n".join(ln.split("#")[0] for ln in txt.split("\n"))
+    fields = "position|species|density|energy|temperature|model_matrix|N|d|box|neighbour_list|species_list"
+    bad = re.findall(r"\b(?:system|s|sys)\.(?:" + fields + r")\s*(?:=(?!=)|\+=|-=|\*=)", code)
+    assert bad == [], bad
+    assert re.search(r"\bs\.temperature\b", code) is None            # (the round-2 text assigned it in two places)
+    fns = _jl_functions()
+    build = [b for k, b in fns.items() if k.startswith("ParticlesMC.build_neighbour_list!")]
+    assert len(build) == 1
+    body = "\n".join(ln.split("#")[0] for ln in build[0].split("\n"))
+    assert "energy" not in body and ":pmc_set_energy" not in body
+    needs = [k for k, b in fns.items() if any(sym in b for sym in (":pmc_displacement_perform", ":pmc_displacement_revert", ":pmc_swap_perform",
+                                                                   ":pmc_swap_revert", ":pmc_sweep,", ":pmc_sweep_many", ":pmc_replica_exchange"))]
+    assert len(needs) >= 7, needs
+    for k in needs:
+        b = fns[k]
+        first_call = min(b.find(sym) for sym in (":pmc_displacement", ":pmc_swap", ":pmc_sweep", ":pmc_replica") if sym in b)
+        assert "handover!" in b[:first_call], k
+    # reverts restore the host-side running energy exactly as src/moves.jl:79 and :206 do
+    for k, b in fns.items():
+        if k.startswith("Arianna.revert_action!"):
+            assert "system.energy[1] -= action.δe" in b, k
+    # the temperature of a HIP-backed chain is read from the handle by both target-density functions (src/utils.jl:4-10)
+    assert "Arianna.delta_log_target_density(e1, e2, system::ParticlesMC.Atoms{D,V,<:HIPLinkedList})" in txt
+    assert "Arianna.unnormalised_log_target_density(e, system::ParticlesMC.Atoms{D,V,<:HIPLinkedList})" in txt
+    assert "function (L::HIPLinkedList)(system::ParticlesMC.Particles, i::Int)" in txt and ":pmc_neighbours_of" in txt
+
+
+def test_replay_follows_the_reference_constructor_order():
+    """tests/c/glue_replay.c must perform System()'s steps in the order of src/atoms.jl:47-56: create/upload/build, THEN the
+    N compute_energy_particle calls and the host sum, and only afterwards the first pmc_set_energy."""
+    src = re.sub(r"/\*.*?\*/", "", open(SRC).read(), flags=re.S)      # code only
+    main = src[src.index("int main("):]
+    i_build = main.index("pmc_build_cells(h)")
+    i_loop = main.index("pmc_energy_particle(h, i, &local[i - 1])")
+    i_sum = main.index("pairwise_sum(local, 0, N - 1) / 2.0")
+    i_first_set = main.index("HANDOVER();")
+    assert i_build < i_loop < i_sum < i_first_set
+    assert "pmc_set_energy" not in main[:i_sum] and "pmc_init_energy" not in main[:i_first_set]
+
+
 def test_glue_declares_an_abstract_rng_over_the_sequential_words():
     txt = open(JL).read()
     assert "struct SequentialWords <: Random.AbstractRNG" in txt and ":pmc_sequential_words" in txt
@@ -125,16 +182,24 @@ def test_glue_call_sequences_replayed_in_c_match_the_oracle(gpu, harness, tmp_pa
     assert np.array_equal(np.array(out["cs"][0], dtype=np.int64), o.cells())
     for i, e in out["e_particle"]:
         assert float(e) == o.energy_particle(int(i))
+    # (L::HIPLinkedList)(system, i): the LinkedIterator's sequence (src/neighbours.jl:316-377), i itself included
+    assert len(out["neighbours"]) == 3
+    for row in out["neighbours"]:
+        assert np.array_equal(np.array(row[1:], dtype=np.int64), o.neighbours_of(int(row[0]))) and int(row[0]) in [int(v) for v in row[1:]]
+    assert out["neighbours_retry"][0][0] == out["neighbours_retry"][0][1] and int(out["neighbours_retry"][0][0]) == len(o.neighbours_of(1))
     delta = np.array([0.031, -0.017, 0.044])
     r = o.displacement_perform(5, delta)
-    assert tuple(float(v) for v in out["disp_perform"][0][:3]) == r and float(out["disp_perform"][0][3]) == o.energy
+    # (column 4: the library's running energy; column 5: the host-side system.energy[1] the glue keeps: they must stay equal)
+    assert tuple(float(v) for v in out["disp_perform"][0][:3]) == r
+    assert float(out["disp_perform"][0][3]) == o.energy == float(out["disp_perform"][0][4])
     o.displacement_revert(5, -delta, r[2])
-    assert float(out["disp_revert"][0][0]) == o.energy
+    assert float(out["disp_revert"][0][0]) == o.energy == float(out["disp_revert"][0][1])
     i, j = int(out["swap_perform"][0][0]), int(out["swap_perform"][0][1])
     r = o.swap_perform(i, j, 1, 2)
-    assert tuple(float(v) for v in out["swap_perform"][0][2:5]) == r and float(out["swap_perform"][0][5]) == o.energy
+    assert tuple(float(v) for v in out["swap_perform"][0][2:5]) == r
+    assert float(out["swap_perform"][0][5]) == o.energy == float(out["swap_perform"][0][6])
     o.swap_revert(j, i, 1, 2, r[2])
-    assert float(out["swap_revert"][0][0]) == o.energy
+    assert float(out["swap_revert"][0][0]) == o.energy == float(out["swap_revert"][0][1])
     pool = O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.8},
                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.2}])
     # make_step! in sequential mode: N steps of the reference chain (seed 77, chain 3, from step 0)
