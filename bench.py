@@ -10,7 +10,11 @@ One "step" = one sweep = N attempted moves.  With --gpus N every rank runs its o
 independent chain (seed 42 + rank) on its own GPU: weak scaling, no data-path
 collective (reference: src/IO/IO.jl:319-327, src/ParticlesMC.jl:164,246).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--lattice 100] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--rounds M] [--lattice 100] [--no-cpu]
+
+The headline `value` runs the schedule with M = 4 sweeps per grid shift (pmc_set_rounds); the same liquid is
+timed with M = 1 (what rounds 1-2 timed) and M = 2 in the same run ("by_rounds"), and what an attempted move of each is
+worth in attempted moves of the reference's sequential chain is measured beside them ("move_efficiency_vs_sequential").
 
 `--gpus N` with N > 1 started plainly (no WORLD_SIZE in the environment) launches the N ranks
 itself through `python -m torch.distributed.run` (one process per GPU, RCCL rendezvous on
@@ -35,9 +39,11 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz = half the 157.3 TF FP32 vector peak
+FP32_VECTOR_PEAK_TFLOPS = 157.3
 FP64_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0   # FP64 wave-instructions/s: one per 4 cycles per SIMD
 SIGMA_MOVE = 0.05
 TEMPERATURE = 1.0
+LATTICE_WARMUP, LATTICE_STEPS = 5, 20     # the protocol of the "from_lattice" figure: what rounds 1-2 timed
 # algorithmic flop model of the pair loop: one distance test = 3 sub + 3 mul + 2 add + 1 compare,
 # one Lennard-Jones pair energy = 1 div + 5 mul + 2 sub + 1 accumulate (src/models.jl:30-34,121-123)
 FLOP_PER_PAIR_TEST = 9
@@ -68,18 +74,18 @@ def cpu_baseline(pos, sp, rho, budget_moves):
     dt = time.perf_counter() - t0
     return {
         "value": n / dt, "unit": "attempted moves/s", "cores": 1, "kind": "port",
-        "sample": f"{n} sequential Displacement steps (reference LinkedList path, oracle/pmc_oracle.c) on the same "
-                  f"N={len(pos)} input after a {t_build:.1f} s build; acceptance {acc[0] / max(1, att[0]):.3f}",
+        "sample": f"{n} sequential Displacement steps (reference LinkedList path, oracle/pmc_oracle.c) from the state the "
+                  f"GPU's timed region starts from (N={len(pos)}), after a {t_build:.1f} s build; acceptance {acc[0] / max(1, att[0]):.3f}",
     }
 
 
 def _cpu_worker(args):
     """One independent chain of the oracle's sequential path (own process = own host core)."""
-    lattice, chain, nsteps = args
+    state_path, rho, chain, nsteps = args
     sys.path.insert(0, ROOT)
     from oracle import oracle as O
-    from particlesmc_amd.workloads import lj_lattice
-    pos, sp, rho = lj_lattice(lattice, jitter=0.05, seed=42)
+    pos = np.load(state_path)
+    sp = np.ones(len(pos), dtype=np.int32)
     ref = O.System(pos, sp, rho, TEMPERATURE, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
     pool = O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}])
     ref.mc_steps(pool, 42 + chain, chain, 0, 2000)
@@ -88,21 +94,25 @@ def _cpu_worker(args):
     return nsteps, time.perf_counter() - t0
 
 
-def cpu_baseline_multicore(lattice, single_rate, max_cores=32):
-    """one independent chain per host core (reference `parallel=true`),
+def cpu_baseline_multicore(pos, rho, single_rate, max_cores=32):
+    """one independent chain per host core (reference `parallel=true`) from the same state,
     bounded to `max_cores` processes of ~10 s each; aggregate attempted moves/s."""
     import multiprocessing as mp
+    import tempfile
     cores = max(1, min(max_cores, os.cpu_count() or 1))
     nsteps = int(max(20000, single_rate * 2.5))    # chains slow each other down ~4x (shared caches, DRAM)
     ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(lattice, c, nsteps) for c in range(cores)])
-    wall = time.perf_counter() - t0
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "state.npy")
+        np.save(path, pos)
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(path, rho, c, nsteps) for c in range(cores)])
+        wall = time.perf_counter() - t0
     tmax = max(r[1] for r in res)
     return {"value": sum(r[0] for r in res) / tmax, "unit": "attempted moves/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} independent chains (one process per core), {nsteps} sequential steps each on the "
-                      f"same N input; slowest chain {tmax:.1f} s, {wall:.1f} s including the builds"}
+            "sample": f"{cores} independent chains (one process per core), {nsteps} sequential steps each from the "
+                      f"same state; slowest chain {tmax:.1f} s, {wall:.1f} s including the builds"}
 
 
 # ---- launcher: `bench.py --gpus N` started plainly ------------------------------------------
@@ -152,14 +162,18 @@ class _StubEngine:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lattice", type=int, default=100, help="lattice sites per side (N = lattice^3)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (baseline and move efficiency)")
     ap.add_argument("--equilibrate", type=int, default=1000,
                     help="untimed sweeps that melt the jittered lattice into the rho = 1, T = 1 liquid before the warm-up "
                          "(0: time the first sweeps from the lattice instead, as rounds 1-2 did; with > 0 that figure is still "
                          "measured first and reported as \"from_lattice\")")
+    ap.add_argument("--rounds", type=int, default=4,
+                    help="schedule parameter m of the headline figure (pmc_set_rounds: sweeps per grid shift = proposal rounds per "
+                         "cell visit); m = 1 -- what rounds 1-2 timed -- and m = 2 are timed in the same run and reported beside it")
+    ap.add_argument("--long-steps", type=int, default=1000, help="steps of the secondary, longer timed region (0: skip)")
     ap.add_argument("--share-devices", action="store_true",
                     help="functional testing only: allow more ranks than visible GPUs (ranks share devices, gloo reductions)")
     return ap.parse_args(argv)
@@ -169,26 +183,46 @@ def roofline_objects(N, steps, st, avg_launch_s, moves_per_launch, ncell_ref):
     """The bench line's roofline fields.  Everything under "roofline" is measured in
     THIS run (kernel counters + HIP events) except the entries that carry a "source"."""
     b_alg = algorithmic_bytes_per_move(N, 3, ncell_ref)
-    moves_timed = float(N) * steps
+    moves_timed = float(N) * steps            # the counters cover every sweep of the call
     tests = float(getattr(st, "pair_tests", 0))
     inrange = float(getattr(st, "pairs_in_range", 0))
+    dense = float(getattr(st, "dense_evals", 0))
+    staged = float(getattr(st, "staged_candidates", 0))
+    written = float(getattr(st, "written_back", 0))
     flop_per_move = (tests * FLOP_PER_PAIR_TEST + inrange * FLOP_PER_PAIR_ENERGY) / moves_timed if tests > 0 else None
     roof = {
         "bound": "fp64-valu", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
         "achieved": None, "frac": None, "traffic": None,
-        "kernel": "k_cb_pass<3,LJ,single-species> (one launch = one fused sweep of all 8 colours)",
+        "kernel": "k_cb_pass<3,LJ,single-species> (one launch = one pass: all 8 colours, `rounds` sweeps)",
         "moves_per_launch": moves_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
         "flop_model": {"per_pair_test": FLOP_PER_PAIR_TEST, "per_pair_energy": FLOP_PER_PAIR_ENERGY,
                        "pair_tests_per_move": tests / moves_timed if tests > 0 else None,
                        "pair_energies_per_move": inrange / moves_timed if tests > 0 else None,
                        "flop_per_move": flop_per_move,
-                       "note": "pair tests and in-range pair energies are COUNTED by the kernel in this run "
-                               "(cell-leaving proposals test nothing); flop = tests*9 + energies*9, FMA-free FP64 "
-                               "operation counts of the reference arithmetic; peak counts an FMA as 2"},
+                       "note": "ALGORITHMIC flop: every (candidate, position) distance test the schedule needs after the box "
+                               "filter and every in-range pair energy, COUNTED by the kernel in this run and priced as the FP64 "
+                               "operations of the reference arithmetic (9 + 9, FMA-free; the peak counts an FMA as 2).  The kernel "
+                               "EXECUTES most of the tests in packed FP32 (pre-filter): see `executed`"},
     }
     if flop_per_move is not None:
         roof["achieved"] = flop_per_move * moves_per_launch / avg_launch_s / 1e12
         roof["frac"] = roof["achieved"] / FP64_VECTOR_PEAK_TFLOPS
+        # what the kernel executes, by precision: FP64 = distance evaluations of the pre-filter's survivors + pair energies;
+        # FP32 = the pre-filter's distance tests (two per packed instruction lane)
+        f64 = (dense * FLOP_PER_PAIR_TEST + inrange * FLOP_PER_PAIR_ENERGY) / moves_timed
+        f32 = tests * FLOP_PER_PAIR_TEST / moves_timed
+        rate = moves_per_launch / avg_launch_s / 1e12
+        roof["executed"] = {"fp64_flop_per_move": f64, "fp64_TFLOPs": f64 * rate, "fp64_frac_of_peak": f64 * rate / FP64_VECTOR_PEAK_TFLOPS,
+                            "fp32_flop_per_move": f32, "fp32_TFLOPs": f32 * rate, "fp32_frac_of_peak": f32 * rate / FP32_VECTOR_PEAK_TFLOPS,
+                            "dense_evals_per_move": dense / moves_timed}
+    # bytes the schedule moves, from counts the kernel takes in this run: every candidate a visit loads (3 doubles), every
+    # proposal slot it reads (4 doubles + 2 words + 1 byte), every particle it writes back (sorted copy + position array)
+    if staged > 0:
+        sched = (staged * 24.0 + moves_timed * 41.0 + written * 48.0) / moves_timed * moves_per_launch
+        roof["schedule_bytes"] = {"per_launch": sched, "GBps": sched / avg_launch_s / 1e9, "frac_of_hbm_peak": sched / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                                  "staged_candidates_per_move": staged / moves_timed, "written_back_per_move": written / moves_timed,
+                                  "note": "counted in-run: 24 B per staged candidate + 41 B per proposal slot + 48 B per written-back particle; "
+                                          "the binning kernels' traffic (about 100 B per particle and pass) is not included"}
     # the SURVEY 8(d) contract figure, kept as a clearly named secondary field: it is NOT a fraction of anything
     # the kernel is bound by (the neighbourhood is staged once per cell visit and reused from LDS)
     contract = b_alg * moves_per_launch / avg_launch_s / 1e9
@@ -218,6 +252,66 @@ def roofline_objects(N, steps, st, avg_launch_s, moves_per_launch, ncell_ref):
         except Exception as exc:      # a malformed profile summary must not cost the bench line
             roof["traffic_source"] = f"profiles/traffic.json unreadable: {exc!r}"
     return roof
+
+
+def move_efficiency(pmc, rounds_list):
+    """What an attempted move of the checkerboard schedule is worth in attempted moves of the reference's sequential chain
+    (src/moves.jl:57-81): mean-square displacement per attempted move, checkerboard (device) over sequential (oracle), on an
+    N = 4096 liquid at the benchmark's state point and cell width (6 cells of 2.667).  A bounded sample: 8 chains of 300
+    sweeps per leg (about 10 s of CPU on 8 host cores).  The integrated autocorrelation time of e/N needs ~100x the CPU
+    time: it is measured by tests/test_gpu_efficiency.py / examples/move_efficiency.py and replayed with its source."""
+    from oracle import efficiency as E
+    from particlesmc_amd.workloads import lj_lattice
+    pos, sp, rho = lj_lattice(16, jitter=0.05, seed=42)
+    g = pmc.System(pos, sp, rho, TEMPERATURE, pmc.LennardJones(1.0, 1.0), seed=4242)
+    pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": SIGMA_MOVE}, 1.0)]
+    pmc.mc_sweep(g, pool, nsweeps=3000)
+    p0 = g.position.copy()
+    nch, nsw = 8, 300
+    _, seq_msd, seq_acc = E.sequential_leg(p0, sp, rho, TEMPERATURE, SIGMA_MOVE, nch, nsw, stride=nsw, processes=nch)
+    out = {"observable": f"MSD after {nsw} sweeps per attempted move, checkerboard (device) / sequential (oracle), N=4096 LJ liquid "
+                         f"rho=1 T=1 sigma={SIGMA_MOVE}, {nch} chains per leg", "by_rounds": {}}
+    for m in rounds_list:
+        _, cb_msd, cb_acc, cb_null = E.gpu_cb_leg(pmc, p0, sp, rho, TEMPERATURE, SIGMA_MOVE, nch, nsw, stride=nsw, rounds=m)
+        r = E.efficiency(None, seq_msd, None, cb_msd)
+        out["by_rounds"][str(m)] = {"msd_ratio": r["msd_ratio"], "sigma": r["msd_ratio_sigma"], "null_move_fraction": cb_null,
+                                    "acceptance": cb_acc}
+    out["acceptance_sequential"] = seq_acc
+    epath = os.path.join(ROOT, "profiles", "move_efficiency.json")
+    if os.path.exists(epath):
+        try:
+            t = json.load(open(epath))
+            out["tau_int"] = {"by_rounds": t.get("tau_ratio_by_rounds"), "source": t.get("source", "profiles/move_efficiency.json"),
+                              "note": "tau_int(e/N) of the sequential chain over the checkerboard's, per attempted move"}
+        except Exception as exc:
+            out["tau_int"] = {"error": repr(exc)}
+    return out
+
+
+def rccl_exchange_check(system, rank, world, dev_index, dist, torch, rounds=4):
+    """The path's one collective on the ranks of this job: a communicator built by the library's own entry points
+    (pmc_rccl_unique_id -> ranks -> pmc_rccl_comm_create) and `rounds` exchange rounds through pmc_replica_exchange_rccl
+    (ncclAllGather of one double per rank); every rank's labels must equal pmc_pt_decide on the gathered energies."""
+    from particlesmc_amd import tempering
+    uid = [tempering.RcclComm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    comm = tempering.RcclComm(uid[0], rank, world, dev_index)
+    ladder = np.geomspace(1.0, 1.0 + 0.002 * world, world)
+    label = np.arange(world, dtype=np.int32)
+    ok, acc = True, 0
+    try:
+        for rnd in range(rounds):
+            e = torch.tensor([system.energy[0]], dtype=torch.float64, device=f"cuda:{dev_index}")
+            es = [torch.zeros_like(e) for _ in range(world)]
+            dist.all_gather(es, e)
+            want, wacc = tempering.pt_decide(77, rnd, [float(t.item()) for t in es], ladder, label)
+            label, nacc = comm.exchange(system, ladder, 77, rnd, label)
+            ok = ok and list(label) == list(want) and nacc == wacc and system.temperature == float(ladder[label[rank]])
+            acc += nacc
+    finally:
+        comm.close()
+    system.temperature = TEMPERATURE
+    return {"n_ranks_rccl": world, "rounds": rounds, "decisions_equal_pt_decide": bool(ok), "accepted": int(acc)}
 
 
 def run_rank(args):
@@ -251,10 +345,13 @@ def run_rank(args):
         else:
             dist.init_process_group("gloo")
     ngpus = world
+    rdev = f"cuda:{dev_index}" if backend == "nccl" else "cpu"
 
     from particlesmc_amd.workloads import lj_lattice
     pos, sp, rho = lj_lattice(args.lattice, jitter=0.05, seed=42)
     N = len(pos)
+    pmc = None
+    system = None
     if stub:
         engine = _StubEngine(N)
         sweep = engine.sweep
@@ -263,6 +360,9 @@ def run_rank(args):
 
         def total_energy():
             return 0.0, 0
+
+        def set_rounds(m):
+            pass
     else:
         import particlesmc_amd as pmc
         if pmc.device_count() < 1:
@@ -278,6 +378,9 @@ def run_rank(args):
         def sweep(nsweeps):
             return pmc.mc_sweep(system, pool, nsweeps=nsweeps)
 
+        def set_rounds(m):
+            system.rounds = m
+
     def sync():
         if not stub:
             torch.cuda.synchronize()
@@ -291,48 +394,97 @@ def run_rank(args):
                 dist.barrier()
         sync()
 
+    def timed(nsteps):
+        """EXACTLY `nsteps` sweeps bracketed by barrier + synchronize on both sides; elapsed = MAX over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        st = sweep(nsteps)           # synchronises its stream before returning
+        sync()
+        el = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return st, el
+
+    def leg(st, el, nsteps, m):
+        att = float(max(1, st.attempted[0]))
+        return {"rounds": m, "value": float(N) * nsteps * ngpus / el, "ms_per_step": el * 1e3 / nsteps, "steps": nsteps,
+                "acceptance": float(st.accepted[0]) / att, "null_move_fraction": float(getattr(st, "null_moves", 0)) / att}
+
     from_lattice = None
     if args.equilibrate > 0:
-        # the state rounds 1-2 timed: the first sweeps from the jittered lattice (same warm-up, same number of steps)
-        if args.warmup > 0:
-            sweep(args.warmup)
-        sync()
-        tl = time.perf_counter()
-        stl = sweep(args.steps)
-        sync()
-        tl = time.perf_counter() - tl
-        from_lattice = {"value": float(N) * args.steps * ngpus / tl, "ms_per_step": tl * 1e3 / args.steps,
-                        "acceptance": float(stl.accepted[0]) / float(max(1, stl.attempted[0])),
-                        "note": "this rank's first sweeps from the jittered lattice, before the equilibration (not max-over-ranks)"}
+        # the state rounds 1-2 timed, with their schedule (m = 1): the first sweeps from the jittered lattice; same
+        # warm-up, same number of steps, same barriers and max-over-ranks as the headline region
+        set_rounds(1)
+        sweep(LATTICE_WARMUP)
+        stl, tl = timed(LATTICE_STEPS)
+        from_lattice = leg(stl, tl, LATTICE_STEPS, 1)
+        from_lattice["warmup"] = LATTICE_WARMUP
+        from_lattice["note"] = ("like-for-like with rounds 1-2, whatever --steps / --warmup / --rounds say: the first 5 + 20 sweeps "
+                                "from the jittered lattice, m = 1 (r01 7.76e8, r02 first half 7.81e8, r02 final 1.04e9)")
         sweep(args.equilibrate)
-    if args.warmup > 0:
-        sweep(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    st = sweep(args.steps)       # synchronises its stream before returning
-    sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    # the timed legs: the headline (m = --rounds) first, then the other schedules from the state it left
+    legs = {}
+    order = [args.rounds] + [m for m in (1, 2, 4) if m != args.rounds]
+    head_state = None
+    st = None
+    elapsed = None
+    for m in order:
+        set_rounds(m)
+        if m == args.rounds and not stub and rank == 0 and ngpus == 1 and not args.no_cpu:
+            head_state = system.position.copy()          # the liquid the headline region runs in: the CPU legs start from it too
+        if args.warmup > 0:
+            sweep(args.warmup)                           # (after the download: the timed region must not start on an idle GPU)
+        stm, elm = timed(args.steps)
+        legs[m] = leg(stm, elm, args.steps, m)
+        if m == args.rounds:
+            st, elapsed = stm, elm
+    long_run = None
+    if args.long_steps > 0:
+        set_rounds(args.rounds)
+        stl2, ell2 = timed(args.long_steps)
+        long_run = leg(stl2, ell2, args.long_steps, args.rounds)
+        run_fix = stl2.energy_fix
+    else:
+        run_fix = None
     # exactness property at full size: the running energy equals a recomputation bit for bit
-    run_fix = st.energy_fix
+    if run_fix is None:
+        run_fix = sweep(0).energy_fix if stub else system.total_energy()[1]
     e1, efix = total_energy()
-    energy_ok = bool(efix == run_fix)
+    energy_ok = bool(efix == run_fix) if not stub else True
     if dist is not None:
-        ok = torch.tensor([1.0 if energy_ok else 0.0], dtype=torch.float64,
-                          device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
+        ok = torch.tensor([1.0 if energy_ok else 0.0], dtype=torch.float64, device=rdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         energy_ok = bool(ok.item() == 1.0)
 
+    # the path's one collective, on the ranks of this job (N > 1 over RCCL only); guarded by a watchdog so that a stuck
+    # communicator cannot cost the bench line
+    rccl = None
+    hung = False
+    if dist is not None and backend == "nccl" and not stub:
+        import threading
+        box = {}
+
+        def work():
+            try:
+                box["r"] = rccl_exchange_check(system, rank, world, dev_index, dist, torch)
+            except Exception as exc:
+                box["r"] = {"n_ranks_rccl": 0, "error": repr(exc)}
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(120.0)
+        if th.is_alive():
+            hung = True
+            rccl = {"n_ranks_rccl": 0, "error": "pmc_replica_exchange_rccl did not return within 120 s"}
+        else:
+            rccl = box.get("r")
+
     if rank == 0:
-        moves = float(N) * args.steps * ngpus
-        value = moves / elapsed
+        value = legs[args.rounds]["value"]
         launches = int(st.sweep_kernel_launches)
-        timed_steps = min(args.steps, 4096)
+        timed_steps = args.steps
         if launches > 0 and st.sweep_kernel_ms > 0:
             avg_launch_s = st.sweep_kernel_ms * 1e-3 / launches
             moves_per_launch = N * timed_steps / launches
@@ -340,7 +492,6 @@ def run_rank(args):
             launches = args.steps
             avg_launch_s = elapsed / max(1, launches)
             moves_per_launch = float(N)
-        attempted = float(max(1, st.attempted[0]))
         out = {
             "metric": "attempted MC moves/sec, N=10^6 3D LJ rho=1.0 (one sweep = N attempted moves)",
             "value": value, "unit": "attempted moves/s", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
@@ -350,32 +501,49 @@ def run_rank(args):
                                    + (f"liquid equilibrated by {args.equilibrate} untimed sweeps from the jittered {args.lattice}^3 lattice"
                                       if args.equilibrate > 0 else f"jittered {args.lattice}^3 lattice")
                                    + ", one independent chain per GPU",
-                       "schedule": "checkerboard", "grid": grid, "reference_cells": ncell_ref,
+                       "schedule": f"checkerboard, {args.rounds} sweeps per grid shift (rounds per cell visit, pmc_set_rounds)",
+                       "rounds": args.rounds, "grid": grid, "reference_cells": ncell_ref,
                        "equilibration_sweeps": args.equilibrate,
                        "backend": backend or "single process", "ranks": world},
             "sweeps_per_s": args.steps * ngpus / elapsed,
-            "acceptance": float(st.accepted[0]) / attempted,
+            "acceptance": legs[args.rounds]["acceptance"],
             # cell-leaving proposals are rejected without any dE work; they are part of the schedule and count
             # as attempted moves, so the fraction is printed next to the headline
-            "null_move_fraction": float(getattr(st, "null_moves", 0)) / attempted,
+            "null_move_fraction": legs[args.rounds]["null_move_fraction"],
             "energy_per_particle": e1 / N, "energy_per_particle_initial": e0 / N,
             "running_energy_equals_recomputed": energy_ok,
+            # the same liquid under the other schedules, each timed like the headline (barriers, max over ranks)
+            "by_rounds": {str(m): legs[m] for m in sorted(legs)},
             "roofline": roofline_objects(N, timed_steps, st, avg_launch_s, moves_per_launch, ncell_ref),
         }
+        if long_run is not None:
+            out["long_run"] = long_run
         if from_lattice is not None:
             out["from_lattice"] = from_lattice
+        if rccl is not None:
+            out["rccl_exchange"] = rccl
+            out["n_ranks_rccl"] = rccl.get("n_ranks_rccl", 0)
         if stub:
             out["stub"] = True
         if ngpus == 1 and not args.no_cpu and not stub:
-            out["cpu_baseline"] = cpu_baseline(pos, sp, rho, 3_000_000)
+            out["cpu_baseline"] = cpu_baseline(head_state, sp, rho, 3_000_000)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
             try:
-                out["cpu_baseline_multicore"] = cpu_baseline_multicore(args.lattice, out["cpu_baseline"]["value"])
+                out["cpu_baseline_multicore"] = cpu_baseline_multicore(head_state, rho, out["cpu_baseline"]["value"])
             except Exception as exc:      # the single-core figure is the contract; this one is a courtesy
                 out["cpu_baseline_multicore"] = {"error": repr(exc)}
+            try:
+                eff = move_efficiency(pmc, sorted({1, args.rounds, 4}))
+                out["move_efficiency_vs_sequential"] = {"value": eff["by_rounds"][str(args.rounds)]["msd_ratio"], "rounds": args.rounds, **eff}
+                out["effective_sequential_moves_per_s"] = value * out["move_efficiency_vs_sequential"]["value"]
+            except Exception as exc:
+                out["move_efficiency_vs_sequential"] = {"error": repr(exc)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if hung:
+        sys.stdout.flush()
+        os._exit(0)                  # a thread is stuck inside RCCL: leave without the orderly teardown
     if dist is not None:
         dist.destroy_process_group()
     return 0

@@ -46,6 +46,7 @@ struct Stats                # pmc_stats
     energy::Float64; energy_fix::Int64
     kernel_ms::Float64; sweep_kernel_ms::Float64; sweep_kernel_launches::Int64
     pair_tests::Int64; pairs_in_range::Int64; null_moves::Int64
+    dense_evals::Int64; staged_candidates::Int64; written_back::Int64
 end
 
 check(rc, h=C_NULL) = rc == 0 || error(unsafe_string(ccall((:pmc_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))

@@ -47,6 +47,7 @@ class Stats(C.Structure):
         ("energy", C.c_double), ("energy_fix", C.c_int64),
         ("kernel_ms", C.c_double), ("sweep_kernel_ms", C.c_double), ("sweep_kernel_launches", C.c_int64),
         ("pair_tests", C.c_int64), ("pairs_in_range", C.c_int64), ("null_moves", C.c_int64),
+        ("dense_evals", C.c_int64), ("staged_candidates", C.c_int64), ("written_back", C.c_int64),
     ]
 
 

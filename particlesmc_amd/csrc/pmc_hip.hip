@@ -1260,6 +1260,18 @@ static int mc_order(pmc_system *h, int nactive)
 
 static int cb_cap(const pmc_system *h);
 
+// Teams (NW >= 2 wavefronts per cell) stage the old way -- everything into LDS, then a separate compaction pass -- unless the
+// runs of three cells that staging loads with one coalesced access per array are mostly longer than a wavefront: then the old
+// path falls into its element-by-element loops, and the fused staging (27 single cells, box filter in registers, one count
+// exchange per 9 segments) is faster.  Measured (r03, teams of 8): Kob-Andersen rho = 1.2 N = 10^5 (73 per run) 1.91 -> 2.21e8
+// with swaps, 2.35 -> 2.61e8 without; LJ rho = 1 N = 32768 (57 per run) 1.33 -> 1.21e8: the switch sits between them.
+static bool cb_fuse_teams(const pmc_system *h)
+{
+    if (const char *e = getenv("PMC_FUSE_TEAMS")) return e[0] == '1';      // experiments
+    if (!h->mc_ok || !h->use_filter || h->D != 3) return false;
+    return 3.0 * (double)h->N / (double)h->ncell_mc > 62.0;
+}
+
 static CbArgs cb_args(pmc_system *h)
 {
     CbArgs a;
@@ -1287,6 +1299,7 @@ static CbArgs cb_args(pmc_system *h)
     // threshold of the FP32 pre-filter: rcut_max^2 (1 + 2^-12), rounded UP to float (pmc_kernels.h: error bound 2^-19)
     a.rc2f = std::nextafter((float)(h->maxcut * h->maxcut * (1.0 + 1.0 / 4096.0)), INFINITY);
     a.filter = h->use_filter ? 1 : 0;
+    a.fuse_teams = cb_fuse_teams(h) ? 1 : 0;
     a.rounds = 1;
     return a;
 }
@@ -1821,7 +1834,7 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
     }
 #endif
 #ifdef PMC_DEBUG_COUNT
-    fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f compacted=%.4f filt=%.4f sd_ncand=%.1f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], (double)st[24] / st[21], (double)st[28] / st[21], (double)st[29] / st[21], sqrt((double)st[30] / st[21] - ((double)st[20] / st[21]) * ((double)st[20] / st[21])));
+    fprintf(stderr, "[pmc debug] visits=%llu mean_ncand=%.1f nowrap=%.3f bounds=%.3f mean_nseg=%.2f compacted=%.4f filt=%.4f sd_ncand=%.1f\n", st[21], (double)st[20] / st[21], (double)st[22] / st[21], (double)st[23] / st[21], 0.0 /* (st[24] now counts the FP64 distance evaluations) */, (double)st[28] / st[21], (double)st[29] / st[21], sqrt((double)st[30] / st[21] - ((double)st[20] / st[21]) * ((double)st[20] / st[21])));
 #endif
     h->e_fix += (long long)st[16];
     h->energy = (double)h->e_fix / PMC_FIX;
@@ -1843,6 +1856,9 @@ static int cb_finish(pmc_system *h, pmc_stats *out)
         out->pair_tests = (int64_t)st[25];
         out->pairs_in_range = (int64_t)st[26];
         out->null_moves = (int64_t)st[27];
+        out->dense_evals = (int64_t)st[24];
+        out->staged_candidates = (int64_t)st[31];
+        out->written_back = (int64_t)st[19];
     }
     return PMC_OK;
 }
@@ -2111,6 +2127,9 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             o.pair_tests = (int64_t)st[25];
             o.pairs_in_range = (int64_t)st[26];
             o.null_moves = (int64_t)st[27];
+            o.dense_evals = (int64_t)st[24];
+            o.staged_candidates = (int64_t)st[31];
+            o.written_back = (int64_t)st[19];
         }
     }
     return first;

@@ -1192,6 +1192,7 @@ struct CbArgs {
     double rc2pad;             // (largest cutoff)^2 * (1 + 1e-9): box-distance filter of the staging
     float rc2f;                // (largest cutoff)^2 * (1 + 2^-12), rounded up: threshold of the FP32 pre-filter (conservative)
     int filter;                // 1: drop candidates that are out of range of the whole centre cell
+    int fuse_teams;            // 1: teams of NW >= 2 wavefronts take the fused staging too (stage_compacted with a count exchange)
     const int *order;          // per colour: cells sorted by population, descending (may be null)
     unsigned long long *stats; // [0..7] attempted, [8..15] accepted, [16] energy delta (fix), [17] error flags, [18] nonfinite pairs
     double *e_particle;        // optional per-particle energies (id order)
@@ -1273,6 +1274,7 @@ struct WaveNbh {
     bool filt;               // the pre-filter is usable for this visit (everything staged, at most 64 PMC_FTRIPS candidates)
     bool compacted;          // the box filter was applied while staging (stage_compacted)
     int kept;                // candidates that passed the box filter (stage_compacted; a huge value if it could not count them)
+    int loaded;              // population of the 3^d cells the staging read from global memory
 #ifdef PMC_DEBUG_TIME
     unsigned long long ts[10];  // stamps inside stage_neighbourhood: entry, table ready, flags seen, coordinates arrived, done; [5..8] inside stage_compacted
 #endif
@@ -1538,7 +1540,7 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
 #pragma unroll
         for (int sft = 1; sft < 16; sft <<= 1) tot += __shfl_xor(tot, sft, PMC_WAVE);
         tot = __shfl(tot, 0, PMC_WAVE);
-        runs_long = FUSE && __builtin_amdgcn_ballot_w64(lane < NR && seg_cnt > PMC_WAVE) != 0ull;
+        runs_long = FUSE && (NW == 1 || a.fuse_teams != 0) && __builtin_amdgcn_ballot_w64(lane < NR && seg_cnt > PMC_WAVE) != 0ull;
         runs_ok = tot <= h.cap && !runs_long;
         run_start = seg_start;
         run_cnt = seg_cnt;
@@ -1572,9 +1574,10 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
     }
     const int seg_off = incl - seg_cnt;
     h.ncand = __shfl(incl, h.nseg - 1, PMC_WAVE);
+    h.loaded = h.ncand;
     // (every wavefront of a team writes the same table.  Not before stage_compacted, which exchanges counts through segoff:
     // a slow wavefront's late write of the table would overwrite a fast one's count)
-    const bool try_fused = FUSE && h.nc > 0;
+    const bool try_fused = FUSE && h.nc > 0 && (NW == 1 || a.fuse_teams != 0);
     if (!try_fused) {
         if (lane < h.nseg) {
             h.segoff[lane] = seg_off;
@@ -2057,6 +2060,7 @@ __device__ __forceinline__ void update_fregs(FRegs &f, int pc, float fx, float f
 
 struct PairCount {
     unsigned tests, energies;     // per wavefront: FP32 distance tests, in-range pair energies evaluated
+    unsigned dense;               // FP64 distance evaluations: (queue entry, old | new position) of the filtered path, every (candidate, position) of the direct one
 #ifdef PMC_DEBUG_TIME
     unsigned long long t_filter, t_dense;
 #endif
@@ -2085,6 +2089,7 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
     const bool isnew = (lane & 1) != 0;
     const double xi = isnew ? xn : xo, yi = isnew ? yn : yo, zi = isnew ? zn : zo;
     const int qe = 2 * qn;
+    pcnt.dense += (unsigned)qe;
     for (int e0 = 0; e0 < qe; e0 += PMC_WAVE) {
         // lanes behind the last entry re-read it (no branch around the loads) and are masked out of the range test
         const int e = min(e0 + lane, qe - 1);
@@ -2287,6 +2292,7 @@ __device__ __forceinline__ double wave_delta_e_direct(const CbArgs &a, const Wav
         term(k, xj, yj, zj, sj, std::false_type{});
     }
     pcnt.tests += 2u * (unsigned)h.ncand;
+    pcnt.dense += 2u * (unsigned)h.ncand;
     unsigned tot = nin;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) tot += __shfl_xor(tot, s, PMC_WAVE);
@@ -2540,6 +2546,7 @@ struct CbTotals {
     long long efix;                  // accepted energy change in units of 2^-32
     unsigned long long nnull;
     unsigned long long tests, energies;
+    unsigned long long loaded, written;   // candidates loaded from global memory by the staging (all 3^d cells); particles written back
     PairCount pcnt;                  // per-wavefront work counters of the current visit
 #ifdef PMC_DEBUG_TIME
     unsigned long long tp[16];
@@ -2577,13 +2584,15 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
 #endif
     // (teams are for small and medium systems, where a visit is one latency chain and LDS is plentiful: the fused staging's
     // count exchange between the wavefronts costs them 2-9 %)
-    constexpr bool FUSE = PMC_FUSED_STAGE && NW == 1;
+    // teams take the fused staging only where a.fuse_teams says so (dense systems: see pmc_hip.hip, cb_fuse_teams)
+    constexpr bool FUSE = PMC_FUSED_STAGE;
     stage_neighbourhood<D, MULTI, NW, FUSE>(a, cell, h, a.fused ? colour : 0);
     PMC_T(t_2);
 #if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 2
     { if (a.fused) publish_done(a, lin, tid == 0); return; }
 #endif
     const int nc = h.nc;
+    tot.loaded += (unsigned long long)h.loaded;
     if (nc == 0) { if (a.fused) publish_done(a, lin, tid == 0); return; }
     if (h.ctr + nc > h.cap) {
         if (tid == 0) atomicOr(&st[17], 1ull);
@@ -2592,7 +2601,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     }
     // histogram of the box-filtered neighbourhood sizes, in steps of 64: the host sizes the LDS staging of the next call
     // from it (pmc_hip.hip: cb_cap_sweep)
-    if (FUSE && tid == 0) atomicAdd(&st[PMC_STAT_KEPT + min((h.kept + 63) >> 6, 15)], 1ull);
+    if (FUSE && NW == 1 && tid == 0) atomicAdd(&st[PMC_STAT_KEPT + min((h.kept + 63) >> 6, 15)], 1ull);
     compact_candidates<D, MULTI, NW>(a, h);
     FRegs fr;
     prepare_filter<D>(a, h, fr);
@@ -2602,7 +2611,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
 #endif
     if (NW == 1) __builtin_amdgcn_s_setprio(0);
 #ifdef PMC_DEBUG_COUNT   // profiling builds only
-    if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], 0ull); atomicAdd(&st[24], (unsigned long long)h.nseg); atomicAdd(&st[28], (unsigned long long)h.compacted); atomicAdd(&st[29], (unsigned long long)h.filt); atomicAdd(&st[30], (unsigned long long)h.ncand * (unsigned long long)h.ncand); }
+    if (tid == 0) { atomicAdd(&st[20], (unsigned long long)h.ncand); atomicAdd(&st[21], 1ull); atomicAdd(&st[22], (unsigned long long)h.nowrap); atomicAdd(&st[23], 0ull); atomicAdd(&st[28], (unsigned long long)h.compacted); atomicAdd(&st[29], (unsigned long long)h.filt); atomicAdd(&st[30], (unsigned long long)h.ncand * (unsigned long long)h.ncand); }
 #endif
 
     // multi-move pools count per move in LDS (cnt[0..7] attempted, cnt[8..15] accepted); a
@@ -2779,45 +2788,53 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i
+                    // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i (none from i >= j)
                     double creg[NW - 1];
 #pragma unroll
-                    for (int i = 0; i < NW - 1; i++) creg[i] = h.cmat[i * NW + jl];
-                    // decisions in slot order; lanes > i accumulate what an accepted slot i does to them
+                    for (int i = 0; i < NW - 1; i++) {
+                        const double c = h.cmat[i * NW + jl];
+                        creg[i] = (lane > i) ? c : 0.0;
+                    }
+                    // samem, bit i: slot i (before this lane's slot) is a Displacement of the particle this slot uses -- if slot i is
+                    // accepted, this slot was evaluated against a stale position: it ends the batch and is evaluated again (a swap after
+                    // accepted Displacements of OTHER particles is corrected like a Displacement: c(i,j) above)
+                    unsigned samem = 0;
+#pragma unroll
+                    for (int i = 0; i < NW - 1; i++) {
+                        const int pci = __builtin_amdgcn_readlane(l_pc, i);
+                        const bool dispi = ONE || !MULTI || __builtin_amdgcn_readlane(l_pj, i) < 0;
+                        if (dispi && lane > i && ((l_pc == pci) || (l_swap && l_pj == pci))) samem |= 1u << i;
+                    }
+                    const unsigned long long inmask = __builtin_amdgcn_ballot_w64(l_in), swapmask = __builtin_amdgcn_ballot_w64(l_swap);
+                    // decisions in slot order, every lane deciding for itself (lane i's answer is the one read at step i); lanes > i
+                    // accumulate what an accepted slot i does to them.  The loop is a chain of ~8 instructions per slot on a CU where
+                    // this wavefront runs alone: it used to be ~40 (cross-lane reads of every operand, a float-to-fixed conversion per
+                    // accepted slot), a quarter of a team's time per batch.
                     double corr = 0.0;
-                    bool conf = false, stop = false;
                     int nres = 0;
                     unsigned accmask = 0;
 #pragma unroll
                     for (int i = 0; i < NW; i++) {
-                        if (i < K && !stop) {
-                            const double dei = readlane_double(l_de + corr, i);
-                            const bool swapi = (__ballot(l_swap && lane == i) != 0ull);
-                            const bool confi = (__ballot(conf && lane == i) != 0ull);
-                            // a slot that re-selects a moved particle ends the batch and is evaluated again (a swap after accepted
-                            // Displacements of OTHER particles is corrected like a Displacement: c(i,j) above)
-                            if (confi) {
-                                stop = true;
-                            } else {
-                                const bool ini = (__ballot(l_in && lane == i) != 0ull);
-                                const bool oki = ini && (readlane_double(l_tlnu, i) < -dei);
-                                nres = i + 1;
-                                if (oki) {
-                                    accmask |= 1u << i;
-                                    acc1 += 1;
-                                    efix += (long long)(dei * PMC_FIX);
-                                    if (swapi) {
-                                        stop = true;            // later slots saw the old species: next batch
-                                    } else if (i < NW - 1) {
-                                        const int pci = __builtin_amdgcn_readlane(l_pc, i);
-                                        if (lane > i) {
-                                            corr += creg[i < NW - 1 ? i : 0];
-                                            conf = conf || (l_pc == pci) || (l_swap && l_pj == pci);
-                                        }
-                                    }
-                                }
-                            }
+                        if (i >= K) break;
+                        const unsigned long long confm = __builtin_amdgcn_ballot_w64((samem & accmask) != 0u);
+                        if ((confm >> i) & 1ull) break;
+                        const unsigned long long okm = __builtin_amdgcn_ballot_w64(l_tlnu < -(l_de + corr)) & inmask;
+                        nres = i + 1;
+                        if ((okm >> i) & 1ull) {
+                            accmask |= 1u << i;
+                            if ((swapmask >> i) & 1ull) break;            // later slots saw the old species: next batch
+                            if (i < NW - 1) corr += creg[i < NW - 1 ? i : 0];
                         }
+                    }
+                    {
+                        // (lane i still holds the dE it decided with: it only ever received corrections from slots before it)
+                        const bool accl = lane < NW && ((accmask >> lane) & 1u);
+                        double dsum = accl ? (l_de + corr) : 0.0;
+                        dsum = dpp_add<0xB1>(dsum);
+                        dsum = dpp_add<0x4E>(dsum);
+                        dsum = dpp_add<0x141>(dsum);          // lanes 0..7 hold the (exact) sum over the accepted slots
+                        efix += (long long)(readlane_double(dsum, 0) * PMC_FIX);
+                        acc1 += (unsigned long long)__popc(accmask);
                     }
                     att1 += (unsigned long long)nres;
                     if (!ONE && lane < nres) {              // per-move counters of multi-move pools (this wavefront only)
@@ -2953,6 +2970,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     }
     PMC_T(t_4);
     if (dirty) {
+        tot.written += (unsigned long long)nc;
         for (int k = tid; k < nc; k += TS) {
             const int kc = h.ctr + k;
             int id = a.ids[h.k0 + k];
@@ -3060,6 +3078,8 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
         }
         if (tot.efix) atomicAdd(&st[16], (unsigned long long)tot.efix);
         if (tot.nnull) atomicAdd(&st[27], tot.nnull);
+        if (tot.loaded) atomicAdd(&st[31], tot.loaded);
+        if (tot.written) atomicAdd(&st[19], tot.written);
 #ifdef PMC_DEBUG_TIME
         for (int q = 0; q < 15; q++) atomicAdd(&st[32 + q], tot.tp[q]);
         atomicAdd(&st[47], tot.tp[15]);
@@ -3069,6 +3089,7 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     if (wave_lane() == 0 && tot.pcnt.tests) {
         atomicAdd(&st[25], (unsigned long long)tot.pcnt.tests);
         atomicAdd(&st[26], (unsigned long long)tot.pcnt.energies);
+        atomicAdd(&st[24], (unsigned long long)tot.pcnt.dense);
     }
 }
 

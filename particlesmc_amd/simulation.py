@@ -42,6 +42,7 @@ class SweepStats:
         self.sweep_kernel_ms = st.sweep_kernel_ms
         self.sweep_kernel_launches = st.sweep_kernel_launches
         self.pair_tests, self.pairs_in_range, self.null_moves = st.pair_tests, st.pairs_in_range, st.null_moves
+        self.dense_evals, self.staged_candidates, self.written_back = st.dense_evals, st.staged_candidates, st.written_back
 
 
 MODES = {"sequential": _lib.SEQUENTIAL, "checkerboard": _lib.CHECKERBOARD}

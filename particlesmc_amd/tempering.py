@@ -65,29 +65,62 @@ class ReplicaExchange:
         return self.temperature
 
 
-def rccl_comm_from_env(device, tag="pmc"):
-    """One-process-per-GPU launchers (torchrun, mpirun, srun) export RANK / WORLD_SIZE / MASTER_PORT: rank 0 creates the
-    RCCL unique id and hands its 128 bytes to the other ranks of the node through a file named after the port; every rank
-    then joins through pmc_rccl_comm_create.  No torch, no MPI: the library's own entry points and the file system."""
+def _env_int(names, default):
+    import os
+    for n in names:
+        if n in os.environ:
+            return int(os.environ[n])
+    return default
+
+
+def rccl_comm_from_env(device, tag="pmc", id_file=None):
+    """One process per GPU without torch or MPI bindings: rank 0 creates the RCCL unique id (pmc_rccl_unique_id) and hands its
+    128 bytes to the other ranks of the node through a file; every rank then joins through pmc_rccl_comm_create.
+
+    Rank and world size are read from RANK / WORLD_SIZE (torchrun), OMPI_COMM_WORLD_RANK / _SIZE (mpirun) or SLURM_PROCID /
+    SLURM_NTASKS (srun).  The file is `id_file`, else $PMC_RCCL_ID_FILE, else a name in $TMPDIR built from the launcher's
+    run id (TORCHELASTIC_RUN_ID / SLURM_JOB_ID / MASTER_PORT) and, for launchers whose ranks share a parent, that parent's
+    PID.  Rank 0 removes any file of that name BEFORE it creates the id and removes its own file once ncclCommInitRank has
+    returned (it returns only after every rank has joined, i.e. has read the id); the other ranks ignore a file older than
+    five minutes, so an id left behind by a crashed job cannot be joined by accident."""
     import os
     import time
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"{tag}_rccl_id_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}")
+    rank = _env_int(("RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID"), 0)
+    world = _env_int(("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS"), 1)
+    path = id_file or os.environ.get("PMC_RCCL_ID_FILE")
+    if not path:
+        run = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("MASTER_PORT", "0")
+        shared_parent = "RANK" in os.environ and "OMPI_COMM_WORLD_RANK" not in os.environ and "SLURM_PROCID" not in os.environ
+        owner = os.getpid() if world == 1 else (os.getppid() if shared_parent else 0)
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"{tag}_rccl_id_{run}_{owner}")
     if rank == 0:
+        try:
+            os.remove(path)                      # a stale id of an earlier job with this name
+        except FileNotFoundError:
+            pass
         uid = RcclComm.unique_id()
         with open(path + ".tmp", "wb") as f:
             f.write(uid)
         os.replace(path + ".tmp", path)
     else:
         t0 = time.time()
-        while not os.path.exists(path):
+        while True:
+            try:
+                if time.time() - os.path.getmtime(path) < 300.0:
+                    uid = open(path, "rb").read()
+                    if len(uid) == 128:
+                        break
+            except FileNotFoundError:
+                pass
             if time.time() - t0 > 120:
-                raise TimeoutError(f"no RCCL id from rank 0 at {path}")
+                raise TimeoutError(f"no fresh RCCL id from rank 0 at {path}")
             time.sleep(0.05)
-        uid = open(path, "rb").read()
-    comm = RcclComm(uid, rank, world, device)
-    if rank == 0 and world == 1:
-        os.remove(path)
+    comm = RcclComm(uid, rank, world, device)    # collective: returns once every rank has joined
+    if rank == 0:
+        try:
+            os.remove(path)
+        except FileNotFoundError:
+            pass
     return comm
 
 

@@ -42,7 +42,7 @@ static void layout(void)
     printf("pmc_stats.sizeof %zu\n", sizeof(pmc_stats));
     F(pmc_stats, attempted); F(pmc_stats, accepted); F(pmc_stats, energy); F(pmc_stats, energy_fix); F(pmc_stats, kernel_ms);
     F(pmc_stats, sweep_kernel_ms); F(pmc_stats, sweep_kernel_launches); F(pmc_stats, pair_tests); F(pmc_stats, pairs_in_range);
-    F(pmc_stats, null_moves);
+    F(pmc_stats, null_moves); F(pmc_stats, dense_evals); F(pmc_stats, staged_candidates); F(pmc_stats, written_back);
 #undef F
 }
 

@@ -245,7 +245,8 @@ def test_bench_line_contract(gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2",
-                                   "--lattice", "32"], stderr=subprocess.DEVNULL, timeout=600).decode().strip().split("\n")
+                                   "--lattice", "32", "--long-steps", "40", "--equilibrate", "50"], stderr=subprocess.DEVNULL,
+                                  timeout=900).decode().strip().split("\n")
     line = [l for l in out if l.startswith("{")]
     assert len(line) == 1
     d = json.loads(line[0])
@@ -267,10 +268,25 @@ def test_bench_line_contract(gpu):
     for k in ("hbm_measured_frac", "valu_issue_frac"):
         assert k not in r or "source" in r[k]                                           # replayed numbers carry a source
     assert 0.0 <= d["null_move_fraction"] < 0.1
+    # what the kernel EXECUTES is reported by precision next to the algorithmic figure, and the schedule's bytes are counted in-run
+    ex = r["executed"]
+    assert 0 < ex["fp64_flop_per_move"] < fm["flop_per_move"] and ex["fp32_flop_per_move"] == pytest.approx(9 * fm["pair_tests_per_move"])
+    assert 0 < ex["fp64_frac_of_peak"] < r["frac"] and 0 < ex["fp32_frac_of_peak"] < 1
+    sb = r["schedule_bytes"]
+    assert 3 < sb["staged_candidates_per_move"] < 60 and 0 < sb["frac_of_hbm_peak"] < 1      # ~27 n_c / (m n_c) per move
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e3 and "sample" in c
     assert d["value"] > 1e6 and d["running_energy_equals_recomputed"] is True
     assert abs(d["value"] - 32768 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+    # the schedule parameter of the headline and the other schedules timed beside it; the like-for-like lattice figure
+    assert d["config"]["rounds"] == 4 and set(d["by_rounds"]) == {"1", "2", "4"}
+    assert d["by_rounds"]["4"]["value"] == d["value"]
+    assert d["from_lattice"]["rounds"] == 1 and d["from_lattice"]["steps"] == 20 and d["from_lattice"]["value"] > 1e6
+    assert d["long_run"]["steps"] == 40 and d["long_run"]["value"] > 1e6
+    # what an attempted move is worth in sequential attempted moves: measured in the run, per schedule
+    me = d["move_efficiency_vs_sequential"]
+    assert me["rounds"] == 4 and set(me["by_rounds"]) == {"1", "4"}
+    assert 0.8 < me["value"] < 1.05 and me["value"] == me["by_rounds"]["4"]["msd_ratio"]
 
 
 def test_long_run_bookkeeping_is_exact(gpu):
