@@ -174,6 +174,9 @@ def parse_args(argv=None):
                     help="schedule parameter m of the headline figure (pmc_set_rounds: sweeps per grid shift = proposal rounds per "
                          "cell visit); m = 1 -- what rounds 1-2 timed -- and m = 2 are timed in the same run and reported beside it")
     ap.add_argument("--long-steps", type=int, default=1000, help="steps of the secondary, longer timed region (0: skip)")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="profiling runs: skip the lattice figure, the other schedules and the long region, so that the LAST "
+                         "steps / rounds launches of the sweep kernel are the timed region (profiles/collect.sh)")
     ap.add_argument("--share-devices", action="store_true",
                     help="functional testing only: allow more ranks than visible GPUs (ranks share devices, gloo reductions)")
     return ap.parse_args(argv)
@@ -257,8 +260,8 @@ def roofline_objects(N, steps, st, avg_launch_s, moves_per_launch, ncell_ref):
 def move_efficiency(pmc, rounds_list):
     """What an attempted move of the checkerboard schedule is worth in attempted moves of the reference's sequential chain
     (src/moves.jl:57-81): mean-square displacement per attempted move, checkerboard (device) over sequential (oracle), on an
-    N = 4096 liquid at the benchmark's state point and cell width (6 cells of 2.667).  A bounded sample: 8 chains of 300
-    sweeps per leg (about 10 s of CPU on 8 host cores).  The integrated autocorrelation time of e/N needs ~100x the CPU
+    N = 4096 liquid at the benchmark's state point and cell width (6 cells of 2.667).  A bounded sample: 16 chains of 500
+    sweeps per leg (about 20 s of CPU on 16 host cores).  The integrated autocorrelation time of e/N needs ~100x the CPU
     time: it is measured by tests/test_gpu_efficiency.py / examples/move_efficiency.py and replayed with its source."""
     from oracle import efficiency as E
     from particlesmc_amd.workloads import lj_lattice
@@ -267,7 +270,7 @@ def move_efficiency(pmc, rounds_list):
     pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": SIGMA_MOVE}, 1.0)]
     pmc.mc_sweep(g, pool, nsweeps=3000)
     p0 = g.position.copy()
-    nch, nsw = 8, 300
+    nch, nsw = 16, 500
     _, seq_msd, seq_acc = E.sequential_leg(p0, sp, rho, TEMPERATURE, SIGMA_MOVE, nch, nsw, stride=nsw, processes=nch)
     out = {"observable": f"MSD after {nsw} sweeps per attempted move, checkerboard (device) / sequential (oracle), N=4096 LJ liquid "
                          f"rho=1 T=1 sigma={SIGMA_MOVE}, {nch} chains per leg", "by_rounds": {}}
@@ -414,7 +417,10 @@ def run_rank(args):
                 "acceptance": float(st.accepted[0]) / att, "null_move_fraction": float(getattr(st, "null_moves", 0)) / att}
 
     from_lattice = None
-    if args.equilibrate > 0:
+    if args.only_headline:
+        set_rounds(1)
+        sweep(args.equilibrate)
+    elif args.equilibrate > 0:
         # the state rounds 1-2 timed, with their schedule (m = 1): the first sweeps from the jittered lattice; same
         # warm-up, same number of steps, same barriers and max-over-ranks as the headline region
         set_rounds(1)
@@ -427,7 +433,7 @@ def run_rank(args):
         sweep(args.equilibrate)
     # the timed legs: the headline (m = --rounds) first, then the other schedules from the state it left
     legs = {}
-    order = [args.rounds] + [m for m in (1, 2, 4) if m != args.rounds]
+    order = [args.rounds] + ([] if args.only_headline else [m for m in (1, 2, 4) if m != args.rounds])
     head_state = None
     st = None
     elapsed = None
@@ -442,7 +448,7 @@ def run_rank(args):
         if m == args.rounds:
             st, elapsed = stm, elm
     long_run = None
-    if args.long_steps > 0:
+    if args.long_steps > 0 and not args.only_headline:
         set_rounds(args.rounds)
         stl2, ell2 = timed(args.long_steps)
         long_run = leg(stl2, ell2, args.long_steps, args.rounds)

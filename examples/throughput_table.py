@@ -5,6 +5,7 @@
   python examples/throughput_table.py            # all rows
   python examples/throughput_table.py lj ka      # selected groups: lj, ka, ss2d, many, equil, images
   PMC_TEAM=2 python examples/throughput_table.py lj   # with a fixed team width (every row carries the team in use)
+  PMC_ROUNDS=4 python examples/throughput_table.py    # with m = 4 sweeps per grid shift (every row carries `rounds`)
 """
 import json
 import os
@@ -38,20 +39,25 @@ def rate(system, pool, sweeps, warm):
 def main():
     groups = set(sys.argv[1:]) or {"lj", "ka", "ss2d", "many", "equil", "images"}
     team = os.environ.get("PMC_TEAM", "auto")
+    rounds = int(os.environ.get("PMC_ROUNDS", "1"))      # schedule parameter m (pmc_set_rounds); every row carries it
     rows = []
+
+    def emit(row):
+        row["rounds"] = rounds
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+
     if "lj" in groups:
         for n, sw in ((16, 400), (24, 400), (32, 400), (48, 300), (64, 200), (100, 40), (128, 20), (200, 10)):
             pos, sp, rho = lj_lattice(n, jitter=0.05, seed=42)
             s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
             s.total_energy()
-            rows.append({"row": f"LJ rho=1 T=1 N={len(pos)}", "team": team, **rate(s, [disp()], sw, max(2, sw // 10))})
-            print(json.dumps(rows[-1]), flush=True)
+            emit({"row": f"LJ rho=1 T=1 N={len(pos)}", "team": team, **rate(s, [disp()], sw, max(2, sw // 10))})
     if "equil" in groups:
         pos, sp, rho = lj_lattice(100, jitter=0.05, seed=42)
         s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
         s.total_energy()
-        rows.append({"row": "LJ N=1000000 after 2000 warm-up sweeps", **rate(s, [disp()], 100, 2000)})
-        print(json.dumps(rows[-1]), flush=True)
+        emit({"row": "LJ N=1000000 after 2000 warm-up sweeps", **rate(s, [disp()], 100, 2000)})
     if "images" in groups:
         # every particle shifted by random whole boxes: positions are never wrapped (src/moves.jl:46-48), so this is what a
         # long run of a liquid looks like to the kernels -- every cell visit takes the general minimum-image path
@@ -61,9 +67,8 @@ def main():
             p = pos + (np.random.default_rng(7).integers(-3, 4, size=pos.shape) * L if shifted else 0.0)
             s = pmc.System(p, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
             s.total_energy()
-            rows.append({"row": "LJ N=1000000 " + ("shifted by random whole boxes" if shifted else "all in the primary box"), "team": team,
+            emit({"row": "LJ N=1000000 " + ("shifted by random whole boxes" if shifted else "all in the primary box"), "team": team,
                          **rate(s, [disp()], 40, 5)})
-            print(json.dumps(rows[-1]), flush=True)
     if "ka" in groups:
         for N, sw in ((100000, 100), (1000000, 20)):
             for swaps in (True, False):
@@ -71,9 +76,8 @@ def main():
                 s = pmc.System(pos, sp, rho, 1.0, pmc.KobAndersen(), seed=42)
                 s.total_energy()
                 pool = [disp(p=0.9), pmc.Move(pmc.DiscreteSwap([1, 2], s), pmc.DoubleUniform(), [], 0.1)] if swaps else [disp()]
-                rows.append({"row": f"Kob-Andersen 80:20 rho=1.2 N={N} " + ("90% Displacement + 10% DiscreteSwap" if swaps else "Displacement only"),
+                emit({"row": f"Kob-Andersen 80:20 rho=1.2 N={N} " + ("90% Displacement + 10% DiscreteSwap" if swaps else "Displacement only"),
                              **rate(s, pool, sw, max(2, sw // 10))})
-                print(json.dumps(rows[-1]), flush=True)
     if "ss2d" in groups:
         n = 256
         N, rho = n * n, 0.8
@@ -85,8 +89,7 @@ def main():
         mm = [[pmc.SoftSpheres(1.0, sg, 14) for sg in row] for row in ([1.0, 1.2], [1.2, 1.4])]
         s = pmc.System(pos, sp, rho, 1.0, mm, seed=5)
         s.total_energy()
-        rows.append({"row": "2-D soft spheres n=14 binary N=65536", **rate(s, [disp(0.065)], 400, 40)})
-        print(json.dumps(rows[-1]), flush=True)
+        emit({"row": "2-D soft spheres n=14 binary N=65536", **rate(s, [disp(0.065)], 400, 40)})
     if "many" in groups:
         pos, sp, rho = lj_lattice(16, jitter=0.05, seed=42)
         chains = [pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42, chain=c) for c in range(8)]
@@ -97,14 +100,12 @@ def main():
         t0 = time.perf_counter()
         pmc.mc_sweep_many(chains, pool, nsweeps=500)
         dt = time.perf_counter() - t0
-        rows.append({"row": "8 chains of N=4096 in shared launches (pmc_sweep_many)", "moves_per_s": 8 * 4096 * 500 / dt})
-        print(json.dumps(rows[-1]), flush=True)
+        emit({"row": "8 chains of N=4096 in shared launches (pmc_sweep_many)", "moves_per_s": 8 * 4096 * 500 / dt})
         t0 = time.perf_counter()
         for c in chains:
             pmc.mc_sweep(c, pool, nsweeps=500)
         dt = time.perf_counter() - t0
-        rows.append({"row": "the same 8 chains one after the other", "moves_per_s": 8 * 4096 * 500 / dt})
-        print(json.dumps(rows[-1]), flush=True)
+        emit({"row": "the same 8 chains one after the other", "moves_per_s": 8 * 4096 * 500 / dt})
 
 
 if __name__ == "__main__":

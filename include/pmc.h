@@ -101,7 +101,8 @@ typedef struct {
                                  capacity a launch was sized with (learnt from earlier sweeps), the results do not */
     int64_t pairs_in_range;   /* pair energies evaluated (r2 <= rcut2, src/atoms.jl:72) */
     int64_t null_moves;       /* attempted slots that evaluated no dE: Displacements that would leave their cell, swaps in a cell lacking a species */
-    int64_t dense_evals;      /* FP64 distance evaluations: (survivor of the FP32 pre-filter, old | new position) */
+    int64_t dense_evals;      /* FP64 distance evaluations: (survivor of the FP32 pre-filter, old | new position); counted by the
+                                 single-species kernels with one wavefront per cell (the large-system path), 0 otherwise */
     int64_t staged_candidates;/* candidates the cell visits loaded from global memory (all 3^d cells of every visit) */
     int64_t written_back;     /* particles the cell visits wrote back (every particle of a cell with an accepted move) */
 } pmc_stats;

@@ -1104,7 +1104,25 @@ struct orc_cb {
     int64_t *cell_ids;   /* N, 0-based ids, ascending inside a cell */
     int64_t *cell_of;    /* N */
     int64_t e_fix;
+    /* Periodic images (DESIGN.md 2.2 "images"): positions are never wrapped (src/moves.jl:46-48), so every particle carries a
+     * PERSISTENT integer image k per dimension, fixed when the state is handed over (orc_cb_create = pmc_upload) as
+     * floor(x / L) (|k| <= 511, else 0); all distances of the schedule are taken between the folded coordinates
+     * xf = x - k L (k = 0: xf = x), recomputed from the positions at every binning. */
+    int32_t *img;        /* N * d */
+    double *xf;          /* N * d, folded copy of the current pass */
 };
+
+#define CB_IMG_MAX 511
+static inline double cb_fold(double x, int32_t k, double L) { return k == 0 ? x : x - (double)k * L; }
+static inline double cb_unfold(double xf, int32_t k, double L) { return k == 0 ? xf : xf + (double)k * L; }
+/* the folded coordinate a move to t = xf + delta is evaluated and stored at: it survives the round trip through the
+ * unwrapped position array exactly (k = 0: t itself, i.e. the reference's x + delta) */
+static inline double cb_settle(double t, int32_t k, double L)
+{
+    if (k == 0) return t;
+    double kl = (double)k * L;
+    return (t + kl) - kl;
+}
 
 static inline double cb_quant(double u)
 {
@@ -1115,7 +1133,7 @@ static inline double cb_quant(double u)
 static inline double cb_pair(const orc_cb *c, const double *xi, int32_t spi, int64_t j)
 {
     const orc_model *m = c->models + (size_t)(spi - 1) * c->nspecies + (c->species[j] - 1);
-    double r2 = nearest_image_distance_squared(xi, c->pos + (size_t)j * c->d, c->box, c->d);
+    double r2 = nearest_image_distance_squared(xi, c->xf + (size_t)j * c->d, c->box, c->d);   /* xi: a FOLDED coordinate */
     if (r2 > m->rcut2)
         return 0.0;
     return cb_quant(orc_potential(r2, m));
@@ -1128,7 +1146,8 @@ static void cb_bin(orc_cb *c, const double *shift)
     for (int64_t i = 0; i < c->N; i++) {
         int64_t lin = 0;
         for (int a = 0; a < d; a++) {
-            double f = floor((c->pos[(size_t)i * d + a] - shift[a]) / c->w[a]);
+            c->xf[(size_t)i * d + a] = cb_fold(c->pos[(size_t)i * d + a], c->img[(size_t)i * d + a], c->box[a]);
+            double f = floor((c->xf[(size_t)i * d + a] - shift[a]) / c->w[a]);
             int64_t q = (int64_t)f;
             int64_t r = q % c->n_mc[a];
             if (r < 0) r += c->n_mc[a];
@@ -1217,6 +1236,13 @@ orc_cb *orc_cb_create(int64_t N, int32_t d, const double *pos, const int32_t *sp
     c->cell_start = (int64_t *)calloc((size_t)c->ncell + 1, sizeof(int64_t));
     c->cell_ids = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
     c->cell_of = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    c->img = (int32_t *)malloc(sizeof(int32_t) * (size_t)N * d);
+    c->xf = (double *)malloc(sizeof(double) * (size_t)N * d);
+    for (int64_t i = 0; i < N; i++)
+        for (int a = 0; a < d; a++) {
+            double f = floor(pos[(size_t)i * d + a] / box[a]);
+            c->img[(size_t)i * d + a] = (fabs(f) <= (double)CB_IMG_MAX) ? (int32_t)f : 0;
+        }
     c->e_fix = orc_cb_total_energy_fix(c);
     return c;
 }
@@ -1226,6 +1252,7 @@ void orc_cb_destroy(orc_cb *c)
     if (!c) return;
     free(c->pos); free(c->species); free(c->models);
     free(c->cell_start); free(c->cell_ids); free(c->cell_of);
+    free(c->img); free(c->xf);
     free(c);
 }
 
@@ -1250,7 +1277,7 @@ int64_t orc_cb_total_energy_fix(const orc_cb *cc)
         int64_t nc = cb_gather(c, lin, cand);
         for (int64_t k = c->cell_start[lin]; k < c->cell_start[lin + 1]; k++) {
             int64_t i = c->cell_ids[k];
-            double e = cb_energy_excl(c, c->pos + (size_t)i * c->d, c->species[i], cand, nc, i, -1);
+            double e = cb_energy_excl(c, c->xf + (size_t)i * c->d, c->species[i], cand, nc, i, -1);
             tot += (int64_t)(e * CB_FIX);
         }
     }
@@ -1261,12 +1288,17 @@ int64_t orc_cb_total_energy_fix(const orc_cb *cc)
 double orc_cb_energy_at(const orc_cb *cc, int64_t i, const double *x, int32_t sp)
 {
     /* brute force over all particles: exact sums do not depend on the set of
-     * zero-contributing (out-of-range) candidates */
-    const orc_cb *c = cc;
+     * zero-contributing (out-of-range) candidates.  x is unwrapped, in the frame of particle i: folded with its image. */
+    orc_cb *c = (orc_cb *)cc;
+    double xq[3] = {0, 0, 0};
+    for (int64_t j = 0; j < c->N; j++)
+        for (int a = 0; a < c->d; a++)
+            c->xf[(size_t)j * c->d + a] = cb_fold(c->pos[(size_t)j * c->d + a], c->img[(size_t)j * c->d + a], c->box[a]);
+    for (int a = 0; a < c->d; a++) xq[a] = cb_fold(x[a], c->img[(size_t)(i - 1) * c->d + a], c->box[a]);
     double e = 0.0;
     for (int64_t j = 0; j < c->N; j++)
         if (j != i - 1)
-            e += cb_pair(c, x, sp, j);
+            e += cb_pair(c, xq, sp, j);
     return e;
 }
 
@@ -1322,12 +1354,13 @@ void orc_cb_sweeps_rounds(orc_cb *c, const orc_move *pool, int32_t npool, uint64
                     if (pool[m].kind == ORC_MOVE_DISPLACEMENT) {
                         int64_t i = c->cell_ids[k0 + mulhi32(R[1], (uint32_t)nc)];
                         double z[4], xn[3];
-                        double *xo = c->pos + (size_t)i * d;
+                        double *xo = c->xf + (size_t)i * d;            /* folded coordinates */
+                        const int32_t *ki = c->img + (size_t)i * d;
                         orc_box_muller(Q[0], Q[1], &z[0], &z[1]);
                         orc_box_muller(Q[2], Q[3], &z[2], &z[3]);
                         int inside = 1;
                         for (int a = 0; a < d; a++) {
-                            xn[a] = xo[a] + pool[m].sigma * z[a];
+                            xn[a] = cb_settle(xo[a] + pool[m].sigma * z[a], ki[a], c->box[a]);
                             if (floor((xn[a] - shift[a]) / c->w[a]) != floor((xo[a] - shift[a]) / c->w[a]))
                                 inside = 0;
                         }
@@ -1336,7 +1369,10 @@ void orc_cb_sweeps_rounds(orc_cb *c, const orc_move *pool, int32_t npool, uint64
                         double e2 = cb_energy_excl(c, xn, c->species[i], cand, ncand, i, -1);
                         double de = e2 - e1;
                         if (c->temperature * lnu < -de) {   /* accept iff T ln u < -dE (DESIGN.md "schedule") */
-                            for (int a = 0; a < d; a++) xo[a] = xn[a];
+                            for (int a = 0; a < d; a++) {
+                                xo[a] = xn[a];
+                                c->pos[(size_t)i * d + a] = cb_unfold(xn[a], ki[a], c->box[a]);   /* k = 0: x + delta (src/moves.jl:46-48) */
+                            }
                             c->e_fix += (int64_t)(de * CB_FIX);
                             stats->accepted[m]++;
                         }
@@ -1356,7 +1392,7 @@ void orc_cb_sweeps_rounds(orc_cb *c, const orc_move *pool, int32_t npool, uint64
                             if (c->species[id] == sa && ka-- == 0) i = id;
                             if (c->species[id] == sb && kb-- == 0) j = id;
                         }
-                        const double *xi = c->pos + (size_t)i * d, *xj = c->pos + (size_t)j * d;
+                        const double *xi = c->xf + (size_t)i * d, *xj = c->xf + (size_t)j * d;
                         double e1 = cb_energy_excl(c, xi, sa, cand, ncand, i, j) +
                                     cb_energy_excl(c, xj, sb, cand, ncand, i, j);
                         double e2 = cb_energy_excl(c, xi, sb, cand, ncand, i, j) +

@@ -19,6 +19,19 @@
 #define PMC_DECL_2_4(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<2, 4, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
 PMC_CB_VARIANTS(PMC_DECL_3_0) PMC_CB_VARIANTS(PMC_DECL_3_1) PMC_CB_VARIANTS(PMC_DECL_3_2) PMC_CB_VARIANTS(PMC_DECL_3_3) PMC_CB_VARIANTS(PMC_DECL_3_4)
 PMC_CB_VARIANTS(PMC_DECL_2_0) PMC_CB_VARIANTS(PMC_DECL_2_1) PMC_CB_VARIANTS(PMC_DECL_2_2) PMC_CB_VARIANTS(PMC_DECL_2_3) PMC_CB_VARIANTS(PMC_DECL_2_4)
+#define PMC_DECLI(DD_, KK_, M_, NW_, ONE_) extern template __global__ void k_cb_pass<DD_, KK_, M_, NW_, ONE_, PMC_CB_MINWAVES, true>(const CbArgs *__restrict__, int);
+#define PMC_DECLI_3_0(M_, NW_, ONE_) PMC_DECLI(3, 0, M_, NW_, ONE_)
+#define PMC_DECLI_3_1(M_, NW_, ONE_) PMC_DECLI(3, 1, M_, NW_, ONE_)
+#define PMC_DECLI_3_2(M_, NW_, ONE_) PMC_DECLI(3, 2, M_, NW_, ONE_)
+#define PMC_DECLI_3_3(M_, NW_, ONE_) PMC_DECLI(3, 3, M_, NW_, ONE_)
+#define PMC_DECLI_3_4(M_, NW_, ONE_) PMC_DECLI(3, 4, M_, NW_, ONE_)
+#define PMC_DECLI_2_0(M_, NW_, ONE_) PMC_DECLI(2, 0, M_, NW_, ONE_)
+#define PMC_DECLI_2_1(M_, NW_, ONE_) PMC_DECLI(2, 1, M_, NW_, ONE_)
+#define PMC_DECLI_2_2(M_, NW_, ONE_) PMC_DECLI(2, 2, M_, NW_, ONE_)
+#define PMC_DECLI_2_3(M_, NW_, ONE_) PMC_DECLI(2, 3, M_, NW_, ONE_)
+#define PMC_DECLI_2_4(M_, NW_, ONE_) PMC_DECLI(2, 4, M_, NW_, ONE_)
+PMC_CB_VARIANTS_IMG(PMC_DECLI_3_0) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_1) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_2) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_3) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_4)
+PMC_CB_VARIANTS_IMG(PMC_DECLI_2_0) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_1) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_2) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_3) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_4)
 #endif
 
 #include <rccl/rccl.h>     // types only: the library itself is opened with dlopen on first use
@@ -109,10 +122,13 @@ struct pmc_system {
     int *d_start = nullptr, *d_ids = nullptr;
     double *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr;
     unsigned char *d_ssp = nullptr;
+    int *d_img = nullptr, *d_simg = nullptr;   // persistent packed images (id order; set by pmc_upload) and their cell-sorted copy
+    bool any_img = false;        // some particle has a non-zero image (else the kernels get null image pointers and skip all of it)
     bool mc_binned = false;      // CSR + SoA consistent with d_pos
     bool count_is_zero = false;  // d_count[0..ncell_mc] is all zero (left so by the last throughput scan)
     unsigned long long *d_stats = nullptr;
-    CbArgs *d_cbtab = nullptr;   // launch arguments of the sweeps of one chunk (k_cb_pass reads them from device memory)
+    CbArgs *d_cbtab = nullptr;   // launch arguments of the passes of one chunk (k_cb_pass reads them from device memory)
+    size_t cbtab_cap = 0;        // entries d_cbtab holds
     double *d_result = nullptr;
     int max_count = 0;
 };
@@ -411,9 +427,10 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         h->grid.n[a] = (int)n;
         h->grid.w[a] = n ? p->box[a] / (double)n : 0.0;
         h->grid.shift[a] = 0.0;
+        h->grid.L[a] = p->box[a];
         nmc *= n;
     }
-    if (h->D == 2) { h->grid.n[2] = 1; h->grid.w[2] = 1.0; h->grid.shift[2] = 0.0; }
+    if (h->D == 2) { h->grid.n[2] = 1; h->grid.w[2] = 1.0; h->grid.shift[2] = 0.0; h->grid.L[2] = 1.0; }
     h->ncell_mc = h->mc_ok ? (int)nmc : 0;
 
     int rc = set_device(h);
@@ -489,6 +506,12 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         CR(hipMalloc(&h->d_sy, N * sizeof(double)));
         CR(hipMalloc(&h->d_sz, N * sizeof(double)));
         CR(hipMalloc(&h->d_ssp, N));
+        CR(hipMalloc(&h->d_img, N * sizeof(int)));
+        CR(hipMalloc(&h->d_simg, N * sizeof(int)));
+        {
+            std::vector<int> z((size_t)N, PMC_IMG_ZERO);
+            CR(hipMemcpy(h->d_img, z.data(), N * sizeof(int), hipMemcpyHostToDevice));
+        }
         CR(hipMalloc(&h->d_slot_f, 4 * N * sizeof(double)));
         CR(hipMalloc(&h->d_slot_w, 2 * N * sizeof(uint32_t)));
         CR(hipMalloc(&h->d_slot_m, N));
@@ -496,6 +519,13 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         CR(hipMemset(h->d_done, 0, (size_t)h->ncell_mc * sizeof(unsigned int)));
         CR(hipMalloc(&h->d_ticket, PMC_TICKET_LANES * PMC_TICKET_STRIDE * sizeof(unsigned long long)));
         CR(hipMemset(h->d_ticket, 0, PMC_TICKET_LANES * PMC_TICKET_STRIDE * sizeof(unsigned long long)));
+        {
+            // one ticket counter per XCD only on a device that reports eight of them (the scheme's progress argument assumes
+            // workgroups are dealt to the XCDs round-robin in launch order: DESIGN.md 4.3); anything else takes the single counter
+            int nxcc = 0;
+            if (hipDeviceGetAttribute(&nxcc, hipDeviceAttributeNumberOfXccs, h->p.device) != hipSuccess) nxcc = 0;
+            h->ticket_lanes = (nxcc == PMC_TICKET_LANES) ? PMC_TICKET_LANES : 1;
+        }
         if (const char *e = getenv("PMC_TICKETS")) h->ticket_lanes = atoi(e) == 1 ? 1 : PMC_TICKET_LANES;
         if (const char *e = getenv("PMC_NO_FUSED")) h->use_fused = !(e[0] == '1');
         if (const char *e = getenv("PMC_FUSED_LPT")) h->fused_lpt = (e[0] == '1') ? 1 : 0;
@@ -521,7 +551,7 @@ extern "C" int pmc_destroy(pmc_system *h)
     void *ptrs[] = {h->d_pos, h->d_species, h->d_models, h->d_cs, h->d_head, h->d_list, h->d_ccount, h->d_nbr,
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
-                    h->d_sz, h->d_ssp, h->d_stats, h->d_cbtab, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m,
+                    h->d_sz, h->d_ssp, h->d_stats, h->d_cbtab, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m, h->d_img, h->d_simg,
                     h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
@@ -585,6 +615,19 @@ extern "C" int pmc_upload(pmc_system *h, const double *pos, const int32_t *speci
         HIPCHK(h, hipMemcpy(h->d_species, sp0.data(), (size_t)h->N * sizeof(int), hipMemcpyHostToDevice));
         rc = build_species_list(h, sp0);
         if (rc) return rc;
+    }
+    if (h->mc_ok) {
+        // the persistent periodic image of every particle (pmc_kernels.h "images"): fixed here, until the next upload
+        const int nb = (h->N + 255) / 256;
+        int *d_any = reinterpret_cast<int *>(h->d_result);      // (scratch of the per-move verbs: 8 doubles)
+        HIPCHK(h, hipMemsetAsync(d_any, 0, sizeof(int), h->stream));
+        if (h->D == 3) hipLaunchKernelGGL(k_fold_images<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->N, h->p.box[0], h->p.box[1], h->p.box[2], h->d_img, d_any);
+        else hipLaunchKernelGGL(k_fold_images<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->N, h->p.box[0], h->p.box[1], 1.0, h->d_img, d_any);
+        HIPCHK(h, hipGetLastError());
+        int any = 0;
+        HIPCHK(h, hipMemcpyAsync(&any, d_any, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->any_img = any != 0;
     }
     h->cells_built = false;
     h->mc_binned = false;
@@ -1227,17 +1270,19 @@ static int mc_bin(pmc_system *h, const double shift[3], const SlotGen *slots = n
     // the scan of the previous throughput binning left the counters zeroed (k_scan_*: zero = 1)
     if (!h->count_is_zero) HIPCHK(h, hipMemsetAsync(h->d_count, 0, ((size_t)h->ncell_mc + 1) * sizeof(int), h->stream));
     unsigned long long *const t8 = h->ticket_lanes == PMC_TICKET_LANES ? h->d_ticket : nullptr;
-    if (h->D == 3) hipLaunchKernelGGL(k_mc_bin_a<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival, t8);
-    else hipLaunchKernelGGL(k_mc_bin_a<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival, t8);
+    const int *const img = h->any_img ? h->d_img : nullptr;
+    int *const simg = h->any_img ? h->d_simg : nullptr;
+    if (h->D == 3) hipLaunchKernelGGL(k_mc_bin_a<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, img, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival, t8);
+    else hipLaunchKernelGGL(k_mc_bin_a<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, img, N, h->grid, h->d_cell_of, h->d_count, h->d_arrival, t8);
     if (int rc = scan_counts(h, h->ncell_mc, h->d_start, 1)) return rc;
     h->count_is_zero = true;
     hipLaunchKernelGGL(k_mc_bin_b, dim3(nb), dim3(256), 0, h->stream, h->d_cell_of, h->d_arrival, N, h->d_start, h->d_tmp_ids);
     if (h->D == 3)
         hipLaunchKernelGGL(k_mc_bin_c<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->d_species, h->d_cell_of, N, h->d_start,
-                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp, gen);
+                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp, gen, img, simg, h->p.box[0], h->p.box[1], h->p.box[2]);
     else
         hipLaunchKernelGGL(k_mc_bin_c<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->d_species, h->d_cell_of, N, h->d_start,
-                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp, gen);
+                           h->d_tmp_ids, h->d_ids, h->d_sx, h->d_sy, h->d_sz, h->d_ssp, gen, img, simg, h->p.box[0], h->p.box[1], 1.0);
     HIPCHK(h, hipGetLastError());
     h->mc_binned = true;
     return PMC_OK;
@@ -1268,7 +1313,7 @@ static int cb_cap(const pmc_system *h);
 static bool cb_fuse_teams(const pmc_system *h)
 {
     if (const char *e = getenv("PMC_FUSE_TEAMS")) return e[0] == '1';      // experiments
-    if (!h->mc_ok || !h->use_filter || h->D != 3) return false;
+    if (!h->mc_ok || !h->use_filter || h->D != 3 || h->S < 2) return false;      // (compiled into the multi-species kernels only)
     return 3.0 * (double)h->N / (double)h->ncell_mc > 62.0;
 }
 
@@ -1289,6 +1334,8 @@ static CbArgs cb_args(pmc_system *h)
     a.start = h->d_start; a.ids = h->d_ids;
     a.sx = h->d_sx; a.sy = h->d_sy; a.sz = h->d_sz; a.ssp = h->d_ssp;
     a.pos = h->d_pos; a.species = h->d_species;
+    a.img = h->any_img ? h->d_img : nullptr;
+    a.simg = h->any_img ? h->d_simg : nullptr;
     a.N = h->N; a.S = h->S;
     a.key0 = h->key[0]; a.key1 = h->key[1];
     a.m0 = to_dev(h->models[0]);
@@ -1372,11 +1419,19 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0, int cap = 0)
     return b;
 }
 
-#define PMC_ARGS_CHUNK 256     // sweeps whose launch arguments are uploaded together
+#define PMC_ARGS_CHUNK 256     // passes whose launch arguments are uploaded together (blocking calls)
+#define PMC_ARGS_ASYNC_MAX 8192   // ... by pmc_sweep_begin, which must not wait for the device: longer calls wait once per 8192 passes
 // k_cb_pass additionally carries the team size NW (wavefronts per cell)
 // The launch arguments (CbArgs) are read from device memory: `args` below is a device pointer to nrep_ of them.
-#define DISPATCH_CB_ONE(DD, KK, NWV, MWV, h, grid, lds, args)   /* uses pool_ (MovePool), nrep_ and mw_ (int) of the caller's scope */                                      \
-    if (!done_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV && mw_ == MWV) {                           \
+#define DISPATCH_CB_ONE(DD, KK, NWV, MWV, h, grid, lds, args)   /* uses pool_ (MovePool), nrep_, mw_ (int) and img_ (bool) of the caller's scope */                                      \
+    if (!done_ && img_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV && MWV == PMC_CB_MINWAVES) {   /* systems with periodic images: one register budget */ \
+        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        done_ = true;                                                                                           \
+    }                                                                                                           \
+    if (!done_ && !img_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV && mw_ == MWV) {                   \
         if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true, MWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
         else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false, MWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
         else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true, MWV>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
@@ -1452,8 +1507,14 @@ static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
         return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity (that cell's slots were "
                                             "skipped; moves accepted in other cells are kept and the energy is recomputed on the next call)");
     if (st[17] & 2ull)
+    {
+        // the eight-counter ticket scheme assumes in-order round-robin dispatch to the XCDs for its progress argument (DESIGN.md
+        // 4.3); whatever starved this launch, the handle takes the order-independent single counter from now on
+        h->ticket_lanes = 1;
         return fail(h, PMC_ERR_STATE, "fused sweep: a cell's completion flag was never seen (positions were modified by a partial "
-                                      "sweep: the chain is invalid; upload the configuration again)");
+                                      "sweep: the chain is invalid; upload the configuration again -- the handle now draws its "
+                                      "workgroup tickets from the single, dispatch-order-independent counter)");
+    }
     return PMC_OK;
 }
 
@@ -1622,12 +1683,16 @@ static void cb_invalidate(pmc_system *h)
     if (h->S > 1) h->species_list_stale = true;
 }
 
-static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing);
+static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing, bool async);
 
-static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing)
+// async (pmc_sweep_begin): the call must return without waiting for the device, so that the chains of several handles
+// overlap: the launch arguments of ALL its passes (up to PMC_ARGS_ASYNC_MAX) go up at once and the LDS capacity is not
+// re-learnt inside the call (pmc_sweep_end learns from the whole call).  Blocking calls (pmc_sweep) work in chunks of
+// PMC_ARGS_CHUNK passes and re-fit the capacity between chunks.
+static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing, bool async = false)
 {
     h->cb_started = false;
-    const int rc = cb_enqueue_sweeps(h, pool, npool, nsweeps, want_timing);
+    const int rc = cb_enqueue_sweeps(h, pool, npool, nsweeps, want_timing, async);
     if (rc != PMC_OK && !h->pending && h->cb_started) {
         // an error part-way through the loop leaves launches queued: drain them, then distrust the state
         (void)hipStreamSynchronize(h->stream);
@@ -1636,7 +1701,7 @@ static int cb_enqueue(pmc_system *h, const pmc_move *pool, int npool, int64_t ns
     return rc;
 }
 
-static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing)
+static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, bool want_timing, bool async)
 {
     pmc_stats *out = want_timing ? &h->done_stats : nullptr;
     if (!h->mc_ok)
@@ -1670,16 +1735,22 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     const int per_sweep = fused ? 1 : ncol;  // launches, and CbArgs entries, per sweep
     const MovePool &pool_ = mp;
     const int nrep_ = 1;
+    const bool img_ = h->any_img;          // some particle carries a periodic image: the kernel instances with the image path
     int mw_ = cb_minwaves(h, lds);
     // long calls: the staging capacity is fitted again (cb_cap_learn) to what the last chunk of sweeps saw -- a first call on
     // a handle after 16 sweeps already
-    const bool learn = cb_cap_sweep_adapts(h);
+    const bool learn = cb_cap_sweep_adapts(h) && !async;
     const bool learn_early = learn && h->cap_hint <= 0 && (nsweeps + h->rounds - 1) / h->rounds > 48;
     memset(h->kept_seen, 0, sizeof h->kept_seen);
     // The launch arguments of the sweep kernel live in device memory (k_cb_pass): all the sweeps of a chunk are prepared
     // here and uploaded at once.
-    const int64_t chunk = PMC_ARGS_CHUNK;
-    if (!h->d_cbtab) HIPCHK(h, hipMalloc(&h->d_cbtab, (size_t)PMC_ARGS_CHUNK * per_sweep * sizeof(CbArgs)));   // use_fused is fixed per handle
+    const int64_t npass_all = (nsweeps + h->rounds - 1) / h->rounds;
+    const int64_t chunk = async ? std::max<int64_t>(PMC_ARGS_CHUNK, std::min<int64_t>(npass_all, PMC_ARGS_ASYNC_MAX)) : PMC_ARGS_CHUNK;
+    if (h->cbtab_cap < (size_t)chunk * per_sweep) {      // (use_fused is fixed per handle)
+        if (h->d_cbtab) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->d_cbtab)); h->d_cbtab = nullptr; h->cbtab_cap = 0; }
+        HIPCHK(h, hipMalloc(&h->d_cbtab, (size_t)chunk * per_sweep * sizeof(CbArgs)));
+        h->cbtab_cap = (size_t)chunk * per_sweep;
+    }
     std::vector<CbArgs> tabh;
     std::vector<std::array<double, 3>> shifts;
     const size_t Ns = (size_t)h->N * (size_t)h->slot_rounds;
@@ -1881,7 +1952,7 @@ extern "C" int pmc_sweep_begin(pmc_system *h, int32_t mode, const pmc_move *pool
     rc = set_device(h);
     if (rc) return rc;
     memset(&h->done_stats, 0, sizeof h->done_stats);
-    if (mode == PMC_CHECKERBOARD) return cb_enqueue(h, pool, npool, nsweeps, true);
+    if (mode == PMC_CHECKERBOARD) return cb_enqueue(h, pool, npool, nsweeps, true, true);
     if (mode == PMC_SEQUENTIAL) {
         rc = sweep_sequential(h, pool, npool, nsweeps, &h->done_stats);   // one wavefront: run it now
         if (rc) return rc;
@@ -2011,6 +2082,8 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         q.pos_ro = h->d_pos; q.pos = h->d_pos; q.species = h->d_species;
         q.cell_of = h->d_cell_of; q.count = h->d_count; q.arrival = h->d_arrival; q.start = h->d_start; q.tmp_ids = h->d_tmp_ids; q.ids = h->d_ids;
         q.sx = h->d_sx; q.sy = h->d_sy; q.sz = h->d_sz; q.ssp = h->d_ssp;
+        q.img = h->any_img ? h->d_img : nullptr;
+        q.simg = h->any_img ? h->d_simg : nullptr;
         q.slots = SlotOut{h->d_slot_f, h->d_slot_f + Ns, h->d_slot_f + 2 * Ns, h->d_slot_f + 3 * Ns, h->d_slot_w, h->d_slot_w + Ns, h->d_slot_m};
         q.key0 = h->key[0]; q.key1 = h->key[1];
         q.temperature = h->p.temperature;
@@ -2030,6 +2103,8 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     std::vector<CbArgs> argsh;
     const MovePool &pool_ = mp;
     const int nrep_ = n;
+    bool img_ = false;                     // (the image instances serve replicas without images too: their pointers are null)
+    for (int r = 0; r < n; r++) img_ = img_ || hs[r]->any_img;
     const int mw_ = cb_minwaves(m, lds);
     const int grid = ncol * n * nactive;
     HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
@@ -2083,8 +2158,8 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             else hipLaunchKernelGGL(k_many_bin_a<2>, dim3(nb, n), dim3(256), 0, m->stream, N, m->grid, dr, ds, t8);
             hipLaunchKernelGGL(k_many_scan, dim3(n), dim3(1024), 0, m->stream, m->ncell_mc, dr);
             hipLaunchKernelGGL(k_many_bin_b, dim3(nb, n), dim3(256), 0, m->stream, N, dr);
-            if (m->D == 3) hipLaunchKernelGGL(k_many_bin_c<3>, dim3(nb, n), dim3(256), 0, m->stream, N, mp, dr, ds);
-            else hipLaunchKernelGGL(k_many_bin_c<2>, dim3(nb, n), dim3(256), 0, m->stream, N, mp, dr, ds);
+            if (m->D == 3) hipLaunchKernelGGL(k_many_bin_c<3>, dim3(nb, n), dim3(256), 0, m->stream, N, mp, dr, ds, m->p.box[0], m->p.box[1], m->p.box[2]);
+            else hipLaunchKernelGGL(k_many_bin_c<2>, dim3(nb, n), dim3(256), 0, m->stream, N, mp, dr, ds, m->p.box[0], m->p.box[1], 1.0);
             const CbArgs *args = d_args.as<CbArgs>() + sw * n;
             DISPATCH_CB(m, grid, lds, args);
             HIPCHK(m, hipGetLastError());

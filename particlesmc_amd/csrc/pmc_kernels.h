@@ -31,6 +31,11 @@
 #define PMC_CB_VARIANTS(X)                                                                                   \
     PMC_CB_VARIANTS_NW(X, 1, 3) PMC_CB_VARIANTS_NW(X, 1, 4) PMC_CB_VARIANTS_NW(X, 2, PMC_CB_MINWAVES)         \
     PMC_CB_VARIANTS_NW(X, 4, PMC_CB_MINWAVES) PMC_CB_VARIANTS_NW(X, 8, PMC_CB_MINWAVES)
+// ... and the instances for systems in which some particle carries a periodic image (IMG = true; compiled for 4 wavefronts per
+// SIMD only): X(MULTI, NW, ONE).  Systems without images -- every run that starts folded -- run the kernels above, whose slot
+// loop does not contain a single instruction of the image path (compiled in, it cost them 1 % through register allocation alone).
+#define PMC_CB_VARIANTS_IMG_NW(X, NW) X(false, NW, false) X(false, NW, true) X(true, NW, false) X(true, NW, true)
+#define PMC_CB_VARIANTS_IMG(X) PMC_CB_VARIANTS_IMG_NW(X, 1) PMC_CB_VARIANTS_IMG_NW(X, 2) PMC_CB_VARIANTS_IMG_NW(X, 4) PMC_CB_VARIANTS_IMG_NW(X, 8)
 #define PMC_REF_IDS 2048     // neighbourhood size (ids) the ordered-energy LDS buffer holds (8 KB: 20 wavefronts per CU)
 #define PMC_MAXNN 27
 #define PMC_REC 12           // doubles per slot record: old xyz, new xyz, dE, T ln u, LDS slot i, valid, LDS slot j, move
@@ -77,7 +82,57 @@ struct GridGeom {
     int n[3];
     double w[3];
     double shift[3];
+    double L[3];               // box lengths (folding of the cell-sorted copy)
 };
+
+// ------------------------------------------------------------------------------
+// Periodic images of the throughput engine (DESIGN.md 2.2 "images").  Positions are never wrapped (src/moves.jl:46-48), so
+// an unwrapped input -- a restart from an unwrapped frame, a long run -- has particles many boxes apart, and every pair
+// then needs the minimum image.  Every particle therefore carries a PERSISTENT integer image k (per dimension), fixed at
+// pmc_upload as floor(x / L) (|k| <= 511, else 0), and the throughput kernels work on the folded coordinate
+//     xf = x - k L          (k = 0: xf = x, bit for bit)
+// of the cell-sorted copy.  A move is evaluated, and stored, at a position that survives the round trip through the
+// unwrapped array exactly:  xf' = ((xf + delta) + k L) - k L,  x' = xf' + k L  (k = 0: xf' = x' = x + delta, the
+// reference's update_position!).  k never changes between uploads, so every energy is a pure function of the state
+// (x, k): the running energy still equals a recomputation bit for bit.  Packed: 10 bits per dimension, biased by 512.
+// ------------------------------------------------------------------------------
+#define PMC_IMG_MAX 511
+__host__ __device__ __forceinline__ int img_pack(int kx, int ky, int kz)
+{
+    return ((kx + 512) & 1023) | (((ky + 512) & 1023) << 10) | (((kz + 512) & 1023) << 20);
+}
+#define PMC_IMG_ZERO (512 | (512 << 10) | (512 << 20))
+__host__ __device__ __forceinline__ int img_get(int packed, int q) { return ((packed >> (10 * q)) & 1023) - 512; }
+// xf = x - k L
+__host__ __device__ __forceinline__ double img_fold(double x, int k, double L) { return k == 0 ? x : x - (double)k * L; }
+// x = xf + k L
+__host__ __device__ __forceinline__ double img_unfold(double xf, int k, double L) { return k == 0 ? xf : xf + (double)k * L; }
+// the folded coordinate a move to `t` = xf + delta is evaluated and stored at
+__host__ __device__ __forceinline__ double img_settle(double t, int k, double L)
+{
+    if (k == 0) return t;
+    const double kl = (double)k * L;
+    return (t + kl) - kl;
+}
+
+// pmc_upload: k = floor(x / L) per dimension (IEEE division); particles farther than PMC_IMG_MAX boxes stay unfolded
+template <int D>
+__global__ void k_fold_images(const double *__restrict__ pos, int N, double L0, double L1, double L2, int *__restrict__ img,
+                              int *__restrict__ any)       // any: set to 1 if some particle has an image
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double L[3] = {L0, L1, L2};
+    int k[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < D; q++) {
+        const double f = floor(pos[(size_t)i * D + q] / L[q]);
+        k[q] = (fabs(f) <= (double)PMC_IMG_MAX) ? (int)f : 0;
+    }
+    const int packed = img_pack(k[0], k[1], k[2]);
+    img[i] = packed;
+    if (__builtin_amdgcn_ballot_w64(packed != PMC_IMG_ZERO) != 0ull && (threadIdx.x & (PMC_WAVE - 1)) == 0) atomicOr(any, 1);
+}
 
 template <int D>
 __device__ __forceinline__ double mc_coord(double x, double shift, double w)
@@ -87,15 +142,16 @@ __device__ __forceinline__ double mc_coord(double x, double shift, double w)
 
 // throughput-grid binning, pass A: cell index + arrival ticket inside the cell
 template <int D>
-__device__ __forceinline__ void mc_bin_a_body(const double *__restrict__ pos, int N, const GridGeom &g, int *__restrict__ cell_of,
-                                              int *__restrict__ count, int *__restrict__ arrival)
+__device__ __forceinline__ void mc_bin_a_body(const double *__restrict__ pos, const int *__restrict__ img, int N, const GridGeom &g,
+                                              int *__restrict__ cell_of, int *__restrict__ count, int *__restrict__ arrival)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     long long lin = 0;
+    const int im = img ? img[i] : PMC_IMG_ZERO;     // (img == nullptr: no particle of this system has an image)
 #pragma unroll
     for (int a = 0; a < D; a++) {
-        long long q = (long long)mc_coord<D>(pos[(size_t)i * D + a], g.shift[a], g.w[a]);
+        long long q = (long long)mc_coord<D>(img_fold(pos[(size_t)i * D + a], img_get(im, a), g.L[a]), g.shift[a], g.w[a]);
         long long r = q % g.n[a];
         if (r < 0) r += g.n[a];
         lin = lin * g.n[a] + r;
@@ -125,11 +181,11 @@ __device__ __forceinline__ void mc_bin_a_body(const double *__restrict__ pos, in
 
 // (ticket8: the fused sweep's ticket counters start every sweep at 0 -- this is the first kernel of a sweep)
 template <int D>
-__global__ void k_mc_bin_a(const double *__restrict__ pos, int N, GridGeom g, int *__restrict__ cell_of,
+__global__ void k_mc_bin_a(const double *__restrict__ pos, const int *__restrict__ img, int N, GridGeom g, int *__restrict__ cell_of,
                            int *__restrict__ count, int *__restrict__ arrival, unsigned long long *__restrict__ ticket8)
 {
     if (ticket8 && blockIdx.x == 0 && threadIdx.x < PMC_TICKET_LANES) ticket8[threadIdx.x * PMC_TICKET_STRIDE] = 0ull;
-    mc_bin_a_body<D>(pos, N, g, cell_of, count, arrival);
+    mc_bin_a_body<D>(pos, img, N, g, cell_of, count, arrival);
 }
 
 // pass B: place ids by ticket (order inside a cell still depends on atomic arrival)
@@ -170,7 +226,8 @@ __device__ __forceinline__ void mc_bin_c_body(const double *__restrict__ pos, co
                                               const int *__restrict__ cell_of, int N, const int *__restrict__ start,
                                               const int *__restrict__ tmp_ids, int *__restrict__ ids, double *__restrict__ sx,
                                               double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp,
-                                              const SlotGen &gen)
+                                              const SlotGen &gen, const int *__restrict__ img, int *__restrict__ simg,
+                                              double L0, double L1, double L2)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -180,9 +237,11 @@ __device__ __forceinline__ void mc_bin_c_body(const double *__restrict__ pos, co
     for (int k = lo; k < hi; k++) r += (tmp_ids[k] < i);
     int dst = lo + r;
     ids[dst] = i;
-    sx[dst] = pos[(size_t)i * D + 0];
-    sy[dst] = pos[(size_t)i * D + 1];
-    if (D == 3) sz[dst] = pos[(size_t)i * D + 2];
+    const int im = img ? img[i] : PMC_IMG_ZERO;
+    if (img) simg[dst] = im;
+    sx[dst] = img_fold(pos[(size_t)i * D + 0], img_get(im, 0), L0);
+    sy[dst] = img_fold(pos[(size_t)i * D + 1], img_get(im, 1), L1);
+    if (D == 3) sz[dst] = img_fold(pos[(size_t)i * D + 2], img_get(im, 2), L2);
     ssp[dst] = (unsigned char)species[i];
     if (gen.enabled) {
         const int nc = hi - lo;
@@ -194,9 +253,10 @@ template <int D>
 __global__ void k_mc_bin_c(const double *__restrict__ pos, const int *__restrict__ species,
                            const int *__restrict__ cell_of, int N, const int *__restrict__ start,
                            const int *__restrict__ tmp_ids, int *__restrict__ ids, double *__restrict__ sx,
-                           double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp, SlotGen gen)
+                           double *__restrict__ sy, double *__restrict__ sz, unsigned char *__restrict__ ssp, SlotGen gen,
+                           const int *__restrict__ img, int *__restrict__ simg, double L0, double L1, double L2)
 {
-    mc_bin_c_body<D>(pos, species, cell_of, N, start, tmp_ids, ids, sx, sy, sz, ssp, gen);
+    mc_bin_c_body<D>(pos, species, cell_of, N, start, tmp_ids, ids, sx, sy, sz, ssp, gen, img, simg, L0, L1, L2);
 }
 
 // ------------------------------------------------------------------------------
@@ -213,6 +273,8 @@ struct ManyRep {
     int *cell_of, *count, *arrival, *start, *tmp_ids, *ids;
     double *sx, *sy, *sz;
     unsigned char *ssp;
+    const int *img;            // persistent images, particle-id order
+    int *simg;                 // ... cell-sorted copy of the current pass
     SlotOut slots;
     uint32_t key0, key1;
     double temperature;
@@ -235,7 +297,7 @@ __global__ void k_many_bin_a(int N, GridGeom g, const ManyRep *__restrict__ reps
     const ManyStep &st = steps[blockIdx.y];
 #pragma unroll
     for (int q = 0; q < 3; q++) g.shift[q] = st.shift[q];
-    mc_bin_a_body<D>(r.pos_ro, N, g, r.cell_of, r.count, r.arrival);
+    mc_bin_a_body<D>(r.pos_ro, r.img, N, g, r.cell_of, r.count, r.arrival);
 }
 
 // exclusive scan of every replica's cell counts, one block per replica (grids of <= PMC_SCAN_SMALL_MAX cells)
@@ -270,7 +332,8 @@ PMC_GLOBAL void k_many_bin_b(int N, const ManyRep *__restrict__ reps)
 }
 
 template <int D>
-__global__ void k_many_bin_c(int N, MovePool pool, const ManyRep *__restrict__ reps, const ManyStep *__restrict__ steps)
+__global__ void k_many_bin_c(int N, MovePool pool, const ManyRep *__restrict__ reps, const ManyStep *__restrict__ steps,
+                             double L0, double L1, double L2)
 {
     const ManyRep &r = reps[blockIdx.y];
     const ManyStep &st = steps[blockIdx.y];
@@ -281,7 +344,7 @@ __global__ void k_many_bin_c(int N, MovePool pool, const ManyRep *__restrict__ r
     gen.temperature = r.temperature;
     gen.pool = pool;
     gen.out = r.slots;
-    mc_bin_c_body<D>(r.pos_ro, r.species, r.cell_of, N, r.start, r.tmp_ids, r.ids, r.sx, r.sy, r.sz, r.ssp, gen);
+    mc_bin_c_body<D>(r.pos_ro, r.species, r.cell_of, N, r.start, r.tmp_ids, r.ids, r.sx, r.sy, r.sz, r.ssp, gen, r.img, r.simg, L0, L1, L2);
 }
 
 // three-launch exclusive scan: tile sums, scan of the tile sums, tile scan + base
@@ -1178,6 +1241,8 @@ struct CbArgs {
     double *sx, *sy, *sz;
     unsigned char *ssp;
     double *pos;               // AoS, particle-id order (kept current)
+    const int *img;            // persistent packed images, particle-id order (img_pack); nullptr: no particle has one
+    const int *simg;           // ... of the cell-sorted slots of this pass (nullptr likewise)
     int *species;
     int N, S;
     uint32_t key0, key1, s_lo, s_hi;
@@ -1275,6 +1340,7 @@ struct WaveNbh {
     bool compacted;          // the box filter was applied while staging (stage_compacted)
     int kept;                // candidates that passed the box filter (stage_compacted; a huge value if it could not count them)
     int loaded;              // population of the 3^d cells the staging read from global memory
+    int myimg;               // packed image of centre-cell particle `lane` (PMC_IMG_ZERO behind the last one)
 #ifdef PMC_DEBUG_TIME
     unsigned long long ts[10];  // stamps inside stage_neighbourhood: entry, table ready, flags seen, coordinates arrived, done; [5..8] inside stage_compacted
 #endif
@@ -1517,6 +1583,8 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
     for (int q = 0; q < D; q++) lin_c = lin_c * a.n[q] + cell[q];
     h.k0 = a.start[lin_c];
     h.nc = a.start[lin_c + 1] - h.k0;
+    // (requested here so that it travels with the coordinate loads; only visits of particles outside the primary box use it)
+    h.myimg = (a.simg && lane < h.nc) ? a.simg[h.k0 + lane] : PMC_IMG_ZERO;     // (a.simg == nullptr: a system without images)
     int run_start = 0, run_cnt = 0;
     bool runs_long = false;    // a run of 3 cells longer than a wavefront: stage_compacted takes the 3^D single cells instead
     if (runs_ok) {
@@ -2061,6 +2129,8 @@ __device__ __forceinline__ void update_fregs(FRegs &f, int pc, float fx, float f
 struct PairCount {
     unsigned tests, energies;     // per wavefront: FP32 distance tests, in-range pair energies evaluated
     unsigned dense;               // FP64 distance evaluations: (queue entry, old | new position) of the filtered path, every (candidate, position) of the direct one
+    bool count_dense;             // ... counted only by the kernels that have a register for it: one wavefront per cell, one species (the
+                                  // benchmark's instance carries it for free; in the others it cost 8-24 B of scratch per lane)
 #ifdef PMC_DEBUG_TIME
     unsigned long long t_filter, t_dense;
 #endif
@@ -2089,7 +2159,7 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
     const bool isnew = (lane & 1) != 0;
     const double xi = isnew ? xn : xo, yi = isnew ? yn : yo, zi = isnew ? zn : zo;
     const int qe = 2 * qn;
-    pcnt.dense += (unsigned)qe;
+    if (pcnt.count_dense) pcnt.dense += (unsigned)qe;
     for (int e0 = 0; e0 < qe; e0 += PMC_WAVE) {
         // lanes behind the last entry re-read it (no branch around the loads) and are masked out of the range test
         const int e = min(e0 + lane, qe - 1);
@@ -2292,7 +2362,7 @@ __device__ __forceinline__ double wave_delta_e_direct(const CbArgs &a, const Wav
         term(k, xj, yj, zj, sj, std::false_type{});
     }
     pcnt.tests += 2u * (unsigned)h.ncand;
-    pcnt.dense += 2u * (unsigned)h.ncand;
+    if (pcnt.count_dense) pcnt.dense += 2u * (unsigned)h.ncand;
     unsigned tot = nin;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) tot += __shfl_xor(tot, s, PMC_WAVE);
@@ -2546,14 +2616,13 @@ struct CbTotals {
     long long efix;                  // accepted energy change in units of 2^-32
     unsigned long long nnull;
     unsigned long long tests, energies;
-    unsigned long long loaded, written;   // candidates loaded from global memory by the staging (all 3^d cells); particles written back
     PairCount pcnt;                  // per-wavefront work counters of the current visit
 #ifdef PMC_DEBUG_TIME
     unsigned long long tp[16];
 #endif
 };
 
-template <int D, int KIND, bool MULTI, int NW, bool ONE>
+template <int D, int KIND, bool MULTI, int NW, bool ONE, bool IMG>
 __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevModel *tab, int colour, int aidx,
                                          unsigned long long *st, CbTotals &tot)
 {
@@ -2584,15 +2653,21 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
 #endif
     // (teams are for small and medium systems, where a visit is one latency chain and LDS is plentiful: the fused staging's
     // count exchange between the wavefronts costs them 2-9 %)
-    // teams take the fused staging only where a.fuse_teams says so (dense systems: see pmc_hip.hip, cb_fuse_teams)
-    constexpr bool FUSE = PMC_FUSED_STAGE;
+    // teams take the fused staging only in the multi-species instances, and there only where a.fuse_teams says so (dense
+    // systems: see pmc_hip.hip, cb_fuse_teams); compiling it into the single-species team kernels as well cost them 20 KB of
+    // code and 16-20 B more scratch per lane for a path their systems never take
+    constexpr bool FUSE = PMC_FUSED_STAGE && (NW == 1 || MULTI);
     stage_neighbourhood<D, MULTI, NW, FUSE>(a, cell, h, a.fused ? colour : 0);
     PMC_T(t_2);
 #if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 2
     { if (a.fused) publish_done(a, lin, tid == 0); return; }
 #endif
     const int nc = h.nc;
-    tot.loaded += (unsigned long long)h.loaded;
+    // packed images of the centre-cell particles, lane p <-> particle p (the load travels while the candidates are compacted);
+    // a visit of in-box particles only -- every visit of a run that started folded -- never looks at them again
+    const int myimg = IMG ? h.myimg : PMC_IMG_ZERO;
+    // (work counter of the roofline: candidates this visit loaded from global memory; fire-and-forget, no register lives on)
+    if (tid == 0 && h.loaded > 0) atomicAdd(&st[31], (unsigned long long)h.loaded);
     if (nc == 0) { if (a.fused) publish_done(a, lin, tid == 0); return; }
     if (h.ctr + nc > h.cap) {
         if (tid == 0) atomicOr(&st[17], 1ull);
@@ -2623,6 +2698,16 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     int nbatch = 0;
     const double my_shift = (lane == 0) ? a.shift[0] : ((lane == 1) ? a.shift[1] : a.shift[2]);
     const double my_w = (lane == 0) ? a.w[0] : ((lane == 1) ? a.w[1] : a.w[2]);
+    const bool anyimg = IMG && a.simg && ((nc > PMC_WAVE) || (__builtin_amdgcn_ballot_w64(myimg != PMC_IMG_ZERO) != 0ull));
+    // the folded position a proposal of centre particle p (image `kp`) is evaluated and stored at (img_settle)
+    auto settle = [&](int p, double &xn, double &yn, double &zn) {
+        const int kp = (p < PMC_WAVE) ? __builtin_amdgcn_readlane(myimg, p) : a.simg[h.k0 + p];
+        if (kp != PMC_IMG_ZERO) {
+            xn = img_settle(xn, img_get(kp, 0), a.L[0]);
+            yn = img_settle(yn, img_get(kp, 1), a.L[1]);
+            if (D == 3) zn = img_settle(zn, img_get(kp, 2), a.L[2]);
+        }
+    };
 
     const int nsl = nc * a.rounds;     // proposal slots of this visit
     for (int chunk = 0; chunk < nsl; chunk += PMC_WAVE) {
@@ -2703,9 +2788,10 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     } else {
                     const int pc = h.ctr + (int)mulhi32(w1, (uint32_t)nc);
                     const double xo = h.cx[pc], yo = h.cy[pc], zo = (D == 3) ? h.cz[pc] : 0.0;
-                    const double xn = xo + readlane_double(g_dx, my);
-                    const double yn = yo + readlane_double(g_dy, my);
-                    const double zn = (D == 3) ? zo + readlane_double(g_dz, my) : 0.0;
+                    double xn = xo + readlane_double(g_dx, my);
+                    double yn = yo + readlane_double(g_dy, my);
+                    double zn = (D == 3) ? zo + readlane_double(g_dz, my) : 0.0;
+                    if (anyimg) settle(__builtin_amdgcn_readfirstlane(pc - h.ctr), xn, yn, zn);
                     const bool inside = stays_in_cell<D>(a, h, pc - h.ctr, xo, yo, zo, xn, yn, zn, my_shift, my_w);
                     double de = 0.0;
                     if (inside) {
@@ -2899,9 +2985,10 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                 const int p = (int)mulhi32(w1, (uint32_t)nc);
                 const int pc = h.ctr + p;
                 const double xo = h.cx[pc], yo = h.cy[pc], zo = (D == 3) ? h.cz[pc] : 0.0;
-                const double xn = xo + readlane_double(g_dx, s);
-                const double yn = yo + readlane_double(g_dy, s);
-                const double zn = (D == 3) ? zo + readlane_double(g_dz, s) : 0.0;
+                double xn = xo + readlane_double(g_dx, s);
+                double yn = yo + readlane_double(g_dy, s);
+                double zn = (D == 3) ? zo + readlane_double(g_dz, s) : 0.0;
+                if (anyimg) settle(__builtin_amdgcn_readfirstlane(p), xn, yn, zn);
                 const bool inside = stays_in_cell<D>(a, h, p, xo, yo, zo, xn, yn, zn, my_shift, my_w);
                 if (inside) {
                     // one wavefront per cell here (teams of NW >= 2 take the batch branch above)
@@ -2970,17 +3057,30 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     }
     PMC_T(t_4);
     if (dirty) {
-        tot.written += (unsigned long long)nc;
+        if (tid == 0) atomicAdd(&st[19], (unsigned long long)nc);
         for (int k = tid; k < nc; k += TS) {
             const int kc = h.ctr + k;
-            int id = a.ids[h.k0 + k];
-            st_agent(a.sx + h.k0 + k, h.cx[kc]);
-            st_agent(a.sy + h.k0 + k, h.cy[kc]);
-            a.pos[(size_t)id * D + 0] = h.cx[kc];
-            a.pos[(size_t)id * D + 1] = h.cy[kc];
-            if (D == 3) {
-                st_agent(a.sz + h.k0 + k, h.cz[kc]);
-                a.pos[(size_t)id * D + 2] = h.cz[kc];
+            const int id = a.ids[h.k0 + k];
+            // the position array through the particle's image: x = xf + k L (k = 0: x = xf, the reference's x + delta).  Folding is
+            // not exact for every x (adding L to a small negative number rounds), so a particle with an image is only written
+            // if it has moved -- its folded coordinates differ from the cell-sorted copy this visit staged; visits of in-box
+            // particles (every visit of a run that started folded) never take that test
+            const double nx = h.cx[kc], ny = h.cy[kc], nz = (D == 3) ? h.cz[kc] : 0.0;
+            const int im = !anyimg ? PMC_IMG_ZERO : ((k < PMC_WAVE && NW == 1) ? myimg : a.simg[h.k0 + k]);
+            bool moved = true;
+            if (im != PMC_IMG_ZERO) {
+                const double ox = ld_agent(a.sx + h.k0 + k), oy = ld_agent(a.sy + h.k0 + k), oz = (D == 3) ? ld_agent(a.sz + h.k0 + k) : 0.0;
+                moved = !(nx == ox && ny == oy && nz == oz);
+            }
+            if (moved) {
+                st_agent(a.sx + h.k0 + k, nx);
+                st_agent(a.sy + h.k0 + k, ny);
+                a.pos[(size_t)id * D + 0] = img_unfold(nx, img_get(im, 0), a.L[0]);
+                a.pos[(size_t)id * D + 1] = img_unfold(ny, img_get(im, 1), a.L[1]);
+                if (D == 3) {
+                    st_agent(a.sz + h.k0 + k, nz);
+                    a.pos[(size_t)id * D + 2] = img_unfold(nz, img_get(im, 2), a.L[2]);
+                }
             }
             if (MULTI) {
                 st_agent(a.ssp + h.k0 + k, h.csp[kc]);
@@ -3018,7 +3118,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
 //    kernel from 84 to 188 VGPRs -- or 128 with scratch spills -- and chunks of tickets let workgroups run ahead by more
 //    than one colour, so cells stall on their neighbours: 1.65 ms against 1.41 ms at N = 10^6.)
 // ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
-template <int D, int KIND, bool MULTI, int NW, bool ONE, int MW = PMC_CB_MINWAVES>   // MW: wavefronts per SIMD it is compiled for
+template <int D, int KIND, bool MULTI, int NW, bool ONE, int MW = PMC_CB_MINWAVES, bool IMG = false>   // MW: wavefronts per SIMD it is compiled for
 __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restrict__ args, int nrep)
 {
     // The arguments of a launch live in DEVICE memory, one CbArgs per replica of the launch (one for a single system,
@@ -3031,6 +3131,7 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     const DevModel *tab = setup_lds<D, MULTI, (NW >= 2 ? NW : 0)>(a0, smem, h);
     const int tid = team_tid<NW>();
     CbTotals tot{};
+    tot.pcnt.count_dense = (NW == 1 && !MULTI);
     if (!ONE) {
         if (tid < 16) h.cnt[tid] = 0;
         if (tid < 8) {
@@ -3065,7 +3166,7 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     }
     const CbArgs &a = args[r];
     unsigned long long *const st = a.stats + (size_t)(aidx & (PMC_NSHARD - 1)) * PMC_NSTATS;   // this workgroup's counter copy
-    cb_visit<D, KIND, MULTI, NW, ONE>(a, h, tab, colour, aidx, st, tot);
+    cb_visit<D, KIND, MULTI, NW, ONE, IMG>(a, h, tab, colour, aidx, st, tot);
     if (tid == 0) {
         if (ONE) {
             if (tot.att1) atomicAdd(&st[0], tot.att1);
@@ -3078,8 +3179,6 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
         }
         if (tot.efix) atomicAdd(&st[16], (unsigned long long)tot.efix);
         if (tot.nnull) atomicAdd(&st[27], tot.nnull);
-        if (tot.loaded) atomicAdd(&st[31], tot.loaded);
-        if (tot.written) atomicAdd(&st[19], tot.written);
 #ifdef PMC_DEBUG_TIME
         for (int q = 0; q < 15; q++) atomicAdd(&st[32 + q], tot.tp[q]);
         atomicAdd(&st[47], tot.tp[15]);
@@ -3089,7 +3188,7 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     if (wave_lane() == 0 && tot.pcnt.tests) {
         atomicAdd(&st[25], (unsigned long long)tot.pcnt.tests);
         atomicAdd(&st[26], (unsigned long long)tot.pcnt.energies);
-        atomicAdd(&st[24], (unsigned long long)tot.pcnt.dense);
+        if (NW == 1 && !MULTI) atomicAdd(&st[24], (unsigned long long)tot.pcnt.dense);
     }
 }
 
@@ -3139,10 +3238,12 @@ __global__ __launch_bounds__(64) void k_delta_e(CbArgs a, int n, const int *__re
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         int i = which[b];
         double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0};
+        const int im = a.img ? a.img[i] : PMC_IMG_ZERO;
 #pragma unroll
         for (int q = 0; q < D; q++) {
-            x[q] = a.pos[(size_t)i * D + q];
-            xn[q] = x[q] + delta[(size_t)b * D + q];
+            // (folded coordinates, as the sweep kernel evaluates a Displacement of particle i: img_fold, img_settle)
+            x[q] = img_fold(a.pos[(size_t)i * D + q], img_get(im, q), a.L[q]);
+            xn[q] = img_settle(x[q] + delta[(size_t)b * D + q], img_get(im, q), a.L[q]);
         }
         int si = a.species[i];
         double ea = stream_energy<D>(a, x[0], x[1], x[2], si, i);

@@ -102,8 +102,13 @@ def test_benchmarked_kernel_instance_against_oracle_at_a_million(gpu):
     assert g.get_counters()[1] == 1000
     liquid = g.position.copy()
     assert st.energy / N < -5.0 and 0.38 < st.accepted[0] / st.attempted[0] < 0.43
+    # hand the state over to both sides afresh: an upload fixes every particle's periodic image (DESIGN.md 2.2 "images"; a few
+    # thousand particles have left the primary box by now), exactly as orc_cb_create does
+    g.position = liquid
+    g.set_counters(sweep=1000)
     cb = O.Checkerboard(liquid, sp, box, 1.0, models, seed=42)
     assert cb.energy_fix == st.energy_fix                       # running energy after 10^9 moves == oracle from scratch
+    assert g.total_energy()[1] == st.energy_fix
     st = pmc.mc_sweep(g, _pool(pmc), nsweeps=1)
     att, acc = cb.sweeps(opool, 1000, 1)
     assert st.accepted[0] == acc[0] and st.energy_fix == cb.energy_fix
@@ -135,6 +140,8 @@ def test_c3_kob_andersen_100k_against_oracle(gpu):
     st = pmc.mc_sweep(g, pool, nsweeps=298)
     p1, s1 = g.position.copy(), g.species.copy()
     assert st.accepted[1] > 1000 and not np.array_equal(s1, sp)
+    g.upload(p1, s1)                                             # both sides take the state over afresh (images, species lists)
+    g.set_counters(sweep=300)
     cb = O.Checkerboard(p1, s1, box, 1.0, models, seed=42)
     assert cb.energy_fix == st.energy_fix
     st = pmc.mc_sweep(g, pool, nsweeps=1)
