@@ -124,6 +124,9 @@ struct pmc_system {
     unsigned char *d_ssp = nullptr;
     int *d_img = nullptr, *d_simg = nullptr;   // persistent packed images (id order; set by pmc_upload) and their cell-sorted copy
     bool any_img = false;        // some particle has a non-zero image (else the kernels get null image pointers and skip all of it)
+    bool img_valid = false;      // the images belong to the current positions: cleared wherever positions change outside the
+                                 // throughput engine (pmc_upload, the per-move verbs, reference-order sweeps, an aborted sweep) -- the
+                                 // same events that invalidate the exact running energy, so a re-fold never meets a valid one
     bool mc_binned = false;      // CSR + SoA consistent with d_pos
     bool count_is_zero = false;  // d_count[0..ncell_mc] is all zero (left so by the last throughput scan)
     unsigned long long *d_stats = nullptr;
@@ -616,19 +619,7 @@ extern "C" int pmc_upload(pmc_system *h, const double *pos, const int32_t *speci
         rc = build_species_list(h, sp0);
         if (rc) return rc;
     }
-    if (h->mc_ok) {
-        // the persistent periodic image of every particle (pmc_kernels.h "images"): fixed here, until the next upload
-        const int nb = (h->N + 255) / 256;
-        int *d_any = reinterpret_cast<int *>(h->d_result);      // (scratch of the per-move verbs: 8 doubles)
-        HIPCHK(h, hipMemsetAsync(d_any, 0, sizeof(int), h->stream));
-        if (h->D == 3) hipLaunchKernelGGL(k_fold_images<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->N, h->p.box[0], h->p.box[1], h->p.box[2], h->d_img, d_any);
-        else hipLaunchKernelGGL(k_fold_images<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->N, h->p.box[0], h->p.box[1], 1.0, h->d_img, d_any);
-        HIPCHK(h, hipGetLastError());
-        int any = 0;
-        HIPCHK(h, hipMemcpyAsync(&any, d_any, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->any_img = any != 0;
-    }
+    h->img_valid = false;      // (re-derived by the next throughput-engine entry: ensure_images)
     h->cells_built = false;
     h->mc_binned = false;
     h->e_fix_valid = false;
@@ -1163,6 +1154,7 @@ static int ref_op_launch(pmc_system *h, RefOp &o)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->mc_binned = false;
     h->e_fix_valid = false;
+    h->img_valid = false;
     return h->list_type >= 2 ? ref_list_errors(h) : PMC_OK;
 }
 
@@ -1259,9 +1251,30 @@ extern "C" int pmc_swap_revert(pmc_system *h, int64_t i, int64_t j, double de)
 
 // ---- throughput engine -----------------------------------------------------------------
 
+// The persistent periodic image of every particle (pmc_kernels.h "images"): k = floor(x / L), derived from the positions
+// the throughput engine takes over -- after an upload, after per-move verbs or reference-order sweeps, after an aborted sweep
+// -- and then kept for as long as the engine's own state (sorted copy, exact running energy) stays valid.
+static int ensure_images(pmc_system *h)
+{
+    if (h->img_valid || !h->mc_ok) return PMC_OK;
+    const int nb = (h->N + 255) / 256;
+    int *d_any = reinterpret_cast<int *>(h->d_result);      // (scratch of the per-move verbs: 8 doubles)
+    HIPCHK(h, hipMemsetAsync(d_any, 0, sizeof(int), h->stream));
+    if (h->D == 3) hipLaunchKernelGGL(k_fold_images<3>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->N, h->p.box[0], h->p.box[1], h->p.box[2], h->d_img, d_any);
+    else hipLaunchKernelGGL(k_fold_images<2>, dim3(nb), dim3(256), 0, h->stream, h->d_pos, h->N, h->p.box[0], h->p.box[1], 1.0, h->d_img, d_any);
+    HIPCHK(h, hipGetLastError());
+    int any = 0;
+    HIPCHK(h, hipMemcpyAsync(&any, d_any, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->any_img = any != 0;
+    h->img_valid = true;
+    return PMC_OK;
+}
+
 static int mc_bin(pmc_system *h, const double shift[3], const SlotGen *slots = nullptr)
 {
     const int N = h->N;
+    if (int ri = ensure_images(h)) return ri;
     const int nb = nblk(N, 256);
     for (int q = 0; q < 3; q++) h->grid.shift[q] = q < h->D ? shift[q] : 0.0;
     SlotGen gen;
@@ -1676,6 +1689,7 @@ static void cb_invalidate(pmc_system *h)
 {
     (void)hipMemsetAsync(h->d_stats, 0, (size_t)PMC_NSHARD * PMC_NSTATS * sizeof(unsigned long long), h->stream);   // every counter copy
     h->e_fix_valid = false;
+    h->img_valid = false;
     h->energy_stale = true;
     h->mc_binned = false;
     h->cells_built = false;
@@ -2048,6 +2062,8 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     if (rc) return rc;
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
+        rc = ensure_images(h);
+        if (rc) return rc;
         if (!h->e_fix_valid) {
             rc = pmc_total_energy(h, nullptr, nullptr);
             if (rc) return rc;

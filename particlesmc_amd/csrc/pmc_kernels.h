@@ -2874,6 +2874,53 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// Two forms of the in-order resolution below.  The second (every lane decides for itself: ~8 instead of ~40 instructions per
+// slot, +3 % for teams of 8) is NOT built by default: with it, the instance <3, SOFT_FLOAT, multi-species, 8 wavefronts, 128-VGPR
+// budget> -- 96 B of scratch per lane -- produced wrong dE (tests/test_gpu_edge.py::test_soft_spheres_odd_exponent; the same source
+// compiled for 168 VGPRs, and every other instance the tests reach, is right).  The third miscompiled-under-spills incident of
+// this kernel: until the team kernels are spill-free, the form that has been soaked since round 2 stays.
+#ifndef PMC_EXP_NEWRESOLVE
+                    // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i
+                    double creg[NW - 1];
+#pragma unroll
+                    for (int i = 0; i < NW - 1; i++) creg[i] = h.cmat[i * NW + jl];
+                    // decisions in slot order; lanes > i accumulate what an accepted slot i does to them
+                    double corr = 0.0;
+                    bool conf = false, stop = false;
+                    int nres = 0;
+                    unsigned accmask = 0;
+#pragma unroll
+                    for (int i = 0; i < NW; i++) {
+                        if (i < K && !stop) {
+                            const double dei = readlane_double(l_de + corr, i);
+                            const bool swapi = (__ballot(l_swap && lane == i) != 0ull);
+                            const bool confi = (__ballot(conf && lane == i) != 0ull);
+                            // a slot that re-selects a moved particle ends the batch and is evaluated again (a swap after accepted
+                            // Displacements of OTHER particles is corrected like a Displacement: c(i,j) above)
+                            if (confi) {
+                                stop = true;
+                            } else {
+                                const bool ini = (__ballot(l_in && lane == i) != 0ull);
+                                const bool oki = ini && (readlane_double(l_tlnu, i) < -dei);
+                                nres = i + 1;
+                                if (oki) {
+                                    accmask |= 1u << i;
+                                    acc1 += 1;
+                                    efix += (long long)(dei * PMC_FIX);
+                                    if (swapi) {
+                                        stop = true;            // later slots saw the old species: next batch
+                                    } else if (i < NW - 1) {
+                                        const int pci = __builtin_amdgcn_readlane(l_pc, i);
+                                        if (lane > i) {
+                                            corr += creg[i < NW - 1 ? i : 0];
+                                            conf = conf || (l_pc == pci) || (l_swap && l_pj == pci);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+#else
                     // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i (none from i >= j)
                     double creg[NW - 1];
 #pragma unroll
@@ -2922,6 +2969,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         efix += (long long)(readlane_double(dsum, 0) * PMC_FIX);
                         acc1 += (unsigned long long)__popc(accmask);
                     }
+#endif
                     att1 += (unsigned long long)nres;
                     if (!ONE && lane < nres) {              // per-move counters of multi-move pools (this wavefront only)
                         atomicAdd(&cnt[l_m], 1);

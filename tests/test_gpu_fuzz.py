@@ -188,12 +188,17 @@ def test_random_operation_sequences(gpu, case):
         for s_ in range(1, S + 1):
             assert np.array_equal(g.species_ids(s_), o.species_ids(s_))
 
+    # The throughput engine derives every particle's periodic image when it takes the state over -- after an upload, per-move
+    # verbs or a reference-order sweep -- and keeps it while its own state stays valid (DESIGN.md 2.2 "images"); the oracle's
+    # Checkerboard fixes the images at its creation, so it lives exactly as long: across consecutive "cb" steps.
+    cb = None
     for step in range(10):
         op = rng.choice(["cb", "seq", "verbs", "temp", "roundtrip"], p=[0.3, 0.25, 0.25, 0.1, 0.1])
         if op == "cb":
             k = int(rng.integers(1, 3))
             _, sweep0 = g.get_counters()
-            cb = O.Checkerboard(o.positions(), o.species(), o.box, T, mo, seed=seed, chain=chain)
+            if cb is None:
+                cb = O.Checkerboard(o.positions(), o.species(), o.box, T, mo, seed=seed, chain=chain)
             st = pmc.mc_sweep(g, pm, nsweeps=k)
             att, acc = cb.sweeps(pool_o, sweep0, k)
             assert np.array_equal(st.attempted[: len(pm)], att) and np.array_equal(st.accepted[: len(pm)], acc)
@@ -204,12 +209,14 @@ def test_random_operation_sequences(gpu, case):
             g.energy[0] = o.energy
             same_state()
         elif op == "seq":
+            cb = None
             step0, _ = g.get_counters()
             st = pmc.mc_sweep(g, pm, nsweeps=1, mode="sequential")
             att, acc = o.mc_steps(pool_o, seed, chain, step0, N)
             assert np.array_equal(st.attempted[: len(pm)], att) and np.array_equal(st.accepted[: len(pm)], acc)
             same_state()
         elif op == "verbs":
+            cb = None
             for _ in range(6):
                 if S > 1 and rng.random() < 0.5:
                     a, b = (int(x) for x in rng.choice(np.arange(1, S + 1), size=2, replace=False))
@@ -238,7 +245,10 @@ def test_random_operation_sequences(gpu, case):
             T = float(rng.uniform(0.6, 1.8))
             g.temperature = T
             o.set_temperature(T)
+            if cb is not None:
+                cb.set_temperature(T)
         else:
+            cb = None
             p_now, s_now = g.position, g.species           # download ... upload: a fresh list on both sides
             g.upload(p_now, s_now)
             o = O.System(p_now, s_now, rho, T, mo, O.LINKEDLIST)
