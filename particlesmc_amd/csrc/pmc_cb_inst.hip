@@ -7,7 +7,7 @@
 
 #ifdef PMC_INST_IMG
 #define PMC_INSTANTIATE_IMG(M, NW, ONE) \
-    template __global__ void k_cb_pass<PMC_INST_D, PMC_INST_KIND, M, NW, ONE, PMC_CB_MINWAVES, true>(const CbArgs *__restrict__ args, int nrep);
+    template __global__ void k_cb_pass<PMC_INST_D, PMC_INST_KIND, M, NW, ONE, PMC_IMG_MW(NW), true>(const CbArgs *__restrict__ args, int nrep);
 PMC_CB_VARIANTS_IMG(PMC_INSTANTIATE_IMG)
 #else
 #define PMC_INSTANTIATE(M, NW, ONE, MW) \

@@ -19,7 +19,7 @@
 #define PMC_DECL_2_4(M_, NW_, ONE_, MW_) extern template __global__ void k_cb_pass<2, 4, M_, NW_, ONE_, MW_>(const CbArgs *__restrict__, int);
 PMC_CB_VARIANTS(PMC_DECL_3_0) PMC_CB_VARIANTS(PMC_DECL_3_1) PMC_CB_VARIANTS(PMC_DECL_3_2) PMC_CB_VARIANTS(PMC_DECL_3_3) PMC_CB_VARIANTS(PMC_DECL_3_4)
 PMC_CB_VARIANTS(PMC_DECL_2_0) PMC_CB_VARIANTS(PMC_DECL_2_1) PMC_CB_VARIANTS(PMC_DECL_2_2) PMC_CB_VARIANTS(PMC_DECL_2_3) PMC_CB_VARIANTS(PMC_DECL_2_4)
-#define PMC_DECLI(DD_, KK_, M_, NW_, ONE_) extern template __global__ void k_cb_pass<DD_, KK_, M_, NW_, ONE_, PMC_CB_MINWAVES, true>(const CbArgs *__restrict__, int);
+#define PMC_DECLI(DD_, KK_, M_, NW_, ONE_) extern template __global__ void k_cb_pass<DD_, KK_, M_, NW_, ONE_, PMC_IMG_MW(NW_), true>(const CbArgs *__restrict__, int);
 #define PMC_DECLI_3_0(M_, NW_, ONE_) PMC_DECLI(3, 0, M_, NW_, ONE_)
 #define PMC_DECLI_3_1(M_, NW_, ONE_) PMC_DECLI(3, 1, M_, NW_, ONE_)
 #define PMC_DECLI_3_2(M_, NW_, ONE_) PMC_DECLI(3, 2, M_, NW_, ONE_)
@@ -494,7 +494,11 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         for (int a = 0; a < h->D; a++) nact *= std::max(1, h->grid.n[a] / 2);
         // End of round 2 (10^8 moves/s in the liquid, teams of 1 / 2 / 4 / 8): 343 cells per colour 1.3 / 1.5 / 2.0 / 2.1; 729:
         // 2.5 / 2.9 / 3.7 / 2.9; 1331: 4.2 / 4.8 / 4.7 / 2.9; 1728: 5.3 / 6.1 / 5.2 / 3.1; 2197: 6.7 / 6.9; 3375: 9.7 / 7.5 / 5.5 / 3.3.
-        h->team = (nact <= 512) ? 8 : ((nact <= 900) ? 4 : ((nact <= 2400) ? 2 : 1));
+        // Round 3: the teams are compiled for three wavefronts per SIMD (PMC_TEAM_MINWAVES: no scratch), i.e. twelve per CU -- one
+        // team of eight, three of four or six of two -- so eight wavefronts per cell only pay while one colour's cells fit the
+        // chip one per CU.  10^8 moves/s in the liquid, teams of 8 / 4 / 2 at that budget: 27 cells per colour 0.181 / 0.165 / 0.119;
+        // 216: 1.32 / 1.26 / 0.91; 512: 1.73 / 2.04 / 1.48; 729: 1.81 / 3.70 / 2.93; 1331: 1.77 / 3.96 / 4.84; 1728: 1.93 / 4.30 / 5.72.
+        h->team = (nact <= 256) ? 8 : ((nact <= 900) ? 4 : ((nact <= 2400) ? 2 : 1));
         // 2-d neighbourhoods hold ~70-100 candidates (two filter trips): N=65536 binary soft spheres (1600 cells per
         // colour) 3.5 / 3.9 / 3.6e8 for teams of 1 / 2 / 4
         if (h->D == 2 && nact > 512) h->team = 2;
@@ -1437,11 +1441,11 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0, int cap = 0)
 // k_cb_pass additionally carries the team size NW (wavefronts per cell)
 // The launch arguments (CbArgs) are read from device memory: `args` below is a device pointer to nrep_ of them.
 #define DISPATCH_CB_ONE(DD, KK, NWV, MWV, h, grid, lds, args)   /* uses pool_ (MovePool), nrep_, mw_ (int) and img_ (bool) of the caller's scope */                                      \
-    if (!done_ && img_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV && MWV == PMC_CB_MINWAVES) {   /* systems with periodic images: one register budget */ \
-        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
-        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
-        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
-        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false, PMC_CB_MINWAVES, true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+    if (!done_ && img_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV && MWV == PMC_IMG_MW(NWV)) {   /* systems with periodic images: one register budget per team width */ \
+        if ((h)->S > 1 && one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, true, PMC_IMG_MW(NWV), true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if ((h)->S > 1) hipLaunchKernelGGL((k_cb_pass<DD, KK, true, NWV, false, PMC_IMG_MW(NWV), true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else if (one_) hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, true, PMC_IMG_MW(NWV), true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
+        else hipLaunchKernelGGL((k_cb_pass<DD, KK, false, NWV, false, PMC_IMG_MW(NWV), true>), dim3(grid), dim3(64 * NWV), lds, (h)->stream, args, nrep_); \
         done_ = true;                                                                                           \
     }                                                                                                           \
     if (!done_ && !img_ && (h)->D == DD && (h)->kind == KK && (h)->team == NWV && mw_ == MWV) {                   \
@@ -1456,13 +1460,13 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0, int cap = 0)
 #define DISPATCH_CB_KIND(DD, KK, h, grid, lds, args)                                                            \
     DISPATCH_CB_ONE(DD, KK, 1, 3, h, grid, lds, args)                                                           \
     DISPATCH_CB_ONE(DD, KK, 1, 4, h, grid, lds, args)                                                           \
-    DISPATCH_CB_ONE(DD, KK, 2, PMC_CB_MINWAVES, h, grid, lds, args)                                             \
-    DISPATCH_CB_ONE(DD, KK, 4, PMC_CB_MINWAVES, h, grid, lds, args)                                             \
-    DISPATCH_CB_ONE(DD, KK, 8, PMC_CB_MINWAVES, h, grid, lds, args)
+    DISPATCH_CB_ONE(DD, KK, 2, PMC_TEAM_MINWAVES, h, grid, lds, args)                                           \
+    DISPATCH_CB_ONE(DD, KK, 4, PMC_TEAM_MINWAVES, h, grid, lds, args)                                           \
+    DISPATCH_CB_ONE(DD, KK, 8, PMC_TEAM_MINWAVES, h, grid, lds, args)
 static int cb_minwaves(const pmc_system *h, size_t lds)
 {
+    if (h->team != 1) return PMC_TEAM_MINWAVES;
     if (const char *e = getenv("PMC_MINWAVES")) return atoi(e) == 3 ? 3 : 4;    // experiments
-    if (h->team != 1) return PMC_CB_MINWAVES;
     return lds * 13 <= 160 * 1024 ? 4 : 3;
 }
 #ifndef PMC_DEV_KIND

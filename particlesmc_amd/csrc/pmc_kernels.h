@@ -17,8 +17,14 @@
 #define PMC_FUSED_STAGE true  // k_cb_pass applies the box filter while staging (stage_compacted)
 #endif
 #ifndef PMC_CB_MINWAVES
-#define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget)
+#define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget): one wavefront per cell
 #endif
+// Teams (NW >= 2 wavefronts per cell) are compiled for THREE wavefronts per SIMD: 168 VGPRs, which all but four of their 160
+// instances fit without scratch (at 128 VGPRs they kept 12 ... 128 B per lane).  Spills are not only slow here: three times
+//  a source change that left every other instance right made ONE spill-heavy instance compute wrong energies --
+// in round 3 twice an instance of eight wavefronts and several species at 96+ B of scratch.  Teams serve small systems
+// (<= 2400 cells per colour), where 12 wavefronts per CU are no constraint once the team width respects it (pmc_create).
+#define PMC_TEAM_MINWAVES 3
 // The kernels that are not templates belong to pmc_hip.hip alone; the translation units that only instantiate k_cb_pass
 // (pmc_cb_inst.hip, compiled in parallel) see them as unused statics.
 #ifdef PMC_INST_ONLY
@@ -29,12 +35,13 @@
 // every k_cb_pass<D, KIND, ...> the host dispatches, for one (D, KIND): X(MULTI, NW, ONE, MW)
 #define PMC_CB_VARIANTS_NW(X, NW, MW) X(false, NW, false, MW) X(false, NW, true, MW) X(true, NW, false, MW) X(true, NW, true, MW)
 #define PMC_CB_VARIANTS(X)                                                                                   \
-    PMC_CB_VARIANTS_NW(X, 1, 3) PMC_CB_VARIANTS_NW(X, 1, 4) PMC_CB_VARIANTS_NW(X, 2, PMC_CB_MINWAVES)         \
-    PMC_CB_VARIANTS_NW(X, 4, PMC_CB_MINWAVES) PMC_CB_VARIANTS_NW(X, 8, PMC_CB_MINWAVES)
-// ... and the instances for systems in which some particle carries a periodic image (IMG = true; compiled for 4 wavefronts per
-// SIMD only): X(MULTI, NW, ONE).  Systems without images -- every run that starts folded -- run the kernels above, whose slot
+    PMC_CB_VARIANTS_NW(X, 1, 3) PMC_CB_VARIANTS_NW(X, 1, 4) PMC_CB_VARIANTS_NW(X, 2, PMC_TEAM_MINWAVES)       \
+    PMC_CB_VARIANTS_NW(X, 4, PMC_TEAM_MINWAVES) PMC_CB_VARIANTS_NW(X, 8, PMC_TEAM_MINWAVES)
+// ... and the instances for systems in which some particle carries a periodic image (IMG = true; one register budget per team
+// width: PMC_IMG_MW): X(MULTI, NW, ONE).  Systems without images -- every run that starts folded -- run the kernels above, whose slot
 // loop does not contain a single instruction of the image path (compiled in, it cost them 1 % through register allocation alone).
 #define PMC_CB_VARIANTS_IMG_NW(X, NW) X(false, NW, false) X(false, NW, true) X(true, NW, false) X(true, NW, true)
+#define PMC_IMG_MW(NW) ((NW) == 1 ? PMC_CB_MINWAVES : PMC_TEAM_MINWAVES)
 #define PMC_CB_VARIANTS_IMG(X) PMC_CB_VARIANTS_IMG_NW(X, 1) PMC_CB_VARIANTS_IMG_NW(X, 2) PMC_CB_VARIANTS_IMG_NW(X, 4) PMC_CB_VARIANTS_IMG_NW(X, 8)
 #define PMC_REF_IDS 2048     // neighbourhood size (ids) the ordered-energy LDS buffer holds (8 KB: 20 wavefronts per CU)
 #define PMC_MAXNN 27
@@ -2874,12 +2881,12 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-// Two forms of the in-order resolution below.  The second (every lane decides for itself: ~8 instead of ~40 instructions per
-// slot, +3 % for teams of 8) is NOT built by default: with it, the instance <3, SOFT_FLOAT, multi-species, 8 wavefronts, 128-VGPR
-// budget> -- 96 B of scratch per lane -- produced wrong dE (tests/test_gpu_edge.py::test_soft_spheres_odd_exponent; the same source
-// compiled for 168 VGPRs, and every other instance the tests reach, is right).  The third miscompiled-under-spills incident of
-// this kernel: until the team kernels are spill-free, the form that has been soaked since round 2 stays.
-#ifndef PMC_EXP_NEWRESOLVE
+// Two forms of the in-order resolution below.  The first is round 2's (cross-lane reads of every operand, ~40 instructions per
+// slot); the second lets every lane decide for itself (~8 per slot, +3 % for teams of 8).  Compiled for 128 VGPRs the second
+// made the instance <3, SOFT_FLOAT, multi-species, 8 wavefronts> -- 96 B of scratch per lane -- compute wrong dE
+// (tests/test_gpu_edge.py::test_soft_spheres_odd_exponent) while every other instance stayed right: the reason the teams are
+// now compiled for 168 VGPRs (PMC_TEAM_MINWAVES), where it and tests/test_gpu_instances.py's whole matrix are green.
+#ifdef PMC_EXP_OLDRESOLVE
                     // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i
                     double creg[NW - 1];
 #pragma unroll

@@ -1,0 +1,79 @@
+"""-m gpu: EVERY instance of the sweep kernel the host can dispatch -- dimension x model kind x {one, several species} x
+team width x {single-Displacement pool, multi-move pool} x {no images, images} -- against the oracle, three sweeps each
+(m = 2, so a pass of two rounds and a pass of one).  The sweep kernel is a template with several hundred instances, many of
+which keep a few dozen bytes of scratch per lane; twice in round 2 and once in round 3 ONE instance computed wrong energies
+after a source change that left every other instance right.  The size-driven tests reach only the instances
+their systems happen to select; this one reaches all of them."""
+import itertools
+
+import numpy as np
+import pytest
+
+from inputs import lj_lattice
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["lj", "soft_int", "soft_odd", "smooth", "mixed"]
+
+
+def _matrix(pmc, O, kind, S):
+    arr = (O.Model * (S * S))()
+    mm = [[None] * S for _ in range(S)]
+    for i in range(S):
+        for j in range(i, S):
+            eps, sig = 1.0 + 0.2 * (i != j), 1.0 - 0.06 * (i + j)
+            rcut = 2.3 * sig
+            k = kind if kind != "mixed" else ["lj", "soft_int", "smooth"][(i + j) % 3]
+            if k == "lj":
+                p, o = pmc.LennardJones(eps, sig, rcut=rcut), O.lennard_jones(eps, sig, rcut)
+            elif k == "soft_int":
+                p, o = pmc.SoftSpheres(eps, sig, 12, rcut=rcut), O.soft_spheres(eps, sig, 12, rcut)
+            elif k == "soft_odd":
+                p, o = pmc.SoftSpheres(eps, sig, 9, rcut=rcut), O.soft_spheres(eps, sig, 9, rcut)
+            else:
+                p, o = pmc.SmoothLennardJones(eps, sig, rcut=rcut), O.smooth_lennard_jones(eps, sig, rcut)
+            mm[i][j] = mm[j][i] = p
+            arr[i * S + j] = arr[j * S + i] = o
+    return mm, (arr, S)
+
+
+@pytest.mark.parametrize("d", [3, 2])
+@pytest.mark.parametrize("kind", KINDS)
+def test_every_kernel_instance_against_the_oracle(gpu, monkeypatch, d, kind):
+    from oracle import oracle as O
+    pmc = gpu
+    n = 12 if d == 3 else 40
+    pos0, sp1, rho = lj_lattice(n, jitter=0.06, seed=11, rho=0.9, d=d)
+    N = len(pos0)
+    L = (N / rho) ** (1.0 / d)
+    rng = np.random.default_rng(5)
+    sp2 = np.where(rng.random(N) < 0.4, 2, 1).astype(np.int32)
+    shift = rng.integers(-2, 3, size=pos0.shape) * L
+    checked = 0
+    for S, team, multi_pool, images in itertools.product((1, 2), ("1", "2", "4", "8"), (False, True), (False, True)):
+        if kind == "mixed" and S == 1:
+            continue                                   # one species has one model: no mixed kinds
+        monkeypatch.setenv("PMC_TEAM", team)
+        sp = sp1 if S == 1 else sp2
+        pos = pos0 + shift if images else pos0
+        mm, mo = _matrix(pmc, O, kind, S)
+        g = pmc.System(pos, sp, rho, 1.1, mm, seed=77)
+        g.rounds = 2
+        pm = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.07}, 1.0)]
+        po = [{"kind": "Displacement", "sigma": 0.07, "probability": 1.0}]
+        if multi_pool:
+            pm.append(pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.3}, 0.3))
+            po.append({"kind": "Displacement", "sigma": 0.3, "probability": 0.3})
+            if S > 1:
+                pm.append(pmc.Move(pmc.DiscreteSwap([1, 2], g), pmc.DoubleUniform(), [], 0.4))
+                po.append({"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.4})
+        cb = O.Checkerboard(pos, sp, np.asarray(g.box), 1.1, mo, seed=77)
+        st = pmc.mc_sweep(g, pm, nsweeps=3)
+        att, acc = cb.sweeps(O.make_pool(po), 0, 3, rounds=2)
+        tag = (d, kind, S, team, multi_pool, images)
+        assert list(st.attempted[: len(pm)]) == list(att) and list(st.accepted[: len(pm)]) == list(acc), tag
+        assert st.energy_fix == cb.energy_fix, tag
+        assert np.array_equal(g.position, cb.positions()) and np.array_equal(g.species, cb.species()), tag
+        assert acc[0] > N // 4, tag
+        checked += 1
+    assert checked == (32 if kind != "mixed" else 16)
