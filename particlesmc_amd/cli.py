@@ -1,7 +1,8 @@
 """`particlesmc params.toml` -- the TOML/CLI surface of src/ParticlesMC.jl:137-299 on the HIP path.
 
-Same keys as the reference; one optional extra key, `[simulation] mode = "checkerboard" |
-"sequential"` (default "checkerboard"), selects the device schedule.
+Same keys as the reference; two optional extra keys: `[simulation] mode = "checkerboard" | "sequential"` (default
+"checkerboard") selects the device schedule, and `[simulation] rounds = m` (default 1; checkerboard only) lets one grid
+shift serve m sweeps (pmc_set_rounds: every cell visit runs m rounds of proposal slots against the neighbourhood it staged).
 """
 import os
 import sys
@@ -35,6 +36,12 @@ def build_simulation(params, base_dir="."):
     mode = sim.get("mode", "checkerboard")
     chains = load_chains(config, args={"temperature": temperature, "density": density, "model": model,
                                        "list_type": list_type, "list_parameters": list_parameters}, seed=seed)
+    rounds = int(sim.get("rounds", 1))
+    if rounds != 1:
+        if mode != "checkerboard":
+            raise ValueError("'rounds' applies to mode = \"checkerboard\" only")
+        for chain in chains:
+            chain.rounds = rounds
     pool = []
     for move in sim["move"]:
         prob, policy, action = move["probability"], move["policy"], move["action"]
