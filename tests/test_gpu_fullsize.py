@@ -343,3 +343,35 @@ def test_fused_launch_equals_colour_launches_under_uneven_load(gpu, monkeypatch,
         out.append((s.position.copy(), int(st.accepted[0]), int(st.energy_fix)))
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
     assert np.array_equal(out[0][0], out[1][0])
+
+
+def test_bench_rccl_exchange_check_with_a_world_of_one(gpu):
+    """bench.py's N > 1 leg (`rccl_exchange_check`: unique id broadcast through torch.distributed, communicator from the
+    library's own entry points, exchange rounds through pmc_replica_exchange_rccl checked against pmc_pt_decide on all-gathered
+    energies) executed with the one rank this box has -- in a child process, over the nccl (= RCCL) backend."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, json\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "import torch, torch.distributed as dist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "import bench, particlesmc_amd as pmc\n"
+        "from particlesmc_amd.workloads import lj_lattice\n"
+        "pos, sp, rho = lj_lattice(12, jitter=0.05, seed=1)\n"
+        "s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=3)\n"
+        "s.total_energy()\n"
+        "print('RESULT', json.dumps(bench.rccl_exchange_check(s, 0, 1, 0, dist, torch)))\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, out.stdout[-2000:]
+    import json
+    r = json.loads(line[0][7:])
+    assert r["n_ranks_rccl"] == 1 and r["decisions_equal_pt_decide"] is True and r["rounds"] == 4

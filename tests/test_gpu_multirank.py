@@ -1,6 +1,6 @@
 """-m gpu: the path's one collective with MORE THAN ONE RANK.  When the box has >= 2 GPUs this starts 2 (and 8 if present)
 fresh processes, one device each, which build an RCCL communicator through the library's own entry points and run 20
-exchange rounds of BASELINE config 5's system through pmc_replica_exchange_rccl; every rank's labels must equal the
+exchange rounds (a world of ONE rank runs everywhere and proves the rank script, the id file and the comparison themselves) of BASELINE config 5's system through pmc_replica_exchange_rccl; every rank's labels must equal the
 oracle's `pt_decide` on the energies all ranks reported.  On a 1-GPU box the test reports itself as NOT RUN (a skip with
 that reason) -- it never passes without having exercised the collective.  (Reference: README.md:33 -- no counterpart;
 replica sharding src/IO/IO.jl:319-327.)"""
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NROUNDS = 20
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [1, 2, 8])
 def test_rccl_replica_exchange_across_ranks(gpu, tmp_path, world):
     from oracle import oracle as O
     ndev = gpu.device_count()
@@ -50,5 +50,5 @@ def test_rccl_replica_exchange_across_ranks(gpu, tmp_path, world):
             got = ranks[r]["rounds"][rnd]
             assert got["label"] == label and got["nacc"] == nacc, (rnd, r, got, label)
             assert got["temperature"] == ladder[label[r]]
-    assert accepted > 0                                              # replicas did exchange temperatures
+    assert accepted > 0 or world == 1                                # replicas did exchange temperatures
     assert not os.path.exists(tmp_path / "rccl_id")                  # rank 0 removed the id file after the join
