@@ -145,6 +145,22 @@ def test_replay_follows_the_reference_constructor_order():
     assert "pmc_set_energy" not in main[:i_sum] and "pmc_init_energy" not in main[:i_first_set]
 
 
+def test_glue_blocks_are_balanced():
+    """No Julia binary parses the file here; at least every block opener has its `end` (comments and strings stripped,
+    the `for` of a comprehension -- inside brackets -- does not open a block)."""
+    depth = 0
+    for n, line in enumerate(open(JL).read().split("\n"), 1):
+        code = re.sub(r'"[^"\n]*"', '""', line.split("#")[0])
+        flat, prev = code, None
+        while flat != prev:                                            # drop bracketed text, innermost first (comprehensions)
+            prev, flat = flat, re.sub(r"\[[^\[\]]*\]", "", flat)
+        opens = re.findall(r"(?<![\w.!:])(function|struct|if|for|begin|module|while|try|let|do)(?![\w!])", flat)
+        ends = re.findall(r"(?<![\w.!:])end(?![\w!])", flat)
+        depth += len(opens) - len(ends)
+        assert depth >= 0, (n, line)
+    assert depth == 0
+
+
 def test_glue_declares_an_abstract_rng_over_the_sequential_words():
     txt = open(JL).read()
     assert "struct SequentialWords <: Random.AbstractRNG" in txt and ":pmc_sequential_words" in txt
