@@ -1467,7 +1467,12 @@ static int cb_minwaves(const pmc_system *h, size_t lds)
 {
     if (h->team != 1) return PMC_TEAM_MINWAVES;
     if (const char *e = getenv("PMC_MINWAVES")) return atoi(e) == 3 ? 3 : 4;    // experiments
-    return lds * 13 <= 160 * 1024 ? 4 : 3;
+    // The 128-VGPR instances of multi-species / non-LJ systems keep 12 ... 72 B of scratch per lane, the 168-VGPR ones none: for
+    // them a 13th or 14th workgroup per CU does not pay for the spills (Kob-Andersen N = 10^6, LDS good for 13 workgroups per CU:
+    // 7.30 -> 7.74e8 moves/s with swaps, 8.28 -> 8.58e8 without, by taking the 12 of the larger budget); the LJ single-species
+    // instance fits 127 VGPRs without scratch and takes the smaller budget from 13 workgroups on
+    const size_t need = (h->S > 1 || h->kind != 0) ? 15 : 13;
+    return lds * need <= 160 * 1024 ? 4 : 3;
 }
 #ifndef PMC_DEV_KIND
 #define PMC_DEV_KIND 0

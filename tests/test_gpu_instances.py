@@ -1,5 +1,5 @@
 """-m gpu: EVERY instance of the sweep kernel the host can dispatch -- dimension x model kind x {one, several species} x
-team width x {single-Displacement pool, multi-move pool} x {no images, images} -- against the oracle, three sweeps each
+team width (and both register budgets of the one-wavefront kernels) x {single-Displacement pool, multi-move pool} x {no images, images} -- against the oracle, three sweeps each
 (m = 2, so a pass of two rounds and a pass of one).  The sweep kernel is a template with several hundred instances, many of
 which keep a few dozen bytes of scratch per lane; twice in round 2 and once in round 3 ONE instance computed wrong energies
 after a source change that left every other instance right.  The size-driven tests reach only the instances
@@ -50,10 +50,18 @@ def test_every_kernel_instance_against_the_oracle(gpu, monkeypatch, d, kind):
     sp2 = np.where(rng.random(N) < 0.4, 2, 1).astype(np.int32)
     shift = rng.integers(-2, 3, size=pos0.shape) * L
     checked = 0
-    for S, team, multi_pool, images in itertools.product((1, 2), ("1", "2", "4", "8"), (False, True), (False, True)):
+    # team "1/3": one wavefront per cell in its 168-VGPR build (the host takes it when LDS leaves room for <= 12-14 workgroups
+    # per CU, i.e. for large dense systems; forced here through PMC_MINWAVES)
+    for S, team, multi_pool, images in itertools.product((1, 2), ("1", "1/3", "2", "4", "8"), (False, True), (False, True)):
         if kind == "mixed" and S == 1:
             continue                                   # one species has one model: no mixed kinds
-        monkeypatch.setenv("PMC_TEAM", team)
+        if team == "1/3" and images:
+            continue                                   # (the image instances exist in one register budget per team width)
+        monkeypatch.setenv("PMC_TEAM", team.split("/")[0])
+        if team == "1/3":
+            monkeypatch.setenv("PMC_MINWAVES", "3")
+        else:
+            monkeypatch.delenv("PMC_MINWAVES", raising=False)
         sp = sp1 if S == 1 else sp2
         pos = pos0 + shift if images else pos0
         mm, mo = _matrix(pmc, O, kind, S)
@@ -76,4 +84,4 @@ def test_every_kernel_instance_against_the_oracle(gpu, monkeypatch, d, kind):
         assert np.array_equal(g.position, cb.positions()) and np.array_equal(g.species, cb.species()), tag
         assert acc[0] > N // 4, tag
         checked += 1
-    assert checked == (32 if kind != "mixed" else 16)
+    assert checked == (36 if kind != "mixed" else 18)
