@@ -395,3 +395,40 @@ def test_oracle_reproduces_the_references_published_mixture_results(O, row_index
     assert abs(acc[0] / att[0] - row["acceptance_rate_displacement"]) < 0.02
     assert abs(acc[1] / att[1] - row["acceptance_rate_swap"]) < 0.04
     assert abs(att[1] / att.sum() - 0.1) < 0.01
+
+
+def test_checkerboard_rounds_and_periodic_images_keep_the_books_exact(O):
+    """The schedule parameter m (passes of m sweeps under one grid shift) and the persistent periodic images of the
+    restatement: the running energy equals a recomputation bit for bit for inputs in the box, shifted by a
+    few boxes, hundreds of boxes, and beyond the 511-box limit of the fold; calls aligned to passes compose; m = 1 is the
+    plain schedule; and a configuration shifted by whole boxes accepts what the in-box one accepts (its folded coordinates
+    differ from it by rounding only)."""
+    from inputs import lj_lattice
+    pos, sp, rho = lj_lattice(12, jitter=0.05, seed=5)
+    N = len(pos)
+    L = (N / rho) ** (1.0 / 3.0)
+    box = np.array([L] * 3)
+    models = O.single(O.lennard_jones(1.0, 1.0))
+    pool = O.make_pool([{"kind": "Displacement", "sigma": 0.08}])
+    accepted = {}
+    for name, span in (("inbox", 0), ("near", 3), ("far", 400), ("beyond", 100000)):
+        p = pos + (np.random.default_rng(7).integers(-span, span + 1, size=pos.shape) * L if span else 0.0)
+        cb = O.Checkerboard(p, sp, box, 1.0, models, seed=3)
+        att, acc = cb.sweeps(pool, 0, 12, rounds=4)
+        assert att[0] == 12 * N and cb.energy_fix == cb.total_energy_fix(), name
+        assert np.abs(cb.positions() - p).max() < 1.5, name            # nobody changed image
+        accepted[name] = int(acc[0])
+        # calls aligned to passes compose: 8 + 4 sweeps at m = 4 == 12 sweeps at m = 4
+        cb2 = O.Checkerboard(p, sp, box, 1.0, models, seed=3)
+        cb2.sweeps(pool, 0, 8, rounds=4)
+        cb2.sweeps(pool, 8, 4, rounds=4)
+        assert np.array_equal(cb2.positions(), cb.positions()) and cb2.energy_fix == cb.energy_fix, name
+    assert abs(accepted["near"] - accepted["inbox"]) <= 3 and abs(accepted["far"] - accepted["inbox"]) <= 3, accepted
+    a = O.Checkerboard(pos, sp, box, 1.0, models, seed=3)
+    b = O.Checkerboard(pos, sp, box, 1.0, models, seed=3)
+    a.sweeps(pool, 0, 5)
+    b.sweeps(pool, 0, 5, rounds=1)
+    assert np.array_equal(a.positions(), b.positions()) and a.energy_fix == b.energy_fix
+    c = O.Checkerboard(pos, sp, box, 1.0, models, seed=3)
+    c.sweeps(pool, 0, 5, rounds=2)
+    assert not np.array_equal(a.positions(), c.positions())             # m = 2 is a different (equally valid) chain
