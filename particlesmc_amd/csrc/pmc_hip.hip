@@ -1330,7 +1330,10 @@ static int cb_cap(const pmc_system *h);
 static bool cb_fuse_teams(const pmc_system *h)
 {
     if (const char *e = getenv("PMC_FUSE_TEAMS")) return e[0] == '1';      // experiments
-    if (!h->mc_ok || !h->use_filter || h->D != 3 || h->S < 2) return false;      // (compiled into the multi-species kernels only)
+#ifndef PMC_EXP_FUSE_ALL
+    if (h->S < 2) return false;      // (compiled into the multi-species kernels only)
+#endif
+    if (!h->mc_ok || !h->use_filter || h->D != 3) return false;
     return 3.0 * (double)h->N / (double)h->ncell_mc > 62.0;
 }
 

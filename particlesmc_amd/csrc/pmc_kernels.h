@@ -2679,7 +2679,11 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     // teams take the fused staging only in the multi-species instances, and there only where a.fuse_teams says so (dense
     // systems: see pmc_hip.hip, cb_fuse_teams); compiling it into the single-species team kernels as well cost them 20 KB of
     // code and 16-20 B more scratch per lane for a path their systems never take
+#ifdef PMC_EXP_FUSE_ALL       // experiments: the fused staging compiled into the single-species team kernels too
+    constexpr bool FUSE = PMC_FUSED_STAGE;
+#else
     constexpr bool FUSE = PMC_FUSED_STAGE && (NW == 1 || MULTI);
+#endif
     stage_neighbourhood<D, MULTI, NW, FUSE>(a, cell, h, a.fused ? colour : 0);
     PMC_T(t_2);
 #if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 2
