@@ -375,3 +375,53 @@ def test_bench_rccl_exchange_check_with_a_world_of_one(gpu):
     import json
     r = json.loads(line[0][7:])
     assert r["n_ranks_rccl"] == 1 and r["decisions_equal_pt_decide"] is True and r["rounds"] == 4
+
+
+def test_cli_rounds_key(gpu, tmp_path):
+    """`[simulation] rounds = m` (the one schedule key the HIP path adds to the reference's TOML surface): the chains run with m
+    sweeps per grid shift, the outputs keep the reference's layout, and the trace is that of `mc_sweep_many` called with the same
+    gaps on a system with `rounds = m` (a pass never spans calls)."""
+    import shutil
+    from particlesmc_amd import cli
+    shutil.copy(os.path.join(GOLD, "config_0.xyz"), tmp_path / "config_0.xyz")
+    toml = """
+[system]
+config = "config_0.xyz"
+temperature = 0.231
+density = 1.192060351952634
+model = "JBB"
+list_type = "LinkedList"
+
+[simulation]
+type = "Metropolis"
+steps = 24
+seed = 10
+parallel = false
+rounds = 4
+output_path = "out"
+
+[[simulation.move]]
+action = "Displacement"
+probability = 1.0
+policy = "SimpleGaussian"
+parameters = {sigma = 0.05}
+
+[[simulation.output]]
+algorithm = "StoreCallbacks"
+callbacks = ["energy"]
+scheduler_params = {linear_interval = 8}
+"""
+    (tmp_path / "params.toml").write_text(toml)
+    sim = cli.particlesmc(str(tmp_path / "params.toml"))
+    assert sim.chains[0].rounds == 4
+    en = np.loadtxt(tmp_path / "out" / "chains" / "1" / "energy.dat")
+    assert list(en[:, 0]) == [0, 8, 16, 24] and abs(en[0, 1] - (-2.676832)) < 1e-6
+    # the same run by hand: gaps of 8 sweeps = two passes of four
+    (tmp_path / "params1.toml").write_text(toml.replace("rounds = 4", "rounds = 1").replace('"out"', '"out1"'))
+    sim1 = cli.particlesmc(str(tmp_path / "params1.toml"))
+    en1 = np.loadtxt(tmp_path / "out1" / "chains" / "1" / "energy.dat")
+    assert en1[0, 1] == en[0, 1] and not np.array_equal(en1[1:, 1], en[1:, 1])       # a different (equally valid) chain
+    assert np.all(np.abs(en[:, 1] + 2.67) < 0.05) and sim1.chains[0].rounds == 1
+    with pytest.raises(ValueError):
+        (tmp_path / "params2.toml").write_text(toml.replace('parallel = false', 'parallel = false\nmode = "sequential"'))
+        cli.particlesmc(str(tmp_path / "params2.toml"))
