@@ -258,7 +258,8 @@ def roofline_objects(N, steps, st, avg_launch_s, moves_per_launch, ncell_ref):
 
 
 def move_efficiency(pmc, rounds_list):
-    """What an attempted move of the checkerboard schedule is worth in attempted moves of the reference's sequential chain
+    """Second half of the CPU-baseline leg (rank 0, N = 1, skipped with --no-cpu; like `cpu_baseline` it runs the oracle's
+    sequential chain on host cores, as the yardstick, never as the thing measured): what an attempted move of the checkerboard schedule is worth in attempted moves of the reference's sequential chain
     (src/moves.jl:57-81): mean-square displacement per attempted move, checkerboard (device) over sequential (oracle), on an
     N = 4096 liquid at the benchmark's state point and cell width (6 cells of 2.667).  A bounded sample: 16 chains of 500
     sweeps per leg (about 20 s of CPU on 16 host cores).  The integrated autocorrelation time of e/N needs ~100x the CPU
