@@ -19,6 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
+RHO = 0.5      # test/ss142d.jl:16
+
 
 def make_system(pmc, n, rho, T, seed, chain, device):
     N = n * n
@@ -38,6 +40,7 @@ def main():
     ap.add_argument("--side", type=int, default=256, help="N = side^2 particles per replica")
     ap.add_argument("--sweeps", type=int, default=400)
     ap.add_argument("--exchange-every", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=1, help="schedule parameter m (pmc_set_rounds); exchange-every should be a multiple of it")
     ap.add_argument("--local", type=int, default=0, help="run this many replicas in one process on one GPU")
     ap.add_argument("--rccl", action="store_true",
                     help="one replica per rank: exchange through the library's own RCCL entry point (pmc_replica_exchange_rccl, "
@@ -57,7 +60,9 @@ def main():
             # (8 replicas: 6.1e8 moves/s with teams of 2 against 4.8e8 with the single-chain default of 4)
             os.environ.setdefault("PMC_TEAM", "2")
         ladder = np.geomspace(args.tmin, args.tmax, n)
-        systems = [make_system(pmc, args.side, 0.8, ladder[r], 5, r, 0) for r in range(n)]
+        systems = [make_system(pmc, args.side, RHO, ladder[r], 5, r, 0) for r in range(n)]
+        for s_ in systems:
+            s_.rounds = args.rounds
         t0 = time.perf_counter()
         label, acc, att, traces = tempering.run_tempering_local(systems, pool, ladder, args.sweeps, args.exchange_every, seed=9)
         dt = time.perf_counter() - t0
@@ -76,7 +81,8 @@ def main():
     dev = local_rank % max(1, ndev)
     tdev = f"cuda:{dev}" if (dist is not None and ndev >= world) else "cpu"
     ladder = np.geomspace(args.tmin, args.tmax, world)
-    system = make_system(pmc, args.side, 0.8, ladder[rank], 5, rank, dev)
+    system = make_system(pmc, args.side, RHO, ladder[rank], 5, rank, dev)
+    system.rounds = args.rounds
     comm = tempering.rccl_comm_from_env(dev) if args.rccl else None
     t0 = time.perf_counter()
     rex, trace = tempering.run_tempering(system, pool, ladder, args.sweeps, args.exchange_every, seed=9, rank=rank,
