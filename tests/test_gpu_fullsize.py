@@ -296,6 +296,34 @@ def test_bench_line_contract(gpu):
     assert 0.8 < me["value"] < 1.05 and me["value"] == me["by_rounds"]["4"]["msd_ratio"]
 
 
+def test_bench_two_ranks_sharing_the_device(gpu):
+    """`bench.py --gpus 2` started plainly launches its own two ranks (children, before anything touches the GPU).  On a
+    one-GPU box `--share-devices` lets both use device 0 (gloo for the barriers: RCCL refuses two ranks on one device),
+    which runs the multi-rank flow of the script on real HIP: one chain per rank, barriers, MAX over ranks, the whole-job
+    value = 2 N steps / that time, the exactness property reduced over both ranks.  Without the flag it must refuse."""
+    import json
+    import subprocess
+    import sys
+    if gpu.device_count() >= 2:
+        pytest.skip("NOT RUN: this is the one-GPU functional leg; with >= 2 devices the driver's --gpus N run covers it")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--lattice", "24",
+           "--long-steps", "16", "--equilibrate", "20", "--no-cpu"]
+    refused = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert refused.returncode != 0 and b"one rank per GPU" in refused.stderr
+    out = subprocess.run(cmd + ["--share-devices"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().split("\n") if l.startswith('{"metric"')]
+    assert len(line) == 1                                            # rank 0 only
+    d = json.loads(line[0])
+    N = 24 ** 3
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["backend"] == "gloo" and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * N * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
+    assert d["running_energy_equals_recomputed"] is True and d["cpu_baseline"] is None
+    assert "n_ranks_rccl" not in d                                   # the collective needs one device per rank: not claimed here
+    assert set(d["by_rounds"]) == {"1", "2", "4"} and d["long_run"]["steps"] == 16
+
+
 def test_long_run_bookkeeping_is_exact(gpu):
     """20 000 sweeps of the N = 32768 system (6.5 * 10^8 attempted moves): the running energy still
     equals a recomputation bit for bit, the chain has equilibrated to the liquid (energy below the
