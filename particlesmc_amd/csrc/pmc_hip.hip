@@ -1737,6 +1737,17 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
         rc = pmc_total_energy(h, nullptr, nullptr);
         if (rc) return rc;
     }
+#ifdef PMC_DEBUG_SLOTLOG
+    if (getenv("PMC_SLOTLOG")) {
+        double *d = nullptr;
+        HIPCHK(h, hipMemcpyFromSymbol(&d, HIP_SYMBOL(g_slotlog), sizeof(d)));
+        if (!d) {
+            HIPCHK(h, hipMalloc(&d, (size_t)8 * h->slot_rounds * h->N * sizeof(double)));
+            HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_slotlog), &d, sizeof(d)));
+        }
+        HIPCHK(h, hipMemset(d, 0, (size_t)8 * h->slot_rounds * h->N * sizeof(double)));
+    }
+#endif
     for (int m = 0; m < npool; m++) {
         if (pool[m].kind == PMC_MOVE_SWAP && h->S < 2)
             return fail(h, PMC_ERR_BADARG, "DiscreteSwap needs at least two species");
@@ -1905,6 +1916,17 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
 static int cb_finish(pmc_system *h, pmc_stats *out)
 {
     HIPCHK(h, hipStreamSynchronize(h->stream));
+#ifdef PMC_DEBUG_SLOTLOG
+    if (const char *path = getenv("PMC_SLOTLOG")) {
+        double *d = nullptr;
+        HIPCHK(h, hipMemcpyFromSymbol(&d, HIP_SYMBOL(g_slotlog), sizeof(d)));
+        if (d) {
+            std::vector<double> buf((size_t)8 * h->slot_rounds * h->N);
+            HIPCHK(h, hipMemcpy(buf.data(), d, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(path, "wb")) { fwrite(buf.data(), sizeof(double), buf.size(), f); fclose(f); }
+        }
+    }
+#endif
     h->pending = false;
     const unsigned long long *st = h->h_stats;
     const int64_t nsweeps = h->pending_nsweeps, timed_sweeps = h->pending_timed;

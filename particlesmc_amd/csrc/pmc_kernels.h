@@ -19,12 +19,15 @@
 #ifndef PMC_CB_MINWAVES
 #define PMC_CB_MINWAVES 4     // waves per SIMD k_cb_pass is compiled for (register budget): one wavefront per cell
 #endif
-// Teams (NW >= 2 wavefronts per cell) are compiled for THREE wavefronts per SIMD: 168 VGPRs, which all but four of their 160
-// instances fit without scratch (at 128 VGPRs they kept 12 ... 128 B per lane).  Spills are not only slow here: three times
-//  a source change that left every other instance right made ONE spill-heavy instance compute wrong energies --
-// in round 3 twice an instance of eight wavefronts and several species at 96+ B of scratch.  Teams serve small systems
-// (<= 2400 cells per colour), where 12 wavefronts per CU are no constraint once the team width respects it (pmc_create).
+// Teams (NW >= 2 wavefronts per cell) are compiled for THREE wavefronts per SIMD: 168 VGPRs, which all but a handful of their
+// 160 instances fit without scratch (at 128 VGPRs they keep 12 ... 128 B per lane).  Teams serve small systems (<= 2400 cells
+// per colour), where 12 wavefronts per CU are no constraint once the team width respects it (pmc_create); measured against
+// the 128-VGPR build at the end of round 3: -1 ... +5 % either way, row by row.  (The "one instance wrong under scratch"
+// incidents of rounds 2-3 that first motivated this were a bug of this file, not of the register budget: DESIGN.md 4.6.
+// -DPMC_TEAM_MINWAVES=4 builds the teams for 128 VGPRs; the whole instance matrix is green with it.)
+#ifndef PMC_TEAM_MINWAVES
 #define PMC_TEAM_MINWAVES 3
+#endif
 // The kernels that are not templates belong to pmc_hip.hip alone; the translation units that only instantiate k_cb_pass
 // (pmc_cb_inst.hip, compiled in parallel) see them as unused statics.
 #ifdef PMC_INST_ONLY
@@ -1684,12 +1687,15 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
 #ifdef PMC_DEBUG_TIME
     h.ts[2] = h.ts[3] = __builtin_amdgcn_s_memtime();
 #endif
-    if (NW >= 4 && a.slot_tlnu && !a.all_cells) {
-        // small systems: a cell visit is one dependent chain, so the slot values ride along with the coordinate loads
-        const int t = lane;
+    if (NW >= 4) {
+        // (defined on every path: cb_visit reads them whenever NW >= 4)
         h.p_tlnu = h.p_dx = h.p_dy = h.p_dz = 0.0;
         h.p_w1 = h.p_w2 = 0u;
         h.p_m = 0;
+    }
+    if (NW >= 4 && a.slot_tlnu && !a.all_cells) {
+        // small systems: a cell visit is one dependent chain, so the slot values ride along with the coordinate loads
+        const int t = lane;
         if (t < h.nc * a.rounds) {
             const int ks = a.rounds * h.k0 + t;
             h.p_m = (int)a.slot_m[ks];
@@ -2148,6 +2154,10 @@ __device__ __forceinline__ void update_fregs(FRegs &f, int pc, float fx, float f
         if (D == 3) f.z[j] = mine ? fz : f.z[j];
     }
 }
+
+#ifdef PMC_DEBUG_SLOTLOG   // development builds only (single translation unit): what a team's resolution decided, slot by slot
+__device__ double *g_slotlog = nullptr;
+#endif
 
 struct PairCount {
     unsigned tests, energies;     // per wavefront: FP32 distance tests, in-range pair energies evaluated
@@ -2787,6 +2797,10 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     const int my = __builtin_amdgcn_readfirstlane(s0 + wv);
                     const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)g_w1, my);
                     const int mm_ = ONE ? 0 : __builtin_amdgcn_readlane(g_m, my);
+                    // (read here, with every lane active.  It used to be read inside `if (lane == 0)` below: a cross-lane read of
+                    // a lane that is inactive at that point is undefined -- it works while the value sits in a register, and returned
+                    // 0 once the compiler reloaded a spilled g_tlnu inside that branch, i.e. for lane 0 only: DESIGN.md 4.6)
+                    const double tlnu_my = readlane_double(g_tlnu, my);
                     if (MULTI && !ONE && h.ptab[mm_] != 0) {
                         // DiscreteSwap slot: both particles and the fused four-energy difference by this wavefront alone
                         const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)g_w2, my);
@@ -2806,7 +2820,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                             r[0] = h.cx[pi]; r[1] = h.cy[pi]; r[2] = (D == 3) ? h.cz[pi] : 0.0;
                             r[3] = h.cx[pj]; r[4] = h.cy[pj]; r[5] = (D == 3) ? h.cz[pj] : 0.0;
                             r[6] = de;
-                            r[7] = readlane_double(g_tlnu, my);
+                            r[7] = tlnu_my;
                             r[8] = (double)pi;
                             r[9] = valid ? 1.0 : 0.0;
                             r[10] = (double)pj;
@@ -2831,7 +2845,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         r[0] = xo; r[1] = yo; r[2] = zo;
                         r[3] = xn; r[4] = yn; r[5] = zn;
                         r[6] = de;
-                        r[7] = readlane_double(g_tlnu, my);
+                        r[7] = tlnu_my;
                         r[8] = (double)pc;
                         r[9] = inside ? 1.0 : 0.0;
                         r[10] = -1.0;
@@ -2902,10 +2916,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 // Two forms of the in-order resolution below.  The first is round 2's (cross-lane reads of every operand, ~40 instructions per
-// slot); the second lets every lane decide for itself (~8 per slot, +3 % for teams of 8).  Compiled for 128 VGPRs the second
-// made the instance <3, SOFT_FLOAT, multi-species, 8 wavefronts> -- 96 B of scratch per lane -- compute wrong dE
-// (tests/test_gpu_edge.py::test_soft_spheres_odd_exponent) while every other instance stayed right: the reason the teams are
-// now compiled for 168 VGPRs (PMC_TEAM_MINWAVES), where it and tests/test_gpu_instances.py's whole matrix are green.
+// slot); the second lets every lane decide for itself (~8 per slot, +3 % for teams of 8).
 #ifdef PMC_EXP_OLDRESOLVE
                     // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i
                     double creg[NW - 1];
@@ -2998,6 +3009,13 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     }
 #endif
                     att1 += (unsigned long long)nres;
+#ifdef PMC_DEBUG_SLOTLOG
+                    if (g_slotlog && lane < nres) {
+                        double *q = g_slotlog + 8 * (size_t)(a.rounds * h.k0 + chunk + s0 + lane);
+                        q[0] = l_de; q[1] = corr; q[2] = l_tlnu; q[3] = (double)l_pc; q[4] = l_in ? 1.0 : 0.0;
+                        q[5] = (double)((accmask >> lane) & 1u); q[6] = rl[0]; q[7] = rl[3];
+                    }
+#endif
                     if (!ONE && lane < nres) {              // per-move counters of multi-move pools (this wavefront only)
                         atomicAdd(&cnt[l_m], 1);
                         if ((accmask >> lane) & 1u) atomicAdd(&cnt[8 + l_m], 1);
@@ -3199,7 +3217,8 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     // The arguments of a launch live in DEVICE memory, one CbArgs per replica of the launch (one for a single system,
     // n for pmc_sweep_many), written once per call for all its sweeps.  They are only ever read through references:
     // a by-value CbArgs that is modified -- or handed to a function the compiler declines to inline -- is copied to
-    // scratch, and both times that happened (r02) the kernel produced wrong energies.
+    // scratch, and both times that happened (r02) the kernel produced wrong energies (the copy put more values into scratch,
+    // and a spilled value was then read across lanes inside a lane-0 branch: the bug found in round 3).
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;
     const CbArgs &a0 = args[0];                      // the shape (grid, models, pool, capacities) is common to all replicas

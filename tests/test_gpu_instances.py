@@ -1,9 +1,10 @@
 """-m gpu: EVERY instance of the sweep kernel the host can dispatch -- dimension x model kind x {one, several species} x
 team width (and both register budgets of the one-wavefront kernels) x {single-Displacement pool, multi-move pool} x {no images, images} -- against the oracle, three sweeps each
 (m = 2, so a pass of two rounds and a pass of one).  The sweep kernel is a template with several hundred instances, many of
-which keep a few dozen bytes of scratch per lane; twice in round 2 and once in round 3 ONE instance computed wrong energies
-after a source change that left every other instance right.  The size-driven tests reach only the instances
-their systems happen to select; this one reaches all of them."""
+which keep a few dozen bytes of scratch per lane; twice in round 2 and twice in round 3 ONE instance computed wrong energies
+after a source change that left every other instance right (a cross-lane read of an inactive lane, harmless
+until the operand is spilled -- fixed, and guarded at source level by tests/test_source_lint.py).  The size-driven tests reach
+only the instances their systems happen to select; this one reaches all of them."""
 import itertools
 
 import numpy as np
