@@ -292,30 +292,65 @@ def move_efficiency(pmc, rounds_list):
     return out
 
 
-def rccl_exchange_check(system, rank, world, dev_index, dist, torch, rounds=4):
-    """The path's one collective on the ranks of this job: a communicator built by the library's own entry points
-    (pmc_rccl_unique_id -> ranks -> pmc_rccl_comm_create) and `rounds` exchange rounds through pmc_replica_exchange_rccl
-    (ncclAllGather of one double per rank); every rank's labels must equal pmc_pt_decide on the gathered energies."""
+def rccl_exchange_check(rank, world, dev_index, dist, rounds=4, timeout=150.0):
+    """The path's one collective on the ranks of this job, each rank in a CHILD process of its own
+    (`python -m particlesmc_amd.rccl_check`): config 5's system on the rank's device, a communicator built by the library's own
+    entry points (pmc_rccl_unique_id -> file -> pmc_rccl_comm_create), `rounds` rounds of sweeps + pmc_replica_exchange_rccl
+    (ncclAllGather of one double per rank).  Rank 0 then checks every rank's labels against pmc_pt_decide on the energies all
+    ranks reported.  A child, because nothing that happens inside a communicator that has never run on this node -- a hang, a
+    crash -- may cost the bench line: a rank that does not finish within `timeout` seconds is killed and reported."""
+    import shutil
+    import tempfile
     from particlesmc_amd import tempering
-    uid = [tempering.RcclComm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    comm = tempering.RcclComm(uid[0], rank, world, dev_index)
-    ladder = np.geomspace(1.0, 1.0 + 0.002 * world, world)
-    label = np.arange(world, dtype=np.int32)
-    ok, acc = True, 0
+    box = [tempfile.mkdtemp(prefix="pmc_bench_rccl_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    outdir = box[0]
+    env = dict(os.environ)
+    for k in list(env):
+        if k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT") or k.startswith("TORCHELASTIC"):
+            env.pop(k)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.dirname(os.path.abspath(__file__))
+    err = None
     try:
-        for rnd in range(rounds):
-            e = torch.tensor([system.energy[0]], dtype=torch.float64, device=f"cuda:{dev_index}")
-            es = [torch.zeros_like(e) for _ in range(world)]
-            dist.all_gather(es, e)
-            want, wacc = tempering.pt_decide(77, rnd, [float(t.item()) for t in es], ladder, label)
-            label, nacc = comm.exchange(system, ladder, 77, rnd, label)
-            ok = ok and list(label) == list(want) and nacc == wacc and system.temperature == float(ladder[label[rank]])
-            acc += nacc
-    finally:
-        comm.close()
-    system.temperature = TEMPERATURE
-    return {"n_ranks_rccl": world, "rounds": rounds, "decisions_equal_pt_decide": bool(ok), "accepted": int(acc)}
+        p = subprocess.Popen([sys.executable, "-m", "particlesmc_amd.rccl_check", str(rank), str(world), str(dev_index), outdir, str(rounds)],
+                             cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        try:
+            out = p.communicate(timeout=timeout)[0].decode(errors="replace")
+            if p.returncode != 0:
+                err = f"rank {rank}: exit code {p.returncode}: {out[-400:]}"
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            err = f"rank {rank}: pmc_replica_exchange_rccl did not finish within {timeout:.0f} s"
+    except Exception as exc:
+        err = f"rank {rank}: {exc!r}"
+    errs = [None] * world
+    dist.all_gather_object(errs, err)                     # also the barrier: every rank's file is written (or its error known)
+    res = None
+    if rank == 0:
+        errs = [e for e in errs if e]
+        if errs:
+            res = {"n_ranks_rccl": 0, "error": "; ".join(errs)[:1500]}
+        else:
+            try:
+                ranks = [json.load(open(os.path.join(outdir, f"rank{r}.json"))) for r in range(world)]
+                ladder = ranks[0]["ladder"]
+                label, ok, acc = list(range(world)), True, 0
+                for rnd in range(rounds):
+                    energies = [ranks[r]["rounds"][rnd]["energy"] for r in range(world)]
+                    label, nacc = tempering.pt_decide(9, rnd, energies, ladder, label)
+                    label = [int(v) for v in label]
+                    acc += int(nacc)
+                    for r in range(world):
+                        got = ranks[r]["rounds"][rnd]
+                        ok = ok and got["label"] == label and got["nacc"] == int(nacc) and got["temperature"] == ladder[label[r]]
+                res = {"n_ranks_rccl": world, "rounds": rounds, "decisions_equal_pt_decide": bool(ok), "accepted": acc,
+                       "system": "config 5: 2-D binary r^-14 soft spheres, N = 4096 per rank, 5 sweeps per round"}
+            except Exception as exc:
+                res = {"n_ranks_rccl": 0, "error": repr(exc)}
+        shutil.rmtree(outdir, ignore_errors=True)
+    return res
 
 
 def run_rank(args):
@@ -466,27 +501,13 @@ def run_rank(args):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         energy_ok = bool(ok.item() == 1.0)
 
-    # the path's one collective, on the ranks of this job (N > 1 over RCCL only); guarded by a watchdog so that a stuck
-    # communicator cannot cost the bench line
+    # the path's one collective, on the ranks of this job (N > 1 over RCCL only), in child processes
     rccl = None
-    hung = False
     if dist is not None and backend == "nccl" and not stub:
-        import threading
-        box = {}
-
-        def work():
-            try:
-                box["r"] = rccl_exchange_check(system, rank, world, dev_index, dist, torch)
-            except Exception as exc:
-                box["r"] = {"n_ranks_rccl": 0, "error": repr(exc)}
-        th = threading.Thread(target=work, daemon=True)
-        th.start()
-        th.join(120.0)
-        if th.is_alive():
-            hung = True
-            rccl = {"n_ranks_rccl": 0, "error": "pmc_replica_exchange_rccl did not return within 120 s"}
-        else:
-            rccl = box.get("r")
+        try:
+            rccl = rccl_exchange_check(rank, world, dev_index, dist)
+        except Exception as exc:
+            rccl = {"n_ranks_rccl": 0, "error": repr(exc)}
 
     if rank == 0:
         value = legs[args.rounds]["value"]
@@ -548,9 +569,6 @@ def run_rank(args):
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if hung:
-        sys.stdout.flush()
-        os._exit(0)                  # a thread is stuck inside RCCL: leave without the orderly teardown
     if dist is not None:
         dist.destroy_process_group()
     return 0

@@ -14,6 +14,8 @@ SOURCES = [os.path.join(ROOT, "particlesmc_amd", "csrc", f) for f in ("pmc_kerne
 CROSS = re.compile(r"readlane|__shfl|update_dpp|dpp_add|mov_dpp|ds_bpermute|ds_swizzle|wave_sum_exact|wave_sum\b")
 # branches that switch lanes off by their index: `if (lane == 0)`, `if (tid == 0 ...`, `if (lane < n ...`, `if (... && lane == i)`
 LANE_BRANCH = re.compile(r"\bif\s*\((?:[^()]|\([^()]*\))*\b(?:lane|tid|threadIdx\.x)\s*(?:==|<|<=|>|>=|!=)(?:[^()]|\([^()]*\))*\)")
+# ... and loops whose trip count depends on the lane: `for (int k = lane; k < n; k += 64)`
+LANE_LOOP = re.compile(r"\b(?:for|while)\s*\((?:[^()]|\([^()]*\))*\b(?:lane|tid|threadIdx\.x)\b(?:[^()]|\([^()]*\))*\)")
 
 
 def strip_comments(text):
@@ -45,7 +47,7 @@ def test_no_cross_lane_read_inside_a_lane_selecting_branch():
     found = []
     for path in SOURCES:
         text = strip_comments(open(path).read())
-        for m in LANE_BRANCH.finditer(text):
+        for m in list(LANE_BRANCH.finditer(text)) + list(LANE_LOOP.finditer(text)):
             body = branch_body(text, m.end())
             hit = CROSS.search(body)
             if hit:
