@@ -103,3 +103,41 @@ def test_chains_of_different_shapes_and_the_sequential_engine_fall_back_to_one_s
     with pytest.raises(pmc.PMCError):
         pmc.mc_sweep_many([a[0], a[0]], pool, nsweeps=1)
     pmc.mc_sweep(a[0], pool, nsweeps=1)
+
+
+@pytest.mark.parametrize("team", ["auto", "8"])
+def test_batched_launches_mix_chains_with_and_without_periodic_images(gpu, monkeypatch, team):
+    """Chains of one shape in shared launches where some carry periodic images (an unwrapped restart) and some sit in the
+    primary box: the launch takes the image instances of the kernel, replicas without images hand it null image pointers.
+    m = 2; every chain == itself alone == the oracle's chain."""
+    from oracle import oracle as O
+    pmc = gpu
+    if team != "auto":
+        monkeypatch.setenv("PMC_TEAM", team)
+    pos, sp, rho = lj_lattice(12, jitter=0.05, seed=9)
+    L = (len(pos) / rho) ** (1.0 / 3.0)
+    rng = np.random.default_rng(4)
+    inputs = [pos,                                                             # in the box
+              pos + rng.integers(-3, 4, size=pos.shape) * L,                   # every particle in some image
+              pos + (rng.random(pos.shape) < 0.1) * L,                         # a tenth of the coordinates one box up
+              pos]
+
+    def mk(r):
+        s = pmc.System(inputs[r], sp, rho, 0.9 + 0.1 * r, pmc.LennardJones(1.0, 1.0), seed=21, chain=r)
+        s.rounds = 2
+        return s
+
+    a, b = [mk(r) for r in range(4)], [mk(r) for r in range(4)]
+    pool = [_disp(pmc, 0.07)]
+    for _ in range(2):
+        sa = pmc.mc_sweep_many(a, pool, nsweeps=5)
+        sb = [pmc.mc_sweep(s, pool, nsweeps=5) for s in b]
+        _same(a, b, sa, sb)
+    for r in range(4):
+        o = O.System(inputs[r], sp, rho, 0.9 + 0.1 * r, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+        cb = O.Checkerboard(inputs[r], sp, o.box, 0.9 + 0.1 * r, o.models, seed=21, chain=r)
+        opool = O.make_pool([{"kind": "Displacement", "sigma": 0.07}])
+        cb.sweeps(opool, 0, 5, rounds=2)
+        cb.sweeps(opool, 5, 5, rounds=2)
+        assert np.array_equal(a[r].position, cb.positions()) and sa[r].energy_fix == cb.energy_fix, r
+        assert np.abs(a[r].position - inputs[r]).max() < 1.0                    # nobody changed image
