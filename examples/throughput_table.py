@@ -106,6 +106,18 @@ def main():
             pmc.mc_sweep(c, pool, nsweeps=500)
         dt = time.perf_counter() - t0
         emit({"row": "the same 8 chains one after the other", "moves_per_s": 8 * 4096 * 500 / dt})
+        # small systems fill the chip by the number of chains, not by their size (parallel = true runs, tempering ladders)
+        for side, nch, sw in ((16, 64, 200), (16, 256, 100), (32, 32, 100)):
+            pos, sp, rho = lj_lattice(side, jitter=0.05, seed=42)
+            chains = [pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42, chain=c) for c in range(nch)]
+            for c in chains:
+                c.total_energy()
+            pmc.mc_sweep_many(chains, pool, nsweeps=max(10, sw // 5))
+            t0 = time.perf_counter()
+            pmc.mc_sweep_many(chains, pool, nsweeps=sw)
+            dt = time.perf_counter() - t0
+            emit({"row": f"{nch} chains of N={len(pos)} in shared launches (pmc_sweep_many)", "moves_per_s": nch * len(pos) * sw / dt})
+            del chains
 
 
 if __name__ == "__main__":

@@ -367,6 +367,17 @@ static void host_neighbour_cells(pmc_system *h)
     }
 }
 
+// wavefronts per cell visit from the number of cells that are active at the same time (one colour of one system, or of all the
+// chains of a shared launch: pmc_sweep_many); the measurements behind the thresholds are in pmc_create
+static int team_rule(int D, long long nact)
+{
+    int team = (nact <= 256) ? 8 : ((nact <= 900) ? 4 : ((nact <= 2400) ? 2 : 1));
+    // 2-d neighbourhoods hold ~70-100 candidates (two filter trips): N=65536 binary soft spheres (1600 cells per
+    // colour) 3.5 / 3.9 / 3.6e8 for teams of 1 / 2 / 4
+    if (D == 2 && nact > 512) team = 2;
+    return team;
+}
+
 extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
 {
     if (!p || !out) return fail(nullptr, PMC_ERR_BADARG, "pmc_create: null argument");
@@ -498,10 +509,7 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
         // team of eight, three of four or six of two -- so eight wavefronts per cell only pay while one colour's cells fit the
         // chip one per CU.  10^8 moves/s in the liquid, teams of 8 / 4 / 2 at that budget: 27 cells per colour 0.181 / 0.165 / 0.119;
         // 216: 1.32 / 1.26 / 0.91; 512: 1.73 / 2.04 / 1.48; 729: 1.81 / 3.70 / 2.93; 1331: 1.77 / 3.96 / 4.84; 1728: 1.93 / 4.30 / 5.72.
-        h->team = (nact <= 256) ? 8 : ((nact <= 900) ? 4 : ((nact <= 2400) ? 2 : 1));
-        // 2-d neighbourhoods hold ~70-100 candidates (two filter trips): N=65536 binary soft spheres (1600 cells per
-        // colour) 3.5 / 3.9 / 3.6e8 for teams of 1 / 2 / 4
-        if (h->D == 2 && nact > 512) h->team = 2;
+        h->team = team_rule(h->D, nact);
         if (const char *e = getenv("PMC_TEAM")) { int t = atoi(e); if (t == 1 || t == 2 || t == 4 || t == 8) h->team = t; }
     }
     CR(hipMalloc(&h->d_start_ref, ((size_t)h->ncell_ref + 1) * sizeof(int)));
@@ -2094,6 +2102,17 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     pmc_system *m = hs[0];
     int rc = set_device(m);
     if (rc) return rc;
+    // The chains of a shared launch fill the chip together: the team width follows the cells that are active at the same time
+    // over ALL of them (64 chains of N = 4096 -- 27 cells per colour each -- ran teams of eight at 1.8e8 moves/s, the rate of
+    // eight chains).  Results do not depend on the width; the handles get their own width back when the call returns.
+    struct TeamOverride {
+        pmc_system **hs; int n; int saved;
+        TeamOverride(pmc_system **hs_, int n_, int team) : hs(hs_), n(n_), saved(hs_[0]->team) { for (int r = 0; r < n; r++) hs[r]->team = team; }
+        ~TeamOverride() { for (int r = 0; r < n; r++) hs[r]->team = saved; }
+    };
+    long long nact_all = n;
+    for (int q = 0; q < m->D; q++) nact_all *= std::max(1, m->grid.n[q] / 2);
+    TeamOverride team_guard(hs, n, getenv("PMC_TEAM") ? m->team : team_rule(m->D, nact_all));
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
         rc = ensure_images(h);

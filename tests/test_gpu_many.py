@@ -141,3 +141,38 @@ def test_batched_launches_mix_chains_with_and_without_periodic_images(gpu, monke
         cb.sweeps(opool, 5, 5, rounds=2)
         assert np.array_equal(a[r].position, cb.positions()) and sa[r].energy_fix == cb.energy_fix, r
         assert np.abs(a[r].position - inputs[r]).max() < 1.0                    # nobody changed image
+
+
+@pytest.mark.parametrize("nchains,team", [(40, 4), (150, 2), (330, 1)])
+def test_team_width_of_a_shared_launch_follows_all_its_chains(gpu, nchains, team):
+    """A chain of N = 1728 has 8 cells per colour and runs teams of eight wavefronts on its own; 40 / 150 / 330 of them in one
+    launch have 320 / 1200 / 2640 cells active at the same time and take teams of 4 / 2 / 1 for that launch (the rule of
+    pmc_create applied to the launch).  Every chain still equals itself alone, a few of them the oracle, and the handles keep
+    their own width afterwards."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(12, jitter=0.05, seed=13)
+
+    def mk(r):
+        s = pmc.System(pos, sp, rho, 0.8 + 0.001 * r, pmc.LennardJones(1.0, 1.0), seed=5, chain=r)
+        s.rounds = 2
+        return s
+
+    a = [mk(r) for r in range(nchains)]
+    pool = [_disp(pmc, 0.06)]
+    sa = pmc.mc_sweep_many(a, pool, nsweeps=3)
+    sa = pmc.mc_sweep_many(a, pool, nsweeps=3)
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.06}])
+    for r in sorted({0, 7, nchains // 2, nchains - 1}):
+        b = mk(r)
+        pmc.mc_sweep(b, pool, nsweeps=3)
+        sb = pmc.mc_sweep(b, pool, nsweeps=3)                    # alone: its own width (8)
+        assert np.array_equal(a[r].position, b.position) and sa[r].energy_fix == sb.energy_fix, r
+        assert np.array_equal(sa[r].accepted, sb.accepted) and sa[r].null_moves == sb.null_moves
+        o = O.System(pos, sp, rho, 0.8 + 0.001 * r, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+        cb = O.Checkerboard(pos, sp, o.box, 0.8 + 0.001 * r, o.models, seed=5, chain=r)
+        cb.sweeps(opool, 0, 3, rounds=2)
+        cb.sweeps(opool, 3, 3, rounds=2)
+        assert np.array_equal(a[r].position, cb.positions()) and sa[r].energy_fix == cb.energy_fix, r
+    assert all(s.total_energy()[1] == st.energy_fix for s, st in zip(a[:20], sa[:20]))
+    assert len({int(st.accepted[0]) for st in sa}) > nchains // 4         # the chains differ
