@@ -2176,6 +2176,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     for (int r = 0; r < n; r++) img_ = img_ || hs[r]->any_img;
     const int mw_ = cb_minwaves(m, lds);
     const int grid = ncol * n * nactive;
+    if (getenv("PMC_DEBUG_CAP")) fprintf(stderr, "[pmc many] chains %d team %d cap %d lds %zu minwaves %d\n", n, m->team, cap_sweep, lds, mw_);
     HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
     for (int64_t s0 = 0; s0 < npass; s0 += chunk) {
         const int64_t ns = std::min<int64_t>(chunk, npass - s0);
@@ -2260,6 +2261,9 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         }
         h->e_fix += (long long)st[16];
         h->energy = (double)h->e_fix / PMC_FIX;
+        // one wavefront per cell (the launch's width, still in force here): the LDS staging of the next call is sized from this
+        // call's survivor histogram, as after a single-chain call (256 chains of N = 4096: 7.4 -> 8.4e8 moves/s)
+        if (cb_cap_sweep_adapts(h)) cb_cap_learn(h, st + PMC_STAT_KEPT);
         if (out) {
             pmc_stats &o = out[r];
             for (int k = 0; k < PMC_MAX_MOVES; k++) { o.attempted[k] = (int64_t)st[k]; o.accepted[k] = (int64_t)st[8 + k]; }
