@@ -371,11 +371,13 @@ static void host_neighbour_cells(pmc_system *h)
 // chains of a shared launch: pmc_sweep_many); the measurements behind the thresholds are in pmc_create
 static int team_rule(int D, long long nact)
 {
-    int team = (nact <= 256) ? 8 : ((nact <= 900) ? 4 : ((nact <= 2400) ? 2 : 1));
-    // 2-d neighbourhoods hold ~70-100 candidates (two filter trips): N=65536 binary soft spheres (1600 cells per
-    // colour) 3.5 / 3.9 / 3.6e8 for teams of 1 / 2 / 4
-    if (D == 2 && nact > 512) team = 2;
-    return team;
+    // 2-d neighbourhoods hold ~70-100 candidates (two filter trips) and one wavefront per cell takes over earlier.  Binary r^-14
+    // soft spheres, rho = 0.8, 10^8 moves/s for teams of 1 / 2 / 4 / 8 (end of round 3, m = 1): 100 cells per colour 0.33 / 0.36 /
+    // 0.43 / 0.43; 400: 1.26 / 1.34 / 1.56 / 1.12; 1600: 4.47 / 4.38 / 3.16 / 1.40; 6561: 12.1 / 5.9 / 3.7 / 1.5; 26569 (N = 2^20):
+    // 14.8 / 6.3 / 3.9 / 1.5.  (Rounds 2-3 kept two wavefronts per cell from 512 cells per colour on WITHOUT an upper bound -- a
+    // rule fitted at N = 65536 before the fused staging existed: large 2-d systems ran at half their rate.)
+    if (D == 2) return (nact <= 256) ? 8 : ((nact <= 900) ? 4 : ((nact <= 1500) ? 2 : 1));
+    return (nact <= 256) ? 8 : ((nact <= 900) ? 4 : ((nact <= 2400) ? 2 : 1));
 }
 
 extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
