@@ -55,10 +55,8 @@ def main():
     pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.065}, 1.0)]
     if args.local:
         n = args.local
-        if n >= 4:
-            # several chains share the GPU: the chip is full, so the narrow teams that waste no issue slots win
-            # (8 replicas: 6.1e8 moves/s with teams of 2 against 4.8e8 with the single-chain default of 4)
-            os.environ.setdefault("PMC_TEAM", "2")
+        # (the replicas share every launch -- pmc_sweep_many -- and the launch picks its wavefronts per cell from the cells of ALL
+        # of them: nothing to set here)
         ladder = np.geomspace(args.tmin, args.tmax, n)
         systems = [make_system(pmc, args.side, RHO, ladder[r], 5, r, 0) for r in range(n)]
         for s_ in systems:

@@ -2062,7 +2062,9 @@ static int validate_pool(pmc_system *h, const pmc_move *pool, int32_t npool, int
 static bool many_compatible(pmc_system **hs, int n)
 {
     const pmc_system *m = hs[0];
-    if (!m->mc_ok || !m->use_fused || m->N >= 500000 || m->ncell_mc > PMC_SCAN_SMALL_MAX) return false;
+    // (k_many_scan scans a replica's cell counts with ONE block, 1024 cells per step: up to 32768 cells that is <= 32 steps per
+    // sweep, a few per cent of a sweep of such a system)
+    if (!m->mc_ok || !m->use_fused || m->N >= 500000 || m->ncell_mc > 4 * PMC_SCAN_SMALL_MAX) return false;
     for (int r = 1; r < n; r++) {
         const pmc_system *h = hs[r];
         if (h == m) return false;
