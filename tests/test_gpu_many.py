@@ -176,3 +176,30 @@ def test_team_width_of_a_shared_launch_follows_all_its_chains(gpu, nchains, team
         assert np.array_equal(a[r].position, cb.positions()) and sa[r].energy_fix == cb.energy_fix, r
     assert all(s.total_energy()[1] == st.energy_fix for s, st in zip(a[:20], sa[:20]))
     assert len({int(st.accepted[0]) for st in sa}) > nchains // 4         # the chains differ
+
+
+def test_shared_launch_with_more_than_8192_cells_per_chain(gpu):
+    """Two chains of config 5's 2-D system at N = 65536 (102 x 102 = 10404 cells each: more than one pass of the shared
+    launch's one-block scan used to allow): the shared launch == each chain alone, running energy == recomputation."""
+    pmc = gpu
+    n, rho = 256, 0.5
+    N = n * n
+    L = (N / rho) ** 0.5
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float64)
+    pos = (g + 0.5) * (L / n) + np.random.default_rng(1).uniform(-0.05, 0.05, (N, 2))
+    sp = np.ones(N, dtype=np.int32)
+    sp[np.random.default_rng(2).permutation(N)[: N // 2]] = 2
+    mm = [[pmc.SoftSpheres(1.0, s, 14) for s in row] for row in ([1.0, 1.2], [1.2, 1.4])]
+
+    def mk(r):
+        s = pmc.System(pos, sp, rho, 1.0 + 0.01 * r, mm, seed=5, chain=r)
+        s.rounds = 2
+        return s
+
+    a, b = [mk(r) for r in range(2)], [mk(r) for r in range(2)]
+    assert int(np.prod(a[0].grid()[0])) > 8192
+    pool = [_disp(pmc, 0.065)]
+    sa = pmc.mc_sweep_many(a, pool, nsweeps=5)
+    sb = [pmc.mc_sweep(s, pool, nsweeps=5) for s in b]
+    _same(a, b, sa, sb)
+    assert sa[0].sweep_kernel_launches == 3 and sa[0].accepted[0] != sa[1].accepted[0]
