@@ -5,7 +5,7 @@ an RCCL communicator through the library's own entry points (pmc_rccl_unique_id 
 over through a file in OUTDIR) and runs NROUNDS rounds of five sweeps + one exchange through pmc_replica_exchange_rccl (one
 ncclAllGather of one double per rank; reference: README.md:33 has no counterpart, replica sharding src/IO/IO.jl:319-327).  What
 the rank saw goes to OUTDIR/rank<r>.json; the caller compares every rank's labels with the decision function on the energies
-all ranks reported (tests/test_gpu_multirank.py: the oracle; bench.py: pmc_pt_decide).
+all ranks reported (tests/test_gpu_zz_multirank.py: the oracle; bench.py: pmc_pt_decide).
 
 It is a separate process on purpose: bench.py's N > 1 run starts one per rank AFTER its measurements, so that nothing that
 happens inside the collective -- a hang, a crash of a communicator that has never run on that node -- can cost the bench line."""

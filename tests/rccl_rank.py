@@ -1,4 +1,4 @@
-"""One rank of the multi-GPU replica-exchange test (started by tests/test_gpu_multirank.py, one fresh process per GPU):
+"""One rank of the multi-GPU replica-exchange test (started by tests/test_gpu_zz_multirank.py, one fresh process per GPU):
 `rccl_rank.py RANK WORLD OUTDIR NROUNDS` = particlesmc_amd.rccl_check with device = rank."""
 import os
 import sys

@@ -3,7 +3,9 @@ fresh processes, one device each, which build an RCCL communicator through the l
 exchange rounds (a world of ONE rank runs everywhere and proves the rank script, the id file and the comparison themselves) of BASELINE config 5's system through pmc_replica_exchange_rccl; every rank's labels must equal the
 oracle's `pt_decide` on the energies all ranks reported.  On a 1-GPU box the test reports itself as NOT RUN (a skip with
 that reason) -- it never passes without having exercised the collective.  (Reference: README.md:33 -- no counterpart;
-replica sharding src/IO/IO.jl:319-327.)"""
+replica sharding src/IO/IO.jl:319-327.)
+(The file name sorts last on purpose: this is the one test whose code path no box of the build rounds could execute, and a
+`pytest -x` run on a multi-GPU box should have gone through every other test before it gets here.)"""
 import json
 import os
 import subprocess
