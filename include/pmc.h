@@ -221,10 +221,11 @@ int pmc_sweep_begin(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t n
 int pmc_sweep_end(pmc_system *h, pmc_stats *out);
 
 /* All the chains of a `parallel = true` run (src/ParticlesMC.jl:164,246) or all the replicas of a tempering ladder in
- * shared launches: when the n handles have one shape (same device, N, box, models, grid; N < 5e5) every kernel of a sweep
+ * shared launches: when the n handles have one shape (same device, N, box, models, grid; N < 5e5, <= 32768 cells) every kernel of a sweep
  * is launched ONCE for all of them -- the binning kernels take the replica from the second grid dimension, the fused
- * sweep kernel from its ticket -- instead of n times on n streams.  The result of every chain is bit-identical to
- * pmc_sweep on it alone.  Other cases (different shapes, PMC_SEQUENTIAL, large systems) run as pmc_sweep_begin on every
+ * sweep kernel from its ticket -- instead of n times on n streams, and the launch takes as many wavefronts per cell as the
+ * cells of ALL its chains call for (many small chains fill the chip like one large system).  The result of every chain is
+ * bit-identical to pmc_sweep on it alone.  Other cases (different shapes, PMC_SEQUENTIAL, large systems) run as pmc_sweep_begin on every
  * handle followed by pmc_sweep_end on every handle.  out: n entries or NULL. */
 int pmc_sweep_many(pmc_system **h, int32_t n, int32_t mode, const pmc_move *pool, int32_t npool, int64_t nsweeps,
                    pmc_stats *out);
