@@ -213,6 +213,18 @@ int pmc_get_rounds(pmc_system *h, int32_t *rounds);
 int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
               int64_t nsweeps, pmc_stats *out);
 
+/* How PMC_SEQUENTIAL sweeps run (the results are the same chain bit for bit: positions, head / list / cs, accept counts,
+ * system.energy[1]).  engine 1: one wavefront takes the steps of src/moves.jl:57-81 literally, one after the other.  engine 2:
+ * speculative windows -- the random part of a step is a function of the step counter, a step only reads and writes the
+ * neighbour cells of its particle (src/neighbours.jl:94-111,316-377), so a window of pending steps is evaluated at once and
+ * every step that no earlier pending step can have influenced commits.  engine 0 (default): 2 for LinkedList /
+ * CellList, 1 for EmptyList / VerletList and for swap moves between a species and itself.  window: pending steps per round
+ * (0: chosen from the cell count; at most 4096). */
+int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window);
+/* diagnostics of the last PMC_SEQUENTIAL call that ran engine 2: out[0] rounds, out[1] step evaluations, out[2] window,
+ * out[3] steps folded into system.energy */
+int pmc_sequential_info(pmc_system *h, int64_t *out);
+
 /* The same sweep split in two so that several handles (chains with parallel=true,
  * src/ParticlesMC.jl:164,246; replicas of a tempering ladder) run concurrently on one GPU: begin
  * enqueues on the handle's stream and returns, end waits and collects.  No other call on the

@@ -104,6 +104,8 @@ SYMBOLS = {
     "pmc_grid": (C.c_int, [_h, _lp, _dp]),
     "pmc_set_rounds": (C.c_int, [_h, C.c_int32]),
     "pmc_get_rounds": (C.c_int, [_h, C.POINTER(C.c_int32)]),
+    "pmc_set_sequential_engine": (C.c_int, [_h, C.c_int32, C.c_int32]),
+    "pmc_sequential_info": (C.c_int, [_h, _lp]),
     "pmc_sweep": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64, C.POINTER(Stats)]),
     "pmc_sweep_begin": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64]),
     "pmc_sweep_end": (C.c_int, [_h, C.POINTER(Stats)]),

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include "../../include/pmc.h"
 #include "pmc_kernels.h"
+#include "pmc_seq.h"
 
 // The instances of the sweep kernel are compiled in their own translation units (pmc_cb_inst.hip, one per dimension and
 // model kind, in parallel); here they are only declared.  -DPMC_SINGLE_TU (and the development builds) keep everything
@@ -134,6 +135,17 @@ struct pmc_system {
     size_t cbtab_cap = 0;        // entries d_cbtab holds
     double *d_result = nullptr;
     int max_count = 0;
+    // fast reference-order engine (pmc_seq.h): speculative windows over the sequential chain
+    int seq_engine = 0;          // 0 auto, 1 the one-wavefront loop (k_ref_ops), 2 speculative windows
+    int seq_window = 0;          // window slots (0: from the cell count)
+    bool rows_own = false;       // d_cl_items was allocated for a LinkedList (the rows the fast engine reads)
+    SqSlot *d_sq_slots[2] = {nullptr, nullptr};
+    SqGen *d_sq_gen = nullptr;
+    unsigned long long *d_sq_M = nullptr, *d_sq_cp = nullptr;
+    int *d_sq_owner = nullptr, *d_sq_logflag = nullptr;
+    double *d_sq_logde = nullptr;
+    SqCtl *d_sq_ctl = nullptr, *h_sq_ctl = nullptr;
+    SqCtl sq_last{};             // control block of the last fast sequential call (diagnostics: rounds, evaluations)
 };
 
 #define HIPCHK(h, call)                                                                         \
@@ -569,9 +581,12 @@ extern "C" int pmc_destroy(pmc_system *h)
                     h->d_nbrcnt, h->d_sp_off, h->d_sp_ids, h->d_sp_heads, h->d_energy, h->d_cell_of, h->d_count,
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
                     h->d_sz, h->d_ssp, h->d_stats, h->d_cbtab, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m, h->d_img, h->d_simg,
-                    h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last};
+                    h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last,
+                    h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_cp, h->d_sq_owner, h->d_sq_logflag,
+                    h->d_sq_logde, h->d_sq_ctl};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
+    if (h->h_sq_ctl) (void)hipHostFree(h->h_sq_ctl);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (hipEvent_t e : h->pass_ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -884,6 +899,7 @@ static int bin_by_cell(pmc_system *h, int ncell, int *d_start, int *d_ids)
 }
 
 static RefArgs ref_args(pmc_system *h);
+static int seq_build_rows(pmc_system *h);
 
 extern "C" int pmc_build_cells(pmc_system *h)
 {
@@ -911,6 +927,10 @@ extern "C" int pmc_build_cells(pmc_system *h)
         // CellList / VerletList: cells[c] vectors in ascending id (build_neighbour_list!, src/neighbours.jl:145-156, 431-435)
         hipLaunchKernelGGL(k_ref_cellvec, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, N, h->d_cell_of, h->d_start_ref,
                            h->d_ids_ref, h->ncell_ref, h->d_cl_items, h->cl_cap, h->d_ccount, h->d_ref_err);
+    } else if (h->list_type == 1 && h->rows_own) {
+        // LinkedList rows of the fast sequential engine (pmc_seq.h): the chain of a cell read backwards = ids ascending
+        rc = seq_build_rows(h);
+        if (rc) return rc;
     }
     if (h->list_type == 3) {
         RefArgs a = ref_args(h);
@@ -1667,8 +1687,32 @@ extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const dou
     return PMC_OK;
 }
 
+#include "pmc_seq_host.h"
+
+extern "C" int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: null handle");
+    if (engine < 0 || engine > 2 || window < 0 || window > SQ_KMAX)
+        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront) or 2 (speculative windows); window 0..4096");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    h->seq_engine = engine;
+    h->seq_window = window;
+    return PMC_OK;
+}
+
+extern "C" int pmc_sequential_info(pmc_system *h, int64_t *out)
+{
+    if (!h || !out) return fail(h, PMC_ERR_BADARG, "pmc_sequential_info: null argument");
+    out[0] = (int64_t)h->sq_last.rounds;
+    out[1] = (int64_t)h->sq_last.evals;
+    out[2] = (int64_t)seq_window(h);
+    out[3] = (int64_t)(h->sq_last.gend - h->sq_last.next == 0 ? h->sq_last.prefix : 0);
+    return PMC_OK;
+}
+
 static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
 {
+    if (nsweeps > 0 && seq_fast_applicable(h, pool, npool)) return sweep_sequential_fast(h, pool, npool, nsweeps, out);
     if (!h->cells_built) {
         int rc = pmc_build_cells(h);
         if (rc) return rc;

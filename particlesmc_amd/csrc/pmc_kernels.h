@@ -765,6 +765,19 @@ __device__ void ref_relink(const RefArgs &a, int i, const double *x)
     a.list[i] = a.head[c2];
     a.head[c2] = i;
     a.cs[i] = c2;
+    if (a.cl_items) {
+        // rows of the fast sequential engine (pmc_seq.h): a cell's chain read backwards, so push-front = append
+        int *v = a.cl_items + (size_t)c * a.cl_cap;
+        const int n = a.ccount[c];
+        int w = 0;
+        for (int r = 0; r < n; r++) {
+            const int t = v[r];
+            if (t != i) v[w++] = t;
+        }
+        const int n2 = a.ccount[c2];
+        if (n2 < a.cl_cap) a.cl_items[(size_t)c2 * a.cl_cap + n2] = i;
+        else if (a.err) atomicOr(a.err, 4);
+    }
     a.ccount[c]--;
     a.ccount[c2]++;
 }

@@ -1,0 +1,222 @@
+// pmc_seq_host.h -- host side of the fast reference-order engine (pmc_seq.h); included by pmc_hip.hip after the handle.
+#pragma once
+
+#define SQ_FREE_BYTE 0x7f          // owner table "free" = 0x7f7f7f7f: larger than any candidate index, settable with hipMemset
+
+static int seq_rows_cap(const pmc_system *h)
+{
+    const double mean = (double)h->N / (double)h->ncell_ref;
+    return std::max(32, (int)(3.0 * mean) + 32);
+}
+
+// the cell rows of a LinkedList: allocated on the first fast sequential call, rebuilt by every pmc_build_cells
+static int seq_build_rows(pmc_system *h)
+{
+    const int tot = std::max(h->N, h->ncell_ref);
+    for (int attempt = 0; attempt < 6; attempt++) {
+        HIPCHK(h, hipMemsetAsync(h->d_ref_err, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_ref_cellvec, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, h->N, h->d_cell_of, h->d_start_ref,
+                           h->d_ids_ref, h->ncell_ref, h->d_cl_items, h->cl_cap, h->d_ccount, h->d_ref_err);
+        HIPCHK(h, hipGetLastError());
+        int e = 0;
+        HIPCHK(h, hipMemcpyAsync(&e, h->d_ref_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!(e & 1)) return PMC_OK;
+        // a cell holds more particles than a row: twice the capacity and again (k_ref_cellvec clamped ccount, k_ref_links
+        // must restore it)
+        (void)hipFree(h->d_cl_items);
+        h->d_cl_items = nullptr;
+        h->cl_cap *= 2;
+        if ((double)h->ncell_ref * h->cl_cap * sizeof(int) > 64e9) break;
+        HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * h->cl_cap * sizeof(int)));
+        hipLaunchKernelGGL(k_ref_links, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, h->d_cell_of, h->N, h->d_start_ref,
+                           h->d_ids_ref, h->ncell_ref, h->d_head, h->d_list, h->d_ccount);
+    }
+    return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine: a cell holds more particles than the row capacity allows");
+}
+
+static bool seq_pool_ok(const pmc_move *pool, int npool)
+{
+    for (int m = 0; m < npool; m++)
+        if (pool[m].kind == PMC_MOVE_SWAP && pool[m].species[0] == pool[m].species[1]) return false;   // i == j picks: the literal loop
+    return true;
+}
+
+static bool seq_fast_applicable(const pmc_system *h, const pmc_move *pool, int npool)
+{
+    if (h->seq_engine == 1) return false;
+    if (h->list_type != 1 && h->list_type != 2) return false;      // EmptyList: every step reads everything; VerletList: own update rule
+    if (!seq_pool_ok(pool, npool)) return false;
+    for (int a = 0; a < h->D; a++) if (h->p.ncells[a] > 65535) return false;   // 16-bit cell coordinates in the pair test
+    if ((double)h->ncell_ref * seq_rows_cap(h) * sizeof(int) > 32e9) return false;   // dilute giants: rows would not fit
+    return true;
+}
+
+static int seq_ensure(pmc_system *h)
+{
+    if (!h->d_ref_err) {
+        HIPCHK(h, hipMalloc(&h->d_ref_err, 16));
+        HIPCHK(h, hipMemset(h->d_ref_err, 0, 16));
+    }
+    if (h->list_type == 1 && !h->d_cl_items) {
+        h->cl_cap = seq_rows_cap(h);
+        HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * h->cl_cap * sizeof(int)));
+        h->rows_own = true;
+        h->cells_built = false;            // the next build fills the rows
+    }
+    if (!h->d_sq_ctl) {
+        HIPCHK(h, hipMalloc(&h->d_sq_slots[0], (size_t)SQ_KMAX * sizeof(SqSlot)));
+        HIPCHK(h, hipMalloc(&h->d_sq_slots[1], (size_t)SQ_KMAX * sizeof(SqSlot)));
+        HIPCHK(h, hipMalloc(&h->d_sq_gen, (size_t)SQ_GEN * sizeof(SqGen)));
+        HIPCHK(h, hipMalloc(&h->d_sq_M, (size_t)SQ_KMAX * SQ_KW * sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc(&h->d_sq_cp, (size_t)SQ_KW * sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc(&h->d_sq_owner, (size_t)h->N * sizeof(int)));
+        HIPCHK(h, hipMalloc(&h->d_sq_logflag, (size_t)SQ_RING * sizeof(int)));
+        HIPCHK(h, hipMalloc(&h->d_sq_logde, (size_t)SQ_RING * sizeof(double)));
+        HIPCHK(h, hipHostMalloc(&h->h_sq_ctl, sizeof(SqCtl)));
+        HIPCHK(h, hipMalloc(&h->d_sq_ctl, sizeof(SqCtl)));
+    }
+    return PMC_OK;
+}
+
+static int seq_window(const pmc_system *h)
+{
+    int K = h->seq_window;
+    if (K <= 0) {
+        // a pair of pending steps interacts with probability ~ 3^d / cells: about two windows' worth of independent steps
+        long long nn = 1;
+        for (int a = 0; a < h->D; a++) nn *= 3;
+        K = (int)(2LL * h->ncell_ref / nn);
+        if (const char *e = getenv("PMC_SEQ_WINDOW")) K = atoi(e);
+        K = std::min(K, 2048);
+    }
+    K = ((std::max(K, 1) + 63) / 64) * 64;
+    return std::min(K, SQ_KMAX);
+}
+
+// mc_sweep!(system, pool, rng; mc_steps = nsweeps N) as the reference runs it -- one particle per step, every step seeing
+// the state all earlier steps left (src/moves.jl:11-20,57-81,187-207) -- in speculative windows (pmc_seq.h).
+static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    int rc = seq_ensure(h);
+    if (rc) return rc;
+    if (!h->cells_built) {
+        rc = pmc_build_cells(h);
+        if (rc) return rc;
+    }
+    if (int rs = refresh_stale_energy(h)) return rs;
+    const int K = seq_window(h);
+    const long long nsteps = nsweeps * (int64_t)h->N;      // sweepstep = N, src/ParticlesMC.jl:246
+    SqArgs s;
+    memset(&s, 0, sizeof s);
+    s.a = ref_args(h);
+    for (int q = 0; q < 3; q++) s.invbox[q] = 1.0 / s.a.box[q];
+    s.slots[0] = h->d_sq_slots[0];
+    s.slots[1] = h->d_sq_slots[1];
+    s.gen = h->d_sq_gen;
+    s.M = h->d_sq_M;
+    s.cp = h->d_sq_cp;
+    s.owner = h->d_sq_owner;
+    s.log_de = h->d_sq_logde;
+    s.log_flag = h->d_sq_logflag;
+    s.ctl = h->d_sq_ctl;
+    s.pool = make_pool(pool, npool);
+    s.K = K;
+    s.cur = 0;
+    s.reverse = (h->list_type == 1) ? 1 : 0;
+    s.ids_cap = h->nn * h->cl_cap;
+    const size_t lds = (size_t)s.ids_cap * sizeof(int);
+    if (lds > 160 * 1024 - 256) return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
+    if (lds > 48 * 1024) {
+        if (h->D == 3) HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_round_a<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_round_a<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    SqCtl c0;
+    memset(&c0, 0, sizeof c0);
+    c0.next = c0.prefix = h->step_ctr;
+    c0.gend = h->step_ctr + (unsigned long long)nsteps;
+    c0.energy = h->energy;
+    c0.trunc = INT_MAX;
+    *h->h_sq_ctl = c0;
+    HIPCHK(h, hipMemcpyAsync(h->d_sq_ctl, h->h_sq_ctl, sizeof(SqCtl), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sq_owner, SQ_FREE_BYTE, (size_t)h->N * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sq_logflag, 0, (size_t)SQ_RING * sizeof(int), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));            // the pinned block is reused for the read-backs below
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    unsigned long long gen_hi = c0.next, next_known = c0.next, prefix_known = c0.prefix;
+    const int kw = K / 64;
+    const int grid_a = K + kw * kw + 1;
+    double per_round = 0.5 * K;                             // steps a round finishes: learnt from the batches
+    int cur = 0;
+    long long guard = 0;
+    while (prefix_known < c0.gend) {
+        // random parts ahead of the admission front (the ring holds SQ_GEN steps; admitted steps have been copied out)
+        unsigned long long target = std::min<unsigned long long>(c0.gend, next_known + SQ_GEN);
+        if (gen_hi < target) {
+            unsigned long long g0 = gen_hi;
+            while (g0 < target) {
+                const int n = (int)std::min<unsigned long long>(target - g0, 1u << 20);
+                hipLaunchKernelGGL(k_sq_gen, dim3(nblk(n, 256)), dim3(256), 0, h->stream, h->d_sq_gen, g0, n, h->key[0], h->key[1], s.pool);
+                g0 += (unsigned long long)n;
+            }
+            gen_hi = target;
+        }
+        s.gen_hi = gen_hi;
+        const double left = (double)(c0.gend - prefix_known);
+        long long rounds = (long long)(left / std::max(per_round, 1.0)) + 2;
+        rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)((gen_hi - next_known) / (unsigned long long)K)));
+        rounds = std::min<long long>(rounds, 256);
+        rounds = std::max<long long>(rounds, 1);
+        for (long long r = 0; r < rounds; r++) {
+            s.cur = cur;
+            if (h->D == 3) hipLaunchKernelGGL(k_sq_fill<3>, dim3(1), dim3(SQ_FILL_THREADS), 0, h->stream, s);
+            else hipLaunchKernelGGL(k_sq_fill<2>, dim3(1), dim3(SQ_FILL_THREADS), 0, h->stream, s);
+            cur ^= 1;
+            s.cur = cur;
+            if (h->D == 3) {
+                hipLaunchKernelGGL(k_sq_round_a<3>, dim3(grid_a), dim3(64), lds, h->stream, s);
+                hipLaunchKernelGGL(k_sq_commit<3>, dim3(K), dim3(64), 0, h->stream, s);
+            } else {
+                hipLaunchKernelGGL(k_sq_round_a<2>, dim3(grid_a), dim3(64), lds, h->stream, s);
+                hipLaunchKernelGGL(k_sq_commit<2>, dim3(K), dim3(64), 0, h->stream, s);
+            }
+        }
+        hipLaunchKernelGGL(k_sq_walk, dim3(1), dim3(64), 0, h->stream, s);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->h_sq_ctl, h->d_sq_ctl, sizeof(SqCtl), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const SqCtl &c = *h->h_sq_ctl;
+        if (c.err) {
+            h->cells_built = false;
+            h->energy_stale = true;
+            return fail(h, PMC_ERR_STATE, (c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
+        }
+        const double done = (double)(c.prefix - prefix_known);
+        if (done > 0) per_round = std::max(1.0, done / (double)rounds);
+        next_known = c.next;
+        prefix_known = c.prefix;
+        if (done == 0 && ++guard > 8) return fail(h, PMC_ERR_STATE, "sequential engine: no progress");
+        if (done > 0) guard = 0;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev[1]));
+    const SqCtl &c = *h->h_sq_ctl;
+    h->sq_last = c;
+    h->energy = c.energy;
+    h->step_ctr += (uint64_t)nsteps;
+    h->sweep_ctr += (uint64_t)nsweeps;
+    h->mc_binned = false;
+    h->e_fix_valid = false;
+    h->img_valid = false;
+    if (out) {
+        for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)c.att[m]; out->accepted[m] = (int64_t)c.acc[m]; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+        out->kernel_ms = ms;
+        out->sweep_kernel_ms = ms;
+        out->sweep_kernel_launches = (int64_t)c.rounds;
+        out->energy = h->energy;
+        out->energy_fix = 0;
+    }
+    return PMC_OK;
+}

@@ -261,6 +261,18 @@ class Atoms(Particles):
         _lib.check(_lib.lib().pmc_set_rounds(self._h, int(m)), self._h)
 
 
+    # --- how PMC_SEQUENTIAL sweeps run (same chain bit for bit; include/pmc.h) --------------------
+    def set_sequential_engine(self, engine=0, window=0):
+        """engine 0 auto, 1 the one-wavefront literal loop, 2 speculative windows; window: pending steps per round (0 auto)."""
+        _lib.check(_lib.lib().pmc_set_sequential_engine(self._h, int(engine), int(window)), self._h)
+
+    def sequential_info(self):
+        """(rounds, step evaluations, window, steps folded) of the last PMC_SEQUENTIAL call that ran engine 2."""
+        out = (C.c_int64 * 4)()
+        _lib.check(_lib.lib().pmc_sequential_info(self._h, out), self._h)
+        return tuple(int(v) for v in out)
+
+
 def get_position(system, i):                 # src/ParticlesMC.jl:41
     return system.position[i - 1]
 

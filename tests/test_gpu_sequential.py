@@ -1,0 +1,171 @@
+"""-m gpu: the FAST reference-order chain (PMC_SEQUENTIAL, engine 2: speculative windows, pmc_seq.h) against the oracle's
+restatement of the reference's sequential chain (src/moves.jl:11-20,57-81,187-207; oracle orc_mc_steps_sequential).
+
+Bar: bit-exact -- positions, cell membership, head / list (or the CellList vectors), SpeciesList, accept counts per move
+and the running system.energy[1] -- whatever the window, the list type, the pool and the grouping into calls."""
+import numpy as np
+import pytest
+
+from inputs import binary_lattice, lj_lattice, random_gas
+
+pytestmark = pytest.mark.gpu
+
+
+def _disp(pmc, sigma, p=1.0):
+    return pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": sigma}, p)
+
+
+def _swap(pmc, species, counts, p):
+    return pmc.Move(pmc.DiscreteSwap(0, 0, species, counts, 0.0), pmc.DoubleUniform(), {}, p)
+
+
+def _same_state(g, o, linked=True, species=False):
+    assert np.array_equal(g.position, o.positions()), "positions differ"
+    assert g.energy[0] == o.energy, (g.energy[0], o.energy)
+    assert np.array_equal(g.get_cells(), o.cells()), "cs differ"
+    if linked:
+        hg, lg = g.get_linked_list()
+        ho, lo = o.linked_list()
+        assert np.array_equal(hg, ho), "heads differ"
+        assert np.array_equal(lg, lo), "list differs"
+    if species:
+        assert np.array_equal(g.species, o.species())
+        for s in (1, 2):
+            assert np.array_equal(g.species_ids(s), o.species_ids(s)), f"sp_ids[{s}] differ"
+
+
+@pytest.mark.parametrize("n,rho,sigma,window", [(6, 0.9, 0.15, 0), (8, 0.9, 0.15, 64), (12, 1.0, 0.05, 0), (16, 1.0, 0.3, 128),
+                                                (24, 1.0, 0.05, 0), (24, 1.0, 0.6, 512)])
+def test_lj_displacements_bitexact(gpu, n, rho, sigma, window):
+    """Displacement-only LJ chains from 3 cells per side (everything interacts) to 9 (windows of hundreds of steps);
+    sigma up to 0.6 makes a quarter of the trials change cell, accepted or not."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(n, jitter=0.1, seed=3, rho=rho)
+    g = pmc.System(pos, sp, rho, 0.8, pmc.LennardJones(1.0, 1.0), seed=99)
+    o = O.System(pos, sp, rho, 0.8, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    g.set_sequential_engine(2, window)
+    nsw = 3 if n <= 16 else 2
+    st = pmc.mc_sweep(g, [_disp(pmc, sigma)], nsweeps=nsw, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": sigma}]), 99, 0, 0, nsw * len(pos))
+    assert st.attempted[0] == att[0] and st.accepted[0] == acc[0], (st.accepted, acc)
+    _same_state(g, o)
+    rounds, evals, win, folded = g.sequential_info()
+    assert folded == nsw * len(pos) and rounds > 0
+
+
+def test_engines_agree_and_calls_compose(gpu):
+    """The literal one-wavefront loop (engine 1), the windows (engine 2) and the oracle are one chain; splitting the sweeps
+    over calls, or alternating the engines between calls, changes nothing."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(10, jitter=0.1, seed=5, rho=0.95)
+    pool = [_disp(pmc, 0.2)]
+    o = O.System(pos, sp, rho, 1.1, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.2}]), 7, 0, 0, 4 * len(pos))
+    a = pmc.System(pos, sp, rho, 1.1, pmc.LennardJones(1.0, 1.0), seed=7)
+    a.set_sequential_engine(2, 0)
+    sa = pmc.mc_sweep(a, pool, nsweeps=4, mode="sequential")
+    b = pmc.System(pos, sp, rho, 1.1, pmc.LennardJones(1.0, 1.0), seed=7)
+    nacc = 0
+    for k, eng in enumerate((2, 1, 2, 1)):
+        b.set_sequential_engine(eng, 64 if k == 0 else 0)
+        nacc += pmc.mc_sweep(b, pool, nsweeps=1, mode="sequential").accepted[0]
+    assert sa.accepted[0] == acc[0] == nacc
+    _same_state(a, o)
+    _same_state(b, o)
+
+
+@pytest.mark.parametrize("N,window", [(1000, 0), (4096, 256)])
+def test_kob_andersen_with_swaps_bitexact(gpu, N, window):
+    """BASELINE config 3's pool (90 % Displacement, 10 % DiscreteSwap) on the sequential chain: species, SpeciesList,
+    both accept counts."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = binary_lattice(N, frac_b=0.2, rho=1.2, jitter=0.05, seed=8)
+    nA, nB = int((sp == 1).sum()), int((sp == 2).sum())
+    g = pmc.System(pos, sp, rho, 1.0, pmc.KobAndersen(), seed=21)
+    o = O.System(pos, sp, rho, 1.0, O.kob_andersen(), O.LINKEDLIST)
+    g.set_sequential_engine(2, window)
+    pool = [_disp(pmc, 0.08, 0.9), _swap(pmc, (1, 2), (nA, nB), 0.1)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.08, "probability": 0.9},
+                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}])
+    for call in range(2):
+        st = pmc.mc_sweep(g, pool, nsweeps=2, mode="sequential")
+        att, acc = o.mc_steps(opool, 21, 0, call * 2 * N, 2 * N)
+        assert np.array_equal(st.attempted, att) and np.array_equal(st.accepted, acc), (st.accepted, acc)
+        _same_state(g, o, species=True)
+
+
+def test_high_swap_acceptance_mixture(gpu):
+    """The published mixture (examples/lj-mixture: size ratio 1.06, rcut = 4, unshifted) accepts most swaps: windows full
+    of accepted DiscreteSwaps; the reference's own N = 1000 has two cells per side."""
+    from oracle import oracle as O
+    from mixture import EPS, SIG, RCUT
+    pmc = gpu
+    N = 1000
+    pos, sp, rho = binary_lattice(N, frac_b=0.5, rho=0.8, jitter=0.05, seed=4)
+    mp = [[pmc.LennardJones(EPS[i][j], SIG[i][j], rcut=RCUT, shift_potential=False) for j in range(2)] for i in range(2)]
+    mo = O.model_matrix(lambda e, s: O.lennard_jones(e, s, RCUT, False), EPS, SIG)
+    g = pmc.System(pos, sp, rho, 1.5, mp, seed=5)
+    o = O.System(pos, sp, rho, 1.5, mo, O.LINKEDLIST)
+    g.set_sequential_engine(2, 0)
+    pool = [_disp(pmc, 0.1, 0.5), _swap(pmc, (1, 2), (N // 2, N // 2), 0.5)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.1, "probability": 0.5},
+                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.5}])
+    st = pmc.mc_sweep(g, pool, nsweeps=2, mode="sequential")
+    att, acc = o.mc_steps(opool, 5, 0, 0, 2 * N)
+    assert np.array_equal(st.attempted, att) and np.array_equal(st.accepted, acc), (st.accepted, acc)
+    assert acc[1] > 0.3 * att[1]
+    _same_state(g, o, species=True)
+
+
+def test_cell_list_vectors_bitexact(gpu):
+    """CellList (src/neighbours.jl:61-217): cells[c] vectors in filter! / push! order, energies summed in vector order."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(12, jitter=0.1, seed=11, rho=0.9)
+    g = pmc.System(pos, sp, rho, 0.9, pmc.LennardJones(1.0, 1.0), list_type=pmc.CellList, seed=3)
+    o = O.System(pos, sp, rho, 0.9, O.single(O.lennard_jones(1.0, 1.0)), O.CELLLIST)
+    g.set_sequential_engine(2, 0)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.4)], nsweeps=3, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.4}]), 3, 0, 0, 3 * len(pos))
+    assert st.accepted[0] == acc[0]
+    _same_state(g, o, linked=False)
+    ncell = int(np.prod(o.cell_geometry()[1]))
+    for c in range(1, ncell + 1):
+        assert np.array_equal(g.get_cell_members(c), o.cell_members(c)), c
+
+
+def test_soft_spheres_2d_unwrapped(gpu):
+    """2-D r^-12 binary soft spheres (BHHP) from positions many boxes away (never wrapped: src/moves.jl:46-48)."""
+    from oracle import oracle as O
+    pmc = gpu
+    N = 900
+    pos, rho = random_gas(N, 0.7, 2, seed=2, min_dist=0.9)
+    rng = np.random.default_rng(1)
+    sp = np.ones(N, dtype=np.int32)
+    sp[rng.permutation(N)[: N // 2]] = 2
+    g = pmc.System(pos, sp, rho, 0.5, pmc.BHHP(), seed=13)
+    o = O.System(pos, sp, rho, 0.5, O.bhhp(), O.LINKEDLIST)
+    g.set_sequential_engine(2, 0)
+    pool = [_disp(pmc, 0.15, 0.8), _swap(pmc, (1, 2), (N // 2, N - N // 2), 0.2)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.15, "probability": 0.8},
+                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.2}])
+    st = pmc.mc_sweep(g, pool, nsweeps=4, mode="sequential")
+    att, acc = o.mc_steps(opool, 13, 0, 0, 4 * N)
+    assert np.array_equal(st.accepted, acc), (st.accepted, acc)
+    _same_state(g, o, species=True)
+
+
+def test_config2_one_sweep_bitexact(gpu):
+    """BASELINE config 2 (N = 32768 LJ liquid, rho = 1, T = 1, rcut = 2.5): one full sweep of the sequential chain."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(32, jitter=0.05, seed=42)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+    o = O.System(pos, sp, rho, 1.0, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.05)], nsweeps=1, mode="sequential")     # engine: auto
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 42, 0, 0, len(pos))
+    assert st.accepted[0] == acc[0]
+    _same_state(g, o)
