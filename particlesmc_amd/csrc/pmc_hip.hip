@@ -142,8 +142,9 @@ struct pmc_system {
     SqSlot *d_sq_slots[2] = {nullptr, nullptr};
     SqGen *d_sq_gen = nullptr;
     unsigned long long *d_sq_M = nullptr, *d_sq_cp = nullptr;
-    int *d_sq_owner = nullptr, *d_sq_logflag = nullptr;
-    double *d_sq_logde = nullptr;
+    int *d_sq_moveto = nullptr;
+    SqLog *d_sq_log = nullptr, *h_sq_log = nullptr;
+    int sq_ring = 0;             // records the log ring holds (a power of two)
     SqCtl *d_sq_ctl = nullptr, *h_sq_ctl = nullptr;
     SqCtl sq_last{};             // control block of the last fast sequential call (diagnostics: rounds, evaluations)
 };
@@ -582,11 +583,11 @@ extern "C" int pmc_destroy(pmc_system *h)
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
                     h->d_sz, h->d_ssp, h->d_stats, h->d_cbtab, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m, h->d_img, h->d_simg,
                     h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last,
-                    h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_cp, h->d_sq_owner, h->d_sq_logflag,
-                    h->d_sq_logde, h->d_sq_ctl};
+                    h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_cp, h->d_sq_moveto, h->d_sq_log, h->d_sq_ctl};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_sq_ctl) (void)hipHostFree(h->h_sq_ctl);
+    if (h->h_sq_log) (void)hipHostFree(h->h_sq_log);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (hipEvent_t e : h->pass_ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);

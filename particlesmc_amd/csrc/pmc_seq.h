@@ -23,8 +23,10 @@
 //     added, in iterator order.  For the same reason the place of particle i itself in the iteration is irrelevant, and
 //     the e2 of a step that changes cell is evaluated without relinking first.
 //   * system.energy[1] is a running FP64 sum over steps in step order (`+= de`, and `-= de` on rejection:
-//     src/moves.jl:17,79).  Steps commit out of order, so every step logs (de, accepted) into a ring and one wavefront
-//     folds the contiguous finished prefix in step order (sq_walk).
+//     src/moves.jl:17,79) -- host code in the reference too (Arianna.perform_action!, src/moves.jl:11-20).  Steps commit
+//     out of order, so every step logs (de, accepted) into a ring by step counter and the HOST folds the contiguous
+//     finished prefix in step order between batches of rounds (seq_fold): a serial chain of dependent FP64 additions
+//     is the one thing on this path a CPU core does faster than a wavefront.
 //   * A rejected step is perform + revert: x + d + (-d) is stored (it can differ from x in the last bit), and a trial
 //     that left its cell relinks twice, which moves i to the front of its chain (src/neighbours.jl:276-302 twice).  Both
 //     are state changes like an accepted move.
@@ -40,7 +42,7 @@
 
 #define SQ_KMAX 4096                 // window slots (bit-matrix rows of SQ_KMAX / 64 words)
 #define SQ_KW (SQ_KMAX / 64)
-#define SQ_RING 65536                // per-step log ring (de, flags), folded in step order by sq_walk
+#define SQ_RING_MAX (1 << 20)        // per-step log ring (de, flags): the host folds it into system.energy in step order
 #define SQ_GEN 262144                // ring of pre-generated random parts
 #define SQ_FILL_THREADS 1024
 
@@ -56,6 +58,12 @@ enum {
 };
 
 enum { SQL_DONE = 1, SQL_ACCEPT = 2, SQL_FINITE = 4, SQL_NULL = 8 };   // log flags; move index in bits 4..6
+
+struct SqLog {           // one committed step, as Arianna.perform_action! / revert_action! see it (src/moves.jl:11-20,79,206)
+    double de;
+    uint32_t tag;        // low word of the step counter: tells a record of this lap of the ring from the last lap's
+    int flag;            // SQL_*
+};
 
 struct SqGen {           // random part of one step: a pure function of (key, step)
     double lnu;
@@ -78,14 +86,14 @@ struct __attribute__((aligned(16))) SqSlot {
 struct SqCtl {
     unsigned long long next;      // first step not yet admitted
     unsigned long long gend;      // one past the last step of the call
-    unsigned long long prefix;    // steps < prefix are folded into energy / att / acc
-    double energy;                // system.energy[1]
-    unsigned long long att[8], acc[8];
+    unsigned long long prefix;    // steps < prefix are folded into system.energy by the host: their ring records are free
     int nslots;
     int trunc;                    // slots >= trunc are held back this round (an exotic step waits to be first)
     int exclusive;                // slot 0 is exotic: only it commits
     int err;                      // 1: a cell row overflowed, 2: a particle was not in its row
     unsigned long long rounds, evals, commits;   // diagnostics
+    int f_nold, f_nkeep;          // k_sq_fill -> k_sq_prep: slots of the old window, held-back steps among them
+    unsigned long long f_next0;   // ... and the step of the first candidate
 };
 
 struct SqArgs {
@@ -95,9 +103,10 @@ struct SqArgs {
     const SqGen *gen;
     unsigned long long *M;        // [K][SQ_KW] conflict bits with earlier slots
     unsigned long long *cp;       // [SQ_KW]: slot changes state or has an earlier potential conflict
-    int *owner;                   // [N]: INT_MAX free, -1 owned by a pending slot, else the claiming candidate
-    double *log_de;               // [SQ_RING]
-    int *log_flag;                // [SQ_RING]
+    int *moveto;                  // [K] k_sq_fill -> k_sq_prep: new index of an old slot, -1 if it committed
+    int *cand;                    // [K][3] ... and the admitted steps: i, j, flags
+    SqLog *log;                   // [ring_mask + 1] what every committed step did to system.energy, by step
+    unsigned long long ring_mask;
     SqCtl *ctl;
     MovePool pool;
     int K;                        // window slots in use (<= SQ_KMAX, multiple of 64)
@@ -105,6 +114,7 @@ struct SqArgs {
     int reverse;                  // 1: LinkedList (chain = row read backwards), 0: CellList (vector order)
     int ids_cap;                  // ints of dynamic LDS of the evaluation (>= 3^d * cl_cap)
     unsigned long long gen_hi;    // steps < gen_hi have their random part in the ring
+    int dbg;                      // PMC_SEQ_DBG (timing experiments only): 1 no energy fold inside the rounds, 2 no pair matrix, 4 no evaluation
 };
 
 // ---- random parts ------------------------------------------------------------------------------------------------------
@@ -181,6 +191,13 @@ __device__ __forceinline__ double sq_dist2(const SqArgs &s, const double *xi, co
     return r2;
 }
 
+__device__ __forceinline__ int __reduce_max_sync_compat(int v)
+{
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v = max(v, __shfl_xor(v, sft, PMC_WAVE));
+    return v;
+}
+
 // acc += u for the lanes whose u is not 0, in lane order (a zero term leaves an FP64 sum as it is)
 __device__ __forceinline__ double sq_ordered_add(double acc, double u)
 {
@@ -194,9 +211,12 @@ __device__ __forceinline__ double sq_ordered_add(double acc, double u)
 }
 
 // The ids the iterator of the list yields for a particle in cell c, in order, into LDS (i itself is among them where the
-// current rows have it: its term is 0 wherever it stands).  Returns their number.
+// current rows have it: its term is 0 wherever it stands).  Returns their number.  One row = one coalesced load, and the
+// loads of all 3^d rows are in flight together.
+template <int D>
 __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids)
 {
+    constexpr int NN = (D == 3) ? 27 : 9;
     const RefArgs &a = s.a;
     const int lane = wave_lane();
     const int cnt = a.nbrcnt[c];
@@ -210,13 +230,33 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids)
     }
     const int off = incl - len;
     const int total = __shfl(incl, 31, PMC_WAVE);
-    const int *row = a.cl_items + (size_t)cc * a.cl_cap;
+    const int maxlen = __reduce_max_sync_compat(len);
     __syncthreads();                              // the previous pass has read its ids
-    for (int k = 0; __any(k < len); k++)
-        if (k < len) lds_ids[off + k] = row[s.reverse ? len - 1 - k : k];
+    int v[NN];
+#pragma unroll
+    for (int l = 0; l < NN; l++) {
+        const int len_l = __builtin_amdgcn_readlane(len, l);
+        const int cc_l = __builtin_amdgcn_readlane(cc, l);
+        v[l] = a.cl_items[(size_t)cc_l * a.cl_cap + (lane < len_l ? lane : 0)];
+    }
+#pragma unroll
+    for (int l = 0; l < NN; l++) {
+        const int len_l = __builtin_amdgcn_readlane(len, l);
+        const int off_l = __builtin_amdgcn_readlane(off, l);
+        if (lane < len_l) lds_ids[off_l + (s.reverse ? len_l - 1 - lane : lane)] = v[l];
+    }
+    if (maxlen > PMC_WAVE) {                      // rows longer than a wavefront (dense cells, long cutoffs)
+        for (int l = 0; l < cnt; l++) {
+            const int len_l = __shfl(len, l, PMC_WAVE), cc_l = __shfl(cc, l, PMC_WAVE), off_l = __shfl(off, l, PMC_WAVE);
+            for (int k = PMC_WAVE + lane; k < len_l; k += PMC_WAVE)
+                lds_ids[off_l + (s.reverse ? len_l - 1 - k : k)] = a.cl_items[(size_t)cc_l * a.cl_cap + k];
+        }
+    }
     __syncthreads();
     return total;
 }
+
+#define SQ_CHUNK 4          // trips of 64 candidates whose position loads are in flight together
 
 // compute_energy_particle (src/atoms.jl:81-88) of particle i, species spi, at xa (and, when BOTH, at xb over the same
 // neighbour sequence) for a particle whose iterator runs over the neighbourhood of cell c
@@ -226,28 +266,39 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
-    const int total = sq_sequence(s, c, lds_ids);
+    const int total = sq_sequence<D>(s, c, lds_ids);
     double acc_a = 0.0, acc_b = 0.0;
-    for (int base = 0; base < total; base += PMC_WAVE) {
-        const int n = min(PMC_WAVE, total - base);
-        double ua = 0.0, ub = 0.0;
-        if (lane < n) {
-            const int j = lds_ids[base + lane];
-            if (j != i) {                                                    // src/atoms.jl:68
-                double xj[3] = {0, 0, 0};
+    for (int base = 0; base < total; base += SQ_CHUNK * PMC_WAVE) {
+        int j[SQ_CHUNK], sj[SQ_CHUNK];
+        double xj[SQ_CHUNK][3];
 #pragma unroll
-                for (int q = 0; q < D; q++) xj[q] = a.pos[(size_t)j * D + q];
-                const DevModel &m = a.models[spi * a.S + (a.S > 1 ? a.species[j] : 0)];
-                const double r2a = sq_dist2<D>(s, xa, xj);
+        for (int u = 0; u < SQ_CHUNK; u++) {
+            const int t = base + u * PMC_WAVE + lane;
+            j[u] = (t < total) ? lds_ids[t] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < SQ_CHUNK; u++) {
+            const int jj = j[u] < 0 ? 0 : j[u];
+#pragma unroll
+            for (int q = 0; q < 3; q++) xj[u][q] = (q < D) ? a.pos[(size_t)jj * D + q] : 0.0;
+            sj[u] = (a.S > 1) ? a.species[jj] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SQ_CHUNK; u++) {
+            if (base + u * PMC_WAVE >= total) break;
+            double ua = 0.0, ub = 0.0;
+            if (j[u] >= 0 && j[u] != i) {                                        // src/atoms.jl:68
+                const DevModel &m = a.models[spi * a.S + sj[u]];
+                const double r2a = sq_dist2<D>(s, xa, xj[u]);
                 if (!(r2a > m.rcut2)) ua = dev_potential_dyn(r2a, m);          // src/atoms.jl:72-73
                 if (BOTH) {
-                    const double r2b = sq_dist2<D>(s, xb, xj);
+                    const double r2b = sq_dist2<D>(s, xb, xj[u]);
                     if (!(r2b > m.rcut2)) ub = dev_potential_dyn(r2b, m);
                 }
             }
+            acc_a = sq_ordered_add(acc_a, ua);
+            if (BOTH) acc_b = sq_ordered_add(acc_b, ub);
         }
-        acc_a = sq_ordered_add(acc_a, ua);
-        if (BOTH) acc_b = sq_ordered_add(acc_b, ub);
     }
     ea = acc_a;
     eb = acc_b;
@@ -261,27 +312,37 @@ __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int 
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
-    const int total = sq_sequence(s, c, lds_ids);
+    const int total = sq_sequence<D>(s, c, lds_ids);
     double acc_a = 0.0, acc_b = 0.0;
-    for (int base = 0; base < total; base += PMC_WAVE) {
-        const int n = min(PMC_WAVE, total - base);
-        double ua = 0.0, ub = 0.0;
-        if (lane < n) {
-            const int j = lds_ids[base + lane];
-            if (j != i) {
-                double xj[3] = {0, 0, 0};
+    for (int base = 0; base < total; base += SQ_CHUNK * PMC_WAVE) {
+        int j[SQ_CHUNK], sj[SQ_CHUNK];
+        double xj[SQ_CHUNK][3];
 #pragma unroll
-                for (int q = 0; q < D; q++) xj[q] = a.pos[(size_t)j * D + q];
-                const int spj = a.species[j];
-                const double r2 = sq_dist2<D>(s, xi, xj);
-                const DevModel &m1 = a.models[sp1 * a.S + spj];
+        for (int u = 0; u < SQ_CHUNK; u++) {
+            const int t = base + u * PMC_WAVE + lane;
+            j[u] = (t < total) ? lds_ids[t] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < SQ_CHUNK; u++) {
+            const int jj = j[u] < 0 ? 0 : j[u];
+#pragma unroll
+            for (int q = 0; q < 3; q++) xj[u][q] = (q < D) ? a.pos[(size_t)jj * D + q] : 0.0;
+            sj[u] = a.species[jj];
+        }
+#pragma unroll
+        for (int u = 0; u < SQ_CHUNK; u++) {
+            if (base + u * PMC_WAVE >= total) break;
+            double ua = 0.0, ub = 0.0;
+            if (j[u] >= 0 && j[u] != i) {
+                const double r2 = sq_dist2<D>(s, xi, xj[u]);
+                const DevModel &m1 = a.models[sp1 * a.S + sj[u]];
                 if (!(r2 > m1.rcut2)) ua = dev_potential_dyn(r2, m1);
-                const DevModel &m2 = a.models[sp2 * a.S + (j == other ? sp1 : spj)];
+                const DevModel &m2 = a.models[sp2 * a.S + (j[u] == other ? sp1 : sj[u])];
                 if (!(r2 > m2.rcut2)) ub = dev_potential_dyn(r2, m2);
             }
+            acc_a = sq_ordered_add(acc_a, ua);
+            acc_b = sq_ordered_add(acc_b, ub);
         }
-        acc_a = sq_ordered_add(acc_a, ua);
-        acc_b = sq_ordered_add(acc_b, ub);
     }
     e_before = acc_a;
     e_after = acc_b;
@@ -376,6 +437,14 @@ __device__ __forceinline__ bool sq_near(int u, int v, int nc)
 }
 
 template <int D>
+__device__ __forceinline__ bool sq_cells_near(const RefArgs &a, int ux, int uy, int uz, int vx, int vy, int vz)
+{
+    bool hit = sq_near(ux, vx, a.nc[0]) && sq_near(uy, vy, a.nc[1]);
+    if (D == 3) hit = hit && sq_near(uz, vz, a.nc[2]);
+    return hit;
+}
+
+template <int D>
 __device__ __forceinline__ void sq_pairs(const SqArgs &s, int wordw, int wordt)
 {
     const int lane = wave_lane();
@@ -388,26 +457,28 @@ __device__ __forceinline__ void sq_pairs(const SqArgs &s, int wordw, int wordt)
         if (w < nslots) { p0 = slots[w].pk[0]; p1 = slots[w].pk[1]; p2 = slots[w].pk[2]; has = slots[w].pk[3]; }
         const int wx0 = p0 & 0xffff, wy0 = (p0 >> 16) & 0xffff, wz0 = p1 & 0xffff;
         const int wx1 = (p1 >> 16) & 0xffff, wy1 = p2 & 0xffff, wz1 = (p2 >> 16) & 0xffff;
+        const bool wtwo = has && (wx1 != wx0 || wy1 != wy0 || wz1 != wz0);
+        const bool anytwo = __any(wtwo);                   // most steps stay in their cell: one cell pair to test, not four
         const int tend = min(64, nslots - wordt * 64);
+        int t0 = 0, t1 = 0, t2 = 0, t3 = 0;                  // lane l holds the cells of slot wordt * 64 + l
+        if (lane < tend) {
+            const SqSlot &ts = slots[wordt * 64 + lane];
+            t0 = ts.pk[0]; t1 = ts.pk[1]; t2 = ts.pk[2]; t3 = ts.pk[3];
+        }
         for (int tt = 0; tt < tend; tt++) {
             const int t = wordt * 64 + tt;
-            const int q0 = slots[t].pk[0], q1 = slots[t].pk[1], q2 = slots[t].pk[2], thas = slots[t].pk[3];   // wave-uniform
+            const int thas = __builtin_amdgcn_readlane(t3, tt);
             if (!thas) continue;
+            const int q0 = __builtin_amdgcn_readlane(t0, tt), q1 = __builtin_amdgcn_readlane(t1, tt), q2 = __builtin_amdgcn_readlane(t2, tt);
             const int tx0 = q0 & 0xffff, ty0 = (q0 >> 16) & 0xffff, tz0 = q1 & 0xffff;
             const int tx1 = (q1 >> 16) & 0xffff, ty1 = q2 & 0xffff, tz1 = (q2 >> 16) & 0xffff;
-            bool hit;
-            if (D == 3) {
-                hit = (sq_near(wx0, tx0, s.a.nc[0]) && sq_near(wy0, ty0, s.a.nc[1]) && sq_near(wz0, tz0, s.a.nc[2])) ||
-                      (sq_near(wx0, tx1, s.a.nc[0]) && sq_near(wy0, ty1, s.a.nc[1]) && sq_near(wz0, tz1, s.a.nc[2])) ||
-                      (sq_near(wx1, tx0, s.a.nc[0]) && sq_near(wy1, ty0, s.a.nc[1]) && sq_near(wz1, tz0, s.a.nc[2])) ||
-                      (sq_near(wx1, tx1, s.a.nc[0]) && sq_near(wy1, ty1, s.a.nc[1]) && sq_near(wz1, tz1, s.a.nc[2]));
-            } else {
-                hit = (sq_near(wx0, tx0, s.a.nc[0]) && sq_near(wy0, ty0, s.a.nc[1])) ||
-                      (sq_near(wx0, tx1, s.a.nc[0]) && sq_near(wy0, ty1, s.a.nc[1])) ||
-                      (sq_near(wx1, tx0, s.a.nc[0]) && sq_near(wy1, ty0, s.a.nc[1])) ||
-                      (sq_near(wx1, tx1, s.a.nc[0]) && sq_near(wy1, ty1, s.a.nc[1]));
+            bool hit = sq_cells_near<D>(s.a, wx0, wy0, wz0, tx0, ty0, tz0);
+            if (anytwo) hit = hit || sq_cells_near<D>(s.a, wx1, wy1, wz1, tx0, ty0, tz0);
+            if (tx1 != tx0 || ty1 != ty0 || tz1 != tz0) {
+                hit = hit || sq_cells_near<D>(s.a, wx0, wy0, wz0, tx1, ty1, tz1);
+                if (anytwo) hit = hit || sq_cells_near<D>(s.a, wx1, wy1, wz1, tx1, ty1, tz1);
             }
-            if (hit && has && t < w && w < nslots) bits |= 1ull << tt;
+            if (hit && has && t < w) bits |= 1ull << tt;
         }
     }
     if (w < s.K) s.M[(size_t)w * SQ_KW + wordt] = bits;
@@ -415,56 +486,7 @@ __device__ __forceinline__ void sq_pairs(const SqArgs &s, int wordw, int wordt)
     if (lane == 0 && any) atomicOr(&s.cp[wordw], any);       // P: the slot has an earlier potential conflict
 }
 
-// ---- system.energy[1] and the counters, folded in step order ------------------------------------------------------------------
-__device__ __forceinline__ void sq_walk(const SqArgs &s)
-{
-    SqCtl *ctl = s.ctl;
-    const int lane = wave_lane();
-    unsigned long long prefix = ctl->prefix;
-    const unsigned long long gend = ctl->gend;
-    double E = ctl->energy;
-    unsigned long long att[8], acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) { att[q] = 0; acc[q] = 0; }
-    for (;;) {
-        const unsigned long long g = prefix + (unsigned long long)lane;
-        const int idx = (int)(g % SQ_RING);
-        int f = 0;
-        double de = 0.0;
-        if (g < gend) { f = s.log_flag[idx]; de = s.log_de[idx]; }
-        const unsigned long long donemask = __ballot(f & SQL_DONE);
-        const int ndone = (donemask == ~0ull) ? 64 : (int)__builtin_ctzll(~donemask);   // the contiguous finished prefix
-        if (ndone == 0) break;
-        if (lane < ndone) s.log_flag[idx] = 0;
-        const unsigned long long in = (ndone == 64) ? ~0ull : ((1ull << ndone) - 1);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const unsigned long long mq = __ballot(((f >> 4) & 7) == q) & in;
-            att[q] += __popcll(mq);
-            acc[q] += __popcll(mq & __ballot(f & SQL_ACCEPT));
-        }
-        unsigned long long ops = __ballot((f & SQL_FINITE) && !(f & SQL_NULL)) & in;
-        const unsigned long long rej = __ballot(!(f & SQL_ACCEPT));
-        while (ops) {
-            const int k = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(ops));
-            const double dk = readlane_double(de, k);
-            E += dk;                                   // src/moves.jl:17
-            if ((rej >> k) & 1) E -= dk;               // src/moves.jl:79, 206
-            ops &= ops - 1;
-        }
-        prefix += (unsigned long long)ndone;
-        if (ndone < 64) break;
-    }
-    if (lane == 0) {
-        ctl->prefix = prefix;
-        ctl->energy = E;
-        for (int q = 0; q < 8; q++) { ctl->att[q] += att[q]; ctl->acc[q] += acc[q]; }
-    }
-}
-
-PMC_GLOBAL __launch_bounds__(64) void k_sq_walk(SqArgs s) { sq_walk(s); }
-
-// ---- round, first launch: evaluation of every pending step | pair matrix | energy fold --------------------------------------
+// ---- round, third launch: evaluation of every pending step | pair matrix --------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void k_sq_round_a(SqArgs s)
 {
@@ -472,16 +494,14 @@ __global__ __launch_bounds__(64) void k_sq_round_a(SqArgs s)
     const int b = blockIdx.x;
     const int kw = s.K / 64;
     if (b < s.K) {
-        if (b < s.ctl->nslots) sq_eval<D>(s, b, sq_lds);
-    } else if (b < s.K + kw * kw) {
-        const int t = b - s.K;
-        sq_pairs<D>(s, t / kw, t % kw);
+        if (b < s.ctl->nslots && !(s.dbg & 4)) sq_eval<D>(s, b, sq_lds);
     } else {
-        sq_walk(s);
+        const int t = b - s.K;
+        if (!(s.dbg & 2)) sq_pairs<D>(s, t / kw, t % kw);
     }
 }
 
-// ---- round, second launch: decide and apply ------------------------------------------------------------------------------------
+// ---- round, fourth launch: decide and apply ------------------------------------------------------------------------------------
 // update_neighbour_list! (src/neighbours.jl:276-302, CellList :162-170) as row operations; whole wavefront
 __device__ __forceinline__ void sq_row_remove(const SqArgs &s, int c, int i)
 {
@@ -583,23 +603,22 @@ __global__ __launch_bounds__(64) void k_sq_commit(SqArgs s)
         }
     }
     if (lane == 0) {
-        const int idx = (int)(sl.g % SQ_RING);
-        s.log_de[idx] = sl.de;
+        SqLog &lg = s.log[sl.g & s.ring_mask];
+        lg.de = sl.de;
+        lg.tag = (uint32_t)sl.g;
         int f = SQL_DONE | (sl.m << 4);
         if (flags & SQF_ACCEPT) f |= SQL_ACCEPT;
         if (flags & SQF_FINITE) f |= SQL_FINITE;
         if (flags & SQF_NULL) f |= SQL_NULL;
-        s.log_flag[idx] = f;
+        lg.flag = f;
         sl.flags = flags | SQF_COMMITTED;
-        if (!(flags & SQF_NULL)) {
-            s.owner[i] = INT_MAX;
-            if (flags & SQF_SWAP) s.owner[sl.j] = INT_MAX;
-        }
     }
 }
 
-// ---- round, third launch (first of the next round): drop the committed steps, admit new ones in step order ----------------------
-// one workgroup; writes slots[cur ^ 1] from slots[cur]
+// ---- round, first launch: drop the committed steps, admit new ones in step order ------------------------------------------------
+// One workgroup; writes slots[cur ^ 1] from slots[cur].  No two pending steps may share a particle: the particles of the
+// steps that stay and of the candidates go into a hash table in LDS (value = the smallest claimant, -1 for a pending step);
+// admission stops at the first candidate that does not hold all its particles.
 __device__ __forceinline__ int sq_block_scan_excl(int v, int *lds, int *total)
 {
     // exclusive scan over the workgroup (SQ_FILL_THREADS threads), wave scan + scan of the 16 wave totals
@@ -623,70 +642,115 @@ __device__ __forceinline__ int sq_block_scan_excl(int v, int *lds, int *total)
     return base + incl - v;
 }
 
+__device__ __forceinline__ unsigned sq_hash(int id) { return (unsigned)id * 2654435761u; }
+
+__device__ __forceinline__ void sq_table_claim(int *keys, int *vals, unsigned mask, int id, int claimant)
+{
+    unsigned hh = (sq_hash(id) >> 7) & mask;
+    for (;;) {
+        const int old = atomicCAS(&keys[hh], -1, id);
+        if (old == -1 || old == id) { atomicMin(&vals[hh], claimant); return; }
+        hh = (hh + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int sq_table_owner(const int *keys, const int *vals, unsigned mask, int id)
+{
+    unsigned hh = (sq_hash(id) >> 7) & mask;
+    while (keys[hh] != id) hh = (hh + 1) & mask;
+    return vals[hh];
+}
+
 template <int D>
 __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(SqArgs s)
 {
+    extern __shared__ int sq_table[];            // keys[4 K], vals[4 K]
     __shared__ int lds[SQ_FILL_THREADS / 64 + 2];
     const RefArgs &a = s.a;
     SqCtl *ctl = s.ctl;
     const SqSlot *src = s.slots[s.cur];
-    SqSlot *dst = s.slots[s.cur ^ 1];
     const int tid = threadIdx.x;
+    const unsigned tmask = (unsigned)(4 * s.K - 1);          // the host keeps K a power of two
+    int *keys = sq_table, *vals = sq_table + 4 * s.K;
     const int nold = ctl->nslots;
+    const unsigned long long next = ctl->next;
+    unsigned long long lim = ctl->gend;
+    if (s.gen_hi < lim) lim = s.gen_hi;
+    if (ctl->prefix + s.ring_mask + 1 < lim) lim = ctl->prefix + s.ring_mask + 1;
+    const int maxcand = (lim <= next) ? 0 : (int)min((unsigned long long)s.K, lim - next);
+    for (int k = tid; k < 4 * s.K; k += SQ_FILL_THREADS) { keys[k] = -1; vals[k] = INT_MAX; }
     constexpr int PER = SQ_KMAX / SQ_FILL_THREADS;
+    // -- the particle words of every step that could be admitted: loads that do not wait for anything below
+    int gm[PER];
+    uint32_t gr1[PER], gq0[PER];
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int q = r * SQ_FILL_THREADS + tid;
+        gm[r] = 0; gr1[r] = 0; gq0[r] = 0;
+        if (q < maxcand) {
+            const SqGen &ge = s.gen[(next + (unsigned long long)q) % SQ_GEN];
+            gm[r] = ge.m; gr1[r] = ge.r1; gq0[r] = ge.q0;
+        }
+    }
     // -- keep the held-back steps, in order
     int nkeep = 0;
     for (int r = 0; r < PER; r++) {
         const int w = r * SQ_FILL_THREADS + tid;
-        const bool keep = (w < nold) && !(src[w].flags & SQF_COMMITTED);
+        int fl = SQF_COMMITTED, pi = -1, pj = -1;
+        if (w < nold) { fl = src[w].flags; pi = src[w].i; pj = src[w].j; }
+        const bool keep = !(fl & SQF_COMMITTED);
         int tot;
-        const int at = nkeep + sq_block_scan_excl(keep ? 1 : 0, lds, &tot);
-        if (keep) dst[at] = src[w];
+        const int at = nkeep + sq_block_scan_excl(keep ? 1 : 0, lds, &tot);   // (its barriers also cover the table's initialisation)
+        if (w < nold) s.moveto[w] = keep ? at : -1;
+        if (keep) {
+            if (pi >= 0) sq_table_claim(keys, vals, tmask, pi, -1);
+            if (pj >= 0) sq_table_claim(keys, vals, tmask, pj, -1);
+        }
         nkeep += tot;
         if (r * SQ_FILL_THREADS + SQ_FILL_THREADS >= nold) break;
     }
-    // -- admit new steps up to the first one that shares a particle with a pending step
-    const unsigned long long next = ctl->next;
-    unsigned long long lim = ctl->gend;
-    if (s.gen_hi < lim) lim = s.gen_hi;
-    if (ctl->prefix + SQ_RING < lim) lim = ctl->prefix + SQ_RING;
-    int avail = s.K - nkeep;
-    if (lim <= next) avail = 0;
-    else if ((unsigned long long)avail > lim - next) avail = (int)(lim - next);
-    int ci[PER], cj[PER], cm[PER], cf[PER];
+    // -- candidates in step order
+    const int avail = min(s.K - nkeep, maxcand);
+    int ci[PER], cj[PER], cf[PER];
+#pragma unroll
     for (int r = 0; r < PER; r++) {
         const int q = r * SQ_FILL_THREADS + tid;
-        ci[r] = -1; cj[r] = -1; cm[r] = 0; cf[r] = 0;
+        ci[r] = -1; cj[r] = -1; cf[r] = 0;
         if (q < avail) {
-            const SqGen &ge = s.gen[(next + (unsigned long long)q) % SQ_GEN];
-            const int m = ge.m;
-            cm[r] = m;
+            const int m = gm[r];
             if (s.pool.kind[m] == 0) {
-                ci[r] = (int)mulhi32(ge.r1, (uint32_t)a.N);                      // src/moves.jl:120-123
+                ci[r] = (int)mulhi32(gr1[r], (uint32_t)a.N);                      // src/moves.jl:120-123
             } else {
                 const int sa = s.pool.sp0[m], sb = s.pool.sp1[m];
                 const int na = a.sp_off[sa + 1] - a.sp_off[sa], nb = a.sp_off[sb + 1] - a.sp_off[sb];
                 cf[r] = SQF_SWAP;
                 if (na > 0 && nb > 0) {
-                    ci[r] = a.sp_ids[a.sp_off[sa] + mulhi32(ge.r1, (uint32_t)na)];   // src/moves.jl:238-241
-                    cj[r] = a.sp_ids[a.sp_off[sb] + mulhi32(ge.q0, (uint32_t)nb)];
+                    ci[r] = a.sp_ids[a.sp_off[sa] + mulhi32(gr1[r], (uint32_t)na)];   // src/moves.jl:238-241
+                    cj[r] = a.sp_ids[a.sp_off[sb] + mulhi32(gq0[r], (uint32_t)nb)];
                 } else {
                     cf[r] |= SQF_NULL;
                 }
             }
-            if (ci[r] >= 0) atomicMin(&s.owner[ci[r]], q);
-            if (cj[r] >= 0) atomicMin(&s.owner[cj[r]], q);
         }
     }
-    __threadfence();
+    __syncthreads();                                   // the pending steps' claims are in the table
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int q = r * SQ_FILL_THREADS + tid;
+        if (q < avail) {
+            if (ci[r] >= 0) sq_table_claim(keys, vals, tmask, ci[r], q);
+            if (cj[r] >= 0) sq_table_claim(keys, vals, tmask, cj[r], q);
+        }
+    }
     __syncthreads();
     int mycut = INT_MAX;
+#pragma unroll
     for (int r = 0; r < PER; r++) {
         const int q = r * SQ_FILL_THREADS + tid;
         if (q < avail) {
             bool lose = false;
-            if (ci[r] >= 0 && s.owner[ci[r]] != q) lose = true;
-            if (cj[r] >= 0 && (s.owner[cj[r]] != q || cj[r] == ci[r])) lose = true;
+            if (ci[r] >= 0 && sq_table_owner(keys, vals, tmask, ci[r]) != q) lose = true;
+            if (cj[r] >= 0 && (cj[r] == ci[r] || sq_table_owner(keys, vals, tmask, cj[r]) != q)) lose = true;
             if (lose) mycut = min(mycut, q);
         }
     }
@@ -698,46 +762,16 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(SqArgs s)
     int cut = INT_MAX;
     for (int q = 0; q < SQ_FILL_THREADS / 64; q++) cut = min(cut, lds[q]);
     const int nadm = min(cut, avail);
-    __syncthreads();
+#pragma unroll
     for (int r = 0; r < PER; r++) {
         const int q = r * SQ_FILL_THREADS + tid;
-        if (q >= avail) continue;
-        const int i = ci[r], j = cj[r];
-        if (q >= nadm) {                                                        // not admitted: give the claims back
-            if (i >= 0 && s.owner[i] == q) s.owner[i] = INT_MAX;
-            if (j >= 0 && s.owner[j] == q) s.owner[j] = INT_MAX;
-            continue;
-        }
-        const unsigned long long g = next + (unsigned long long)q;
-        const SqGen &ge = s.gen[g % SQ_GEN];
-        SqSlot sl;
-        sl.g = g;
-        sl.i = i; sl.j = j; sl.m = cm[r]; sl.flags = cf[r];
-        sl.c0 = sl.c1 = sl.c2 = 0; sl.spi = sl.spj = 0; sl.pad0 = sl.pad1 = sl.pad2 = 0;
-        sl.lnu = ge.lnu; sl.de = 0.0;
-        for (int k = 0; k < 3; k++) { sl.x[k] = 0; sl.d[k] = 0; sl.xn[k] = 0; sl.xr[k] = 0; }
-        sl.pk[0] = sl.pk[1] = sl.pk[2] = sl.pk[3] = 0;
-        if (i >= 0) {
-            s.owner[i] = -1;
-            if (j >= 0) s.owner[j] = -1;
-#pragma unroll
-            for (int k = 0; k < D; k++) sl.x[k] = a.pos[(size_t)i * D + k];
-            if (j < 0) {
-#pragma unroll
-                for (int k = 0; k < D; k++) { sl.d[k] = ge.d[k]; sl.xn[k] = sl.x[k] + ge.d[k]; }
-            } else {
-#pragma unroll
-                for (int k = 0; k < D; k++) sl.xn[k] = a.pos[(size_t)j * D + k];     // swap: the partner's position
-            }
-            sl.c0 = ref_cell_of<D>(a, sl.x);
-            sl.c1 = ref_cell_of<D>(a, sl.xn);
-            sl.c2 = sl.c0;
-            sq_pack_cells<D>(a, sl.c0, sl.c1, sl.pk);
-        }
-        dst[nkeep + q] = sl;
+        if (q < nadm) { s.cand[3 * q] = ci[r]; s.cand[3 * q + 1] = cj[r]; s.cand[3 * q + 2] = cf[r]; }
     }
     if (tid < SQ_KW) s.cp[tid] = 0;
     if (tid == 0) {
+        ctl->f_nold = nold;
+        ctl->f_nkeep = nkeep;
+        ctl->f_next0 = next;
         ctl->nslots = nkeep + nadm;
         ctl->next = next + (unsigned long long)nadm;
         ctl->trunc = INT_MAX;
@@ -746,6 +780,51 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(SqArgs s)
         ctl->evals += (unsigned long long)(nkeep + nadm);
         ctl->commits += (unsigned long long)(nold - nkeep);
     }
+}
+
+// ---- round, second launch: the new window -- held-back steps moved up, admitted steps built (position, trial position, cells) ------
+// one thread per old slot and per admitted step; writes slots[cur] from slots[cur ^ 1] (the host has flipped cur)
+template <int D>
+__global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
+{
+    const RefArgs &a = s.a;
+    const SqCtl *ctl = s.ctl;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nold = ctl->f_nold, nkeep = ctl->f_nkeep;
+    const int nadm = ctl->nslots - nkeep;
+    SqSlot *dst = s.slots[s.cur];
+    if (t < nold) {
+        const int to = s.moveto[t];
+        if (to >= 0) dst[to] = s.slots[s.cur ^ 1][t];
+        return;
+    }
+    const int q = t - nold;
+    if (q >= nadm) return;
+    const unsigned long long g = ctl->f_next0 + (unsigned long long)q;
+    const SqGen &ge = s.gen[g % SQ_GEN];
+    const int i = s.cand[3 * q], j = s.cand[3 * q + 1];
+    SqSlot sl;
+    sl.g = g;
+    sl.i = i; sl.j = j; sl.m = ge.m; sl.flags = s.cand[3 * q + 2];
+    sl.c0 = sl.c1 = sl.c2 = 0; sl.spi = sl.spj = 0; sl.pad0 = sl.pad1 = sl.pad2 = 0;
+    sl.lnu = ge.lnu; sl.de = 0.0;
+    sl.pk[0] = sl.pk[1] = sl.pk[2] = sl.pk[3] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        sl.x[k] = (k < D && i >= 0) ? a.pos[(size_t)i * D + k] : 0.0;
+        sl.d[k] = ge.d[k];
+        sl.xn[k] = (k < D && i >= 0) ? ((j >= 0) ? a.pos[(size_t)j * D + k]      // DiscreteSwap: the partner's position
+                                               : sl.x[k] + ge.d[k])            // update_position! (src/moves.jl:46-48)
+                                   : 0.0;
+        sl.xr[k] = 0.0;
+    }
+    if (i >= 0) {                                       // (a null step has no cells and interacts with nothing)
+        sl.c0 = ref_cell_of<D>(a, sl.x);
+        sl.c1 = ref_cell_of<D>(a, sl.xn);
+        sl.c2 = sl.c0;
+        sq_pack_cells<D>(a, sl.c0, sl.c1, sl.pk);
+    }
+    dst[nkeep + q] = sl;
 }
 
 // rows of a LinkedList from the CSR the build leaves (ids ascending inside a cell = the chain read backwards): k_ref_cellvec

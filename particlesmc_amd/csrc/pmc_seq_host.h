@@ -1,8 +1,6 @@
 // pmc_seq_host.h -- host side of the fast reference-order engine (pmc_seq.h); included by pmc_hip.hip after the handle.
 #pragma once
 
-#define SQ_FREE_BYTE 0x7f          // owner table "free" = 0x7f7f7f7f: larger than any candidate index, settable with hipMemset
-
 static int seq_rows_cap(const pmc_system *h)
 {
     const double mean = (double)h->N / (double)h->ncell_ref;
@@ -52,7 +50,7 @@ static bool seq_fast_applicable(const pmc_system *h, const pmc_move *pool, int n
     return true;
 }
 
-static int seq_ensure(pmc_system *h)
+static int seq_ensure(pmc_system *h, int K)
 {
     if (!h->d_ref_err) {
         HIPCHK(h, hipMalloc(&h->d_ref_err, 16));
@@ -70,11 +68,20 @@ static int seq_ensure(pmc_system *h)
         HIPCHK(h, hipMalloc(&h->d_sq_gen, (size_t)SQ_GEN * sizeof(SqGen)));
         HIPCHK(h, hipMalloc(&h->d_sq_M, (size_t)SQ_KMAX * SQ_KW * sizeof(unsigned long long)));
         HIPCHK(h, hipMalloc(&h->d_sq_cp, (size_t)SQ_KW * sizeof(unsigned long long)));
-        HIPCHK(h, hipMalloc(&h->d_sq_owner, (size_t)h->N * sizeof(int)));
-        HIPCHK(h, hipMalloc(&h->d_sq_logflag, (size_t)SQ_RING * sizeof(int)));
-        HIPCHK(h, hipMalloc(&h->d_sq_logde, (size_t)SQ_RING * sizeof(double)));
+        HIPCHK(h, hipMalloc(&h->d_sq_moveto, (size_t)SQ_KMAX * 4 * sizeof(int)));
         HIPCHK(h, hipHostMalloc(&h->h_sq_ctl, sizeof(SqCtl)));
         HIPCHK(h, hipMalloc(&h->d_sq_ctl, sizeof(SqCtl)));
+    }
+    // the log ring: 64 windows' worth of steps between two folds (16 B per step, device + pinned host)
+    int ring = 4096;
+    while (ring < 64 * K && ring < SQ_RING_MAX) ring *= 2;
+    if (ring > h->sq_ring) {
+        if (h->d_sq_log) (void)hipFree(h->d_sq_log);
+        if (h->h_sq_log) (void)hipHostFree(h->h_sq_log);
+        h->d_sq_log = nullptr; h->h_sq_log = nullptr; h->sq_ring = 0;
+        HIPCHK(h, hipMalloc(&h->d_sq_log, (size_t)ring * sizeof(SqLog)));
+        HIPCHK(h, hipHostMalloc(&h->h_sq_log, (size_t)ring * sizeof(SqLog)));
+        h->sq_ring = ring;
     }
     return PMC_OK;
 }
@@ -90,23 +97,49 @@ static int seq_window(const pmc_system *h)
         if (const char *e = getenv("PMC_SEQ_WINDOW")) K = atoi(e);
         K = std::min(K, 2048);
     }
-    K = ((std::max(K, 1) + 63) / 64) * 64;
-    return std::min(K, SQ_KMAX);
+    int P = 64;                                             // a power of two (the fill kernel's hash table has 4 K entries)
+    while (P < K && P < SQ_KMAX) P *= 2;
+    return P;
+}
+
+// Arianna.perform_action! / revert_action! keep system.energy[1] on the host (src/moves.jl:11-20,79,206): `+= de` for
+// every step with finite energies, `-= de` again when the step is rejected, in step order.  The device logs (de, accepted)
+// per step; this folds the contiguous finished prefix.  Returns the new prefix.
+static unsigned long long seq_fold(const SqLog *log, unsigned long long mask, unsigned long long from, unsigned long long to,
+                                   double *energy, unsigned long long *att, unsigned long long *acc)
+{
+    double E = *energy;
+    unsigned long long g = from;
+    for (; g < to; g++) {
+        const SqLog &r = log[g & mask];
+        if (!(r.flag & SQL_DONE) || r.tag != (uint32_t)g) break;
+        const int m = (r.flag >> 4) & 7;
+        att[m]++;
+        if (r.flag & SQL_NULL) continue;
+        if (r.flag & SQL_ACCEPT) acc[m]++;
+        if (r.flag & SQL_FINITE) {
+            E += r.de;
+            if (!(r.flag & SQL_ACCEPT)) E -= r.de;
+        }
+    }
+    *energy = E;
+    return g;
 }
 
 // mc_sweep!(system, pool, rng; mc_steps = nsweeps N) as the reference runs it -- one particle per step, every step seeing
 // the state all earlier steps left (src/moves.jl:11-20,57-81,187-207) -- in speculative windows (pmc_seq.h).
 static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
 {
-    int rc = seq_ensure(h);
+    const int K = seq_window(h);
+    int rc = seq_ensure(h, K);
     if (rc) return rc;
     if (!h->cells_built) {
         rc = pmc_build_cells(h);
         if (rc) return rc;
     }
     if (int rs = refresh_stale_energy(h)) return rs;
-    const int K = seq_window(h);
     const long long nsteps = nsweeps * (int64_t)h->N;      // sweepstep = N, src/ParticlesMC.jl:246
+    const unsigned long long ring = (unsigned long long)h->sq_ring;
     SqArgs s;
     memset(&s, 0, sizeof s);
     s.a = ref_args(h);
@@ -116,40 +149,48 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
     s.gen = h->d_sq_gen;
     s.M = h->d_sq_M;
     s.cp = h->d_sq_cp;
-    s.owner = h->d_sq_owner;
-    s.log_de = h->d_sq_logde;
-    s.log_flag = h->d_sq_logflag;
+    s.log = h->d_sq_log;
+    s.ring_mask = ring - 1;
+    s.moveto = h->d_sq_moveto;
+    s.cand = h->d_sq_moveto + SQ_KMAX;
     s.ctl = h->d_sq_ctl;
     s.pool = make_pool(pool, npool);
     s.K = K;
     s.cur = 0;
     s.reverse = (h->list_type == 1) ? 1 : 0;
     s.ids_cap = h->nn * h->cl_cap;
+    if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
     const size_t lds = (size_t)s.ids_cap * sizeof(int);
     if (lds > 160 * 1024 - 256) return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
     if (lds > 48 * 1024) {
         if (h->D == 3) HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_round_a<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         else HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_round_a<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    const size_t lds_fill = (size_t)8 * K * sizeof(int);    // keys[4 K] + vals[4 K]
+    if (lds_fill > 48 * 1024) {
+        if (h->D == 3) HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_fill<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill));
+        else HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_fill<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill));
+    }
     SqCtl c0;
     memset(&c0, 0, sizeof c0);
     c0.next = c0.prefix = h->step_ctr;
     c0.gend = h->step_ctr + (unsigned long long)nsteps;
-    c0.energy = h->energy;
     c0.trunc = INT_MAX;
     *h->h_sq_ctl = c0;
     HIPCHK(h, hipMemcpyAsync(h->d_sq_ctl, h->h_sq_ctl, sizeof(SqCtl), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_sq_owner, SQ_FREE_BYTE, (size_t)h->N * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_sq_logflag, 0, (size_t)SQ_RING * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sq_log, 0, (size_t)ring * sizeof(SqLog), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));            // the pinned block is reused for the read-backs below
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    unsigned long long gen_hi = c0.next, next_known = c0.next, prefix_known = c0.prefix;
+    unsigned long long gen_hi = c0.next, next_known = c0.next, prefix = c0.prefix;
+    unsigned long long att[8] = {0}, acc[8] = {0};
+    double energy = h->energy;
     const int kw = K / 64;
-    const int grid_a = K + kw * kw + 1;
+    const int grid_a = K + kw * kw;
     double per_round = 0.5 * K;                             // steps a round finishes: learnt from the batches
     int cur = 0;
     long long guard = 0;
-    while (prefix_known < c0.gend) {
+    SqCtl c = c0;
+    while (prefix < c0.gend) {
         // random parts ahead of the admission front (the ring holds SQ_GEN steps; admitted steps have been copied out)
         unsigned long long target = std::min<unsigned long long>(c0.gend, next_known + SQ_GEN);
         if (gen_hi < target) {
@@ -162,54 +203,65 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
             gen_hi = target;
         }
         s.gen_hi = gen_hi;
-        const double left = (double)(c0.gend - prefix_known);
+        const double left = (double)(c0.gend - prefix);
         long long rounds = (long long)(left / std::max(per_round, 1.0)) + 2;
         rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)((gen_hi - next_known) / (unsigned long long)K)));
-        rounds = std::min<long long>(rounds, 256);
+        rounds = std::min<long long>(rounds, (long long)(ring / (2ull * K)));    // the log ring holds a batch and the window
         rounds = std::max<long long>(rounds, 1);
         for (long long r = 0; r < rounds; r++) {
             s.cur = cur;
-            if (h->D == 3) hipLaunchKernelGGL(k_sq_fill<3>, dim3(1), dim3(SQ_FILL_THREADS), 0, h->stream, s);
-            else hipLaunchKernelGGL(k_sq_fill<2>, dim3(1), dim3(SQ_FILL_THREADS), 0, h->stream, s);
+            if (h->D == 3) hipLaunchKernelGGL(k_sq_fill<3>, dim3(1), dim3(SQ_FILL_THREADS), lds_fill, h->stream, s);
+            else hipLaunchKernelGGL(k_sq_fill<2>, dim3(1), dim3(SQ_FILL_THREADS), lds_fill, h->stream, s);
             cur ^= 1;
             s.cur = cur;
             if (h->D == 3) {
+                hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256), dim3(256), 0, h->stream, s);
                 hipLaunchKernelGGL(k_sq_round_a<3>, dim3(grid_a), dim3(64), lds, h->stream, s);
                 hipLaunchKernelGGL(k_sq_commit<3>, dim3(K), dim3(64), 0, h->stream, s);
             } else {
+                hipLaunchKernelGGL(k_sq_prep<2>, dim3((2 * K + 255) / 256), dim3(256), 0, h->stream, s);
                 hipLaunchKernelGGL(k_sq_round_a<2>, dim3(grid_a), dim3(64), lds, h->stream, s);
                 hipLaunchKernelGGL(k_sq_commit<2>, dim3(K), dim3(64), 0, h->stream, s);
             }
         }
-        hipLaunchKernelGGL(k_sq_walk, dim3(1), dim3(64), 0, h->stream, s);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->h_sq_ctl, h->d_sq_ctl, sizeof(SqCtl), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        const SqCtl &c = *h->h_sq_ctl;
+        c = *h->h_sq_ctl;
         if (c.err) {
             h->cells_built = false;
             h->energy_stale = true;
             return fail(h, PMC_ERR_STATE, (c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
         }
-        const double done = (double)(c.prefix - prefix_known);
+        // the log records of [prefix, next): at most two contiguous pieces of the ring
+        if (c.next > prefix) {
+            const unsigned long long lo = prefix & s.ring_mask, n = c.next - prefix;
+            const unsigned long long n1 = std::min<unsigned long long>(n, ring - lo);
+            HIPCHK(h, hipMemcpyAsync(h->h_sq_log + lo, h->d_sq_log + lo, (size_t)n1 * sizeof(SqLog), hipMemcpyDeviceToHost, h->stream));
+            if (n > n1) HIPCHK(h, hipMemcpyAsync(h->h_sq_log, h->d_sq_log, (size_t)(n - n1) * sizeof(SqLog), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        const unsigned long long before = prefix;
+        prefix = seq_fold(h->h_sq_log, s.ring_mask, prefix, c.next, &energy, att, acc);
+        HIPCHK(h, hipMemcpyAsync(&h->d_sq_ctl->prefix, &prefix, sizeof prefix, hipMemcpyHostToDevice, h->stream));
+        const double done = (double)(prefix - before);
         if (done > 0) per_round = std::max(1.0, done / (double)rounds);
         next_known = c.next;
-        prefix_known = c.prefix;
         if (done == 0 && ++guard > 8) return fail(h, PMC_ERR_STATE, "sequential engine: no progress");
         if (done > 0) guard = 0;
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[1]));
-    const SqCtl &c = *h->h_sq_ctl;
+    c.prefix = prefix;
     h->sq_last = c;
-    h->energy = c.energy;
+    h->energy = energy;
     h->step_ctr += (uint64_t)nsteps;
     h->sweep_ctr += (uint64_t)nsweeps;
     h->mc_binned = false;
     h->e_fix_valid = false;
     h->img_valid = false;
     if (out) {
-        for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)c.att[m]; out->accepted[m] = (int64_t)c.acc[m]; }
+        for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)att[m]; out->accepted[m] = (int64_t)acc[m]; }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
         out->kernel_ms = ms;
