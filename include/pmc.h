@@ -217,9 +217,13 @@ int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
  * system.energy[1]).  engine 1: one wavefront takes the steps of src/moves.jl:57-81 literally, one after the other.  engine 2:
  * speculative windows -- the random part of a step is a function of the step counter, a step only reads and writes the
  * neighbour cells of its particle (src/neighbours.jl:94-111,316-377), so a window of pending steps is evaluated at once and
- * every step that no earlier pending step can have influenced commits.  engine 0 (default): 2 for LinkedList /
- * CellList, 1 for EmptyList / VerletList and for swap moves between a species and itself.  window: pending steps per round
- * (0: chosen from the cell count; at most 4096). */
+ * every step that no earlier pending step can have influenced commits.  engine 3: the whole state of a small
+ * system (positions, species, cell rows, SpeciesList: up to 160 KB) lives in LDS and one wavefront walks the chain with no
+ * global-memory traffic; pmc_sweep_many runs any number of such chains of one shape in one launch (the reference's own
+ * workloads: benchmark/particles_benchmarks.jl:10-28, N = 216; test/ss142d.jl:8-21, 100 chains of N = 8).  engine 0 (default):
+ * 3 for LinkedList / CellList systems of at most 7 cells per side whose state fits 64 KB, else 2; 1 for EmptyList / VerletList
+ * and for swap moves between a species and itself.  window: pending steps per round of engine 2 (0: chosen from the cell
+ * count; at most 4096). */
 int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window);
 /* diagnostics of the last PMC_SEQUENTIAL call that ran engine 2: out[0] rounds, out[1] step evaluations, out[2] window,
  * out[3] steps folded into system.energy */

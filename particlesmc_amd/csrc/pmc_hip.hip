@@ -1693,8 +1693,10 @@ extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const dou
 extern "C" int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: null handle");
-    if (engine < 0 || engine > 2 || window < 0 || window > SQ_KMAX)
-        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront) or 2 (speculative windows); window 0..4096");
+    if (engine < 0 || engine > 3 || window < 0 || window > SQ_KMAX)
+        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront), 2 (speculative windows) or 3 (state in LDS); window 0..4096");
+    if (engine == 3 && !seq_lds_fits(h, SQ_LDS_MAX))
+        return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 3 needs a LinkedList or CellList system whose state fits 160 KB of LDS");
     if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     h->seq_engine = engine;
     h->seq_window = window;
@@ -1713,7 +1715,13 @@ extern "C" int pmc_sequential_info(pmc_system *h, int64_t *out)
 
 static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
 {
-    if (nsweeps > 0 && seq_fast_applicable(h, pool, npool)) return sweep_sequential_fast(h, pool, npool, nsweeps, out);
+    if (nsweeps > 0 && seq_pool_ok(pool, npool) && h->seq_engine != 1 && h->seq_engine != 2 &&
+        (h->seq_engine == 3 || (h->ncell_ref <= 343 && seq_lds_fits(h, SQ_LDS_AUTO)))) {
+        // few cells per side: every step interacts with every other, and the whole state fits the LDS (pmc_seq.h, engine 3)
+        pmc_system *one[1] = {h};
+        return sweep_sequential_lds(one, 1, pool, npool, nsweeps, out);
+    }
+    if (nsweeps > 0 && h->seq_engine != 3 && seq_fast_applicable(h, pool, npool)) return sweep_sequential_fast(h, pool, npool, nsweeps, out);
     if (!h->cells_built) {
         int rc = pmc_build_cells(h);
         if (rc) return rc;
@@ -2135,6 +2143,16 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         if (int rc = validate_pool(hs[r], pool, npool, nsweeps)) return rc;
     }
     if (out) memset(out, 0, (size_t)n * sizeof *out);
+    if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0 && seq_pool_ok(pool, npool) && seq_lds_compatible(hs, n)) {
+        // the chains of a `parallel = true` run on the reference's own chain (src/moves.jl:57-81): small systems of one shape
+        // run one wavefront per chain with their state in LDS, all chains in one launch (pmc_seq.h, engine 3)
+        bool lds_ok = true;
+        for (int r = 0; r < n; r++) {
+            const int e = hs[r]->seq_engine;
+            if (e == 1 || e == 2 || !seq_lds_fits(hs[r], e == 3 ? SQ_LDS_MAX : SQ_LDS_AUTO)) lds_ok = false;
+        }
+        if (lds_ok) return sweep_sequential_lds(hs, n, pool, npool, nsweeps, out);
+    }
     if (mode != PMC_CHECKERBOARD || n == 1 || nsweeps == 0 || !many_compatible(hs, n)) {
         // different shapes, large systems (they fill the chip on their own) or the reference-order engine: one stream per handle
         int first = PMC_OK, begun = 0;

@@ -828,3 +828,355 @@ __global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
 }
 
 // rows of a LinkedList from the CSR the build leaves (ids ascending inside a cell = the chain read backwards): k_ref_cellvec
+
+// ================================================================================================================================
+// Small systems, many chains: the whole chain state in LDS (engine 3)
+// ================================================================================================================================
+// The reference's own workloads are small systems run as many chains (benchmark/particles_benchmarks.jl:10-28: N = 216;
+// test/ss142d.jl:8-21: N = 8, M = 100 chains; parallel = true, src/ParticlesMC.jl:164,246).  A box of a few cells per side has
+// nothing for the windows above to work with -- every step interacts with every other -- but its whole state (positions,
+// species, cell rows, SpeciesList) is a few KB: ONE wavefront per chain keeps it in LDS and walks the chain step by step with no
+// global-memory traffic at all; a launch runs as many chains as it is given, one per SIMD.  Same arithmetic, same iterator
+// order, same bits as above.  The random parts of 64 steps are generated at once, one step per lane.
+
+struct SqChain {             // per-chain arguments (device table)
+    double *pos;
+    int *species;
+    int *cs, *head, *list, *ccount, *cl_items;
+    int *sp_ids, *sp_heads;
+    const int *sp_off;
+    uint32_t key0, key1;
+    int pad0, pad1;
+    unsigned long long step0;
+    double energy;           // in: system.energy[1]; out: after the steps
+    double temperature;
+    unsigned long long att[8], acc[8];   // out (added to)
+    int err;
+    int pad2;
+};
+
+struct SqLdsArgs {
+    RefArgs a;               // geometry, models, neighbour-cell table, cl_cap (pointers to chain state unused: see SqChain)
+    double invbox[3];
+    SqChain *chains;
+    MovePool pool;
+    long long nsteps;
+    int reverse;
+    int ncell;
+    // byte offsets of the arrays inside the dynamic LDS block
+    int o_rows, o_ccount, o_cs, o_spids, o_spheads, o_species, o_seq, o_gen, o_nbr, o_nbrcnt, o_spoff;
+    int nbr_in_lds;
+};
+
+struct SqLdsView {
+    double *pos;
+    unsigned short *rows, *ccount, *cs, *spids, *spheads, *seq;
+    unsigned char *species;
+    SqGen *gen;
+    const int *nbr, *nbrcnt;
+    int *spoff;
+};
+
+template <int D>
+__device__ __forceinline__ int sql_sequence(const SqLdsArgs &s, const SqLdsView &v, int c)
+{
+    constexpr int NN = (D == 3) ? 27 : 9;
+    const int lane = wave_lane();
+    const int cap = s.a.cl_cap;
+    const int cnt = v.nbrcnt[c];
+    const int cc = (lane < cnt) ? v.nbr[(size_t)c * s.a.nnmax + lane] : 0;
+    const int len = (lane < cnt) ? (int)v.ccount[cc] : 0;
+    int incl = len;
+#pragma unroll
+    for (int sft = 1; sft < 32; sft <<= 1) {
+        const int t = __shfl_up(incl, sft, PMC_WAVE);
+        if (lane >= sft) incl += t;
+    }
+    const int off = incl - len;
+    const int total = __shfl(incl, 31, PMC_WAVE);
+    const int maxlen = __reduce_max_sync_compat(len);
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < NN; l++) {
+        const int len_l = __builtin_amdgcn_readlane(len, l);
+        const int cc_l = __builtin_amdgcn_readlane(cc, l);
+        const int off_l = __builtin_amdgcn_readlane(off, l);
+        for (int k = lane; k < len_l; k += PMC_WAVE)
+            v.seq[off_l + (s.reverse ? len_l - 1 - k : k)] = v.rows[cc_l * cap + k];
+    }
+    (void)maxlen;
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ double sql_vector_1d(double c1, double c2, double L, double invL) { return sq_vector_1d(c1, c2, L, invL); }
+
+template <int D>
+__device__ __forceinline__ double sql_dist2(const SqLdsArgs &s, const double *xi, const double *xj)
+{
+    double w = sq_vector_1d(xi[0], xj[0], s.a.box[0], s.invbox[0]);
+    double r2 = w * w;
+#pragma unroll
+    for (int q = 1; q < D; q++) {
+        w = sq_vector_1d(xi[q], xj[q], s.a.box[q], s.invbox[q]);
+        r2 = r2 + w * w;
+    }
+    return r2;
+}
+
+// compute_energy_particle at xa (and xb when BOTH) over the neighbourhood of cell c; species spa at xa, spb at xb; `other`
+// (a swap partner, or -1) is seen with species sp_other at xb (src/moves.jl:159-167)
+template <int D, bool BOTH>
+__device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v, int c, int i, int spa, int spb, int other, int sp_other,
+                                         const double *xa, const double *xb, double &ea, double &eb)
+{
+    const int lane = wave_lane();
+    const int S = s.a.S;
+    const int total = sql_sequence<D>(s, v, c);
+    double acc_a = 0.0, acc_b = 0.0;
+    for (int base = 0; base < total; base += PMC_WAVE) {
+        const int t = base + lane;
+        double ua = 0.0, ub = 0.0;
+        if (t < total) {
+            const int j = v.seq[t];
+            if (j != i) {
+                double xj[3] = {0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < D; q++) xj[q] = v.pos[j * D + q];
+                const int sj = (S > 1) ? (int)v.species[j] : 0;
+                const DevModel &ma = s.a.models[spa * S + sj];
+                const double r2a = sql_dist2<D>(s, xa, xj);
+                if (!(r2a > ma.rcut2)) ua = dev_potential_dyn(r2a, ma);
+                if (BOTH) {
+                    const DevModel &mb = s.a.models[spb * S + (j == other ? sp_other : sj)];
+                    const double r2b = sql_dist2<D>(s, xb, xj);
+                    if (!(r2b > mb.rcut2)) ub = dev_potential_dyn(r2b, mb);
+                }
+            }
+        }
+        acc_a = sq_ordered_add(acc_a, ua);
+        if (BOTH) acc_b = sq_ordered_add(acc_b, ub);
+    }
+    ea = acc_a;
+    eb = acc_b;
+}
+
+__device__ __forceinline__ void sql_row_move(const SqLdsArgs &s, const SqLdsView &v, int from, int to, int i)
+{
+    // update_neighbour_list!: i leaves the row of `from` (order kept) and is appended to the row of `to`
+    const int lane = wave_lane();
+    const int cap = s.a.cl_cap;
+    unsigned short *row = v.rows + from * cap;
+    const int n = v.ccount[from];
+    int p = -1;
+    for (int base = 0; base < n; base += PMC_WAVE) {
+        const int k = base + lane;
+        const unsigned long long mk = __ballot(k < n && row[k] == i);
+        if (mk) { p = base + (int)__builtin_ctzll(mk); break; }
+    }
+    __syncthreads();
+    if (p >= 0) {
+        for (int base = p; base < n - 1; base += PMC_WAVE) {
+            const int k = base + lane;
+            unsigned short t = 0;
+            if (k < n - 1) t = row[k + 1];
+            __syncthreads();
+            if (k < n - 1) row[k] = t;
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        const int nfrom = (p >= 0) ? n - 1 : n;
+        v.ccount[from] = (unsigned short)nfrom;
+        const int n2 = (from == to) ? nfrom : (int)v.ccount[to];
+        if (n2 < cap) {
+            v.rows[to * cap + n2] = (unsigned short)i;
+            v.ccount[to] = (unsigned short)(n2 + 1);
+        } else {
+            s.chains[blockIdx.x].err |= 1;          // a cell outgrew its row: the host reports it and rebuilds
+        }
+        if (p < 0) s.chains[blockIdx.x].err |= 2;
+        v.cs[i] = (unsigned short)to;
+    }
+    __syncthreads();
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sql_smem[];
+    const RefArgs &a = s.a;
+    SqChain &ch = s.chains[blockIdx.x];
+    const int lane = wave_lane();
+    const int N = a.N, S = a.S, cap = a.cl_cap;
+    SqLdsView v;
+    v.pos = reinterpret_cast<double *>(sql_smem);
+    v.rows = reinterpret_cast<unsigned short *>(sql_smem + s.o_rows);
+    v.ccount = reinterpret_cast<unsigned short *>(sql_smem + s.o_ccount);
+    v.cs = reinterpret_cast<unsigned short *>(sql_smem + s.o_cs);
+    v.spids = reinterpret_cast<unsigned short *>(sql_smem + s.o_spids);
+    v.spheads = reinterpret_cast<unsigned short *>(sql_smem + s.o_spheads);
+    v.species = sql_smem + s.o_species;
+    v.seq = reinterpret_cast<unsigned short *>(sql_smem + s.o_seq);
+    v.gen = reinterpret_cast<SqGen *>(sql_smem + s.o_gen);
+    v.spoff = reinterpret_cast<int *>(sql_smem + s.o_spoff);
+    if (s.nbr_in_lds) {
+        int *lnbr = reinterpret_cast<int *>(sql_smem + s.o_nbr), *lcnt = reinterpret_cast<int *>(sql_smem + s.o_nbrcnt);
+        for (int k = lane; k < s.ncell * a.nnmax; k += PMC_WAVE) lnbr[k] = a.nbr[k];
+        for (int k = lane; k < s.ncell; k += PMC_WAVE) lcnt[k] = a.nbrcnt[k];
+        v.nbr = lnbr; v.nbrcnt = lcnt;
+    } else {
+        v.nbr = a.nbr; v.nbrcnt = a.nbrcnt;
+    }
+    // -- the chain's state into LDS
+    for (int k = lane; k < N * D; k += PMC_WAVE) v.pos[k] = ch.pos[k];
+    for (int k = lane; k < N; k += PMC_WAVE) {
+        v.species[k] = (unsigned char)ch.species[k];
+        v.cs[k] = (unsigned short)ch.cs[k];
+        v.spids[k] = (unsigned short)ch.sp_ids[k];
+        v.spheads[k] = (unsigned short)ch.sp_heads[k];
+    }
+    for (int k = lane; k <= S; k += PMC_WAVE) v.spoff[k] = ch.sp_off[k];
+    for (int c = 0; c < s.ncell; c++) {
+        const int n = ch.ccount[c];
+        if (lane == 0) v.ccount[c] = (unsigned short)n;
+        for (int k = lane; k < n; k += PMC_WAVE) v.rows[c * cap + k] = (unsigned short)ch.cl_items[(size_t)c * cap + k];
+    }
+    __syncthreads();
+    double E = ch.energy;
+    const double T = ch.temperature;
+    unsigned long long att[8], acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { att[q] = 0; acc[q] = 0; }
+    const unsigned long long gend = ch.step0 + (unsigned long long)s.nsteps;
+    for (unsigned long long g0 = ch.step0; g0 < gend; g0 += PMC_WAVE) {
+        // -- random parts of the next 64 steps, one per lane: the words and operations of k_ref_ops for step g
+        {
+            const unsigned long long g = g0 + (unsigned long long)lane;
+            uint32_t R[4], Q[4];
+            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, ch.key0, ch.key1, R);
+            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ1, ch.key0, ch.key1, Q);
+            SqGen o;
+            o.m = select_move(s.pool, R[0]);
+            o.lnu = det_log(uniform53(R[2], R[3]));
+            o.r1 = R[1]; o.q0 = Q[0]; o.pad = 0;
+            o.d[0] = o.d[1] = o.d[2] = 0.0;
+            if (s.pool.kind[o.m] == 0) {
+                double z[4];
+                box_muller(Q[0], Q[1], &z[0], &z[1]);
+                box_muller(Q[2], Q[3], &z[2], &z[3]);
+                for (int q = 0; q < 3; q++) o.d[q] = s.pool.sigma[o.m] * z[q];
+            }
+            __syncthreads();
+            v.gen[lane] = o;
+            __syncthreads();
+        }
+        const int nt = (int)min((unsigned long long)PMC_WAVE, gend - g0);
+        for (int t = 0; t < nt; t++) {
+            const SqGen ge = v.gen[t];
+            const int m = ge.m;
+            bool ok = false;
+            if (s.pool.kind[m] == 0) {
+                const int i = (int)mulhi32(ge.r1, (uint32_t)N);
+                double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0}, xr[3] = {0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < D; q++) {
+                    x[q] = v.pos[i * D + q];
+                    xn[q] = x[q] + ge.d[q];
+                    xr[q] = xn[q] + (-ge.d[q]);
+                }
+                const int c0 = v.cs[i];                       // the list is current: cs[i] is the cell of x_i
+                const int c1 = ref_cell_of<D>(a, xn);
+                const int spi = (S > 1) ? (int)v.species[i] : 0;
+                double e1, e2, dummy;
+                if (c1 == c0) {
+                    sql_pass<D, true>(s, v, c0, i, spi, spi, -1, 0, x, xn, e1, e2);
+                } else {
+                    sql_pass<D, false>(s, v, c0, i, spi, spi, -1, 0, x, x, e1, dummy);
+                    sql_pass<D, false>(s, v, c1, i, spi, spi, -1, 0, xn, xn, e2, dummy);
+                }
+                double de = 0.0;
+                if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }           // src/moves.jl:13-18
+                ok = ge.lnu < -(e2 - e1) / T;
+                if (ok) {
+                    if (lane < D) v.pos[i * D + lane] = xn[lane];
+                    if (c1 != c0) sql_row_move(s, v, c0, c1, i);
+                } else {
+                    E -= de;                                                         // src/moves.jl:79
+                    bool chg = false;
+#pragma unroll
+                    for (int q = 0; q < D; q++) chg |= sq_bits_differ(xr[q], x[q]);
+                    if (chg && lane < D) v.pos[i * D + lane] = xr[lane];
+                    const int c2 = chg ? ref_cell_of<D>(a, xr) : c0;
+                    if (c1 != c0) sql_row_move(s, v, c0, c1, i);
+                    if (c2 != c1) sql_row_move(s, v, c1, c2, i);
+                }
+                __syncthreads();
+            } else {
+                const int sa = s.pool.sp0[m], sb = s.pool.sp1[m];
+                const int na = v.spoff[sa + 1] - v.spoff[sa], nb = v.spoff[sb + 1] - v.spoff[sb];
+                if (na > 0 && nb > 0) {
+                    const int i = v.spids[v.spoff[sa] + mulhi32(ge.r1, (uint32_t)na)];
+                    const int j = v.spids[v.spoff[sb] + mulhi32(ge.q0, (uint32_t)nb)];
+                    double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
+                    const int spi = v.species[i], spj = v.species[j];
+                    double e1i, e2i, e1j, e2j;
+                    sql_pass<D, true>(s, v, v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
+                    sql_pass<D, true>(s, v, v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
+                    const double e1 = e1i + e1j, e2 = e2i + e2j;
+                    double de = 0.0;
+                    if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
+                    ok = ge.lnu < -(e2 - e1) / T;
+                    if (ok) {
+                        if (lane == 0) {
+                            v.species[i] = (unsigned char)spj;
+                            v.species[j] = (unsigned char)spi;
+                            // update_species_list!, src/moves.jl:175-179
+                            v.spids[v.spoff[sa] + v.spheads[i]] = (unsigned short)j;
+                            v.spids[v.spoff[sb] + v.spheads[j]] = (unsigned short)i;
+                            const unsigned short hh = v.spheads[i];
+                            v.spheads[i] = v.spheads[j];
+                            v.spheads[j] = hh;
+                        }
+                    } else {
+                        E -= de;                                                     // src/moves.jl:206
+                    }
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                att[q] += (q == m);
+                acc[q] += (q == m && ok);
+            }
+        }
+    }
+    // -- back to global memory: positions, species, SpeciesList, rows, cs, ccount, and head / list rebuilt from the rows
+    __syncthreads();
+    for (int k = lane; k < N * D; k += PMC_WAVE) ch.pos[k] = v.pos[k];
+    for (int k = lane; k < N; k += PMC_WAVE) {
+        ch.species[k] = v.species[k];
+        ch.cs[k] = v.cs[k];
+        ch.sp_ids[k] = v.spids[k];
+        ch.sp_heads[k] = v.spheads[k];
+    }
+    for (int c = 0; c < s.ncell; c++) {
+        const int n = v.ccount[c];
+        if (lane == 0) {
+            ch.ccount[c] = n;
+            if (s.reverse) ch.head[c] = n > 0 ? (int)v.rows[c * cap + n - 1] : -1;
+        }
+        for (int k = lane; k < n; k += PMC_WAVE) {
+            const int id = v.rows[c * cap + k];
+            ch.cl_items[(size_t)c * cap + k] = id;
+            if (s.reverse) ch.list[id] = k > 0 ? (int)v.rows[c * cap + k - 1] : -1;   // the chain is the row read backwards
+        }
+    }
+    if (lane == 0) {
+        ch.energy = E;
+        ch.step0 = gend;                         // the next launch of the call continues here
+        for (int q = 0; q < 8; q++) { ch.att[q] += att[q]; ch.acc[q] += acc[q]; }
+    }
+}

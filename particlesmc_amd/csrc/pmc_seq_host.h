@@ -272,3 +272,166 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
     }
     return PMC_OK;
 }
+
+// ---- engine 3: chains whose whole state fits the LDS, one wavefront per chain, any number of chains per launch (pmc_seq.h) ----
+
+static size_t seq_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// LDS bytes of k_sq_lds for this system's shape (and the offsets of its arrays)
+static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s)
+{
+    const size_t N = (size_t)h->N, nc = (size_t)h->ncell_ref, nn = (size_t)h->nn;
+    size_t o = seq_align(N * h->D * sizeof(double), 16);
+    const size_t o_rows = o;      o = seq_align(o + nc * cap * 2, 16);
+    const size_t o_ccount = o;    o = seq_align(o + nc * 2, 16);
+    const size_t o_cs = o;        o = seq_align(o + N * 2, 16);
+    const size_t o_spids = o;     o = seq_align(o + N * 2, 16);
+    const size_t o_spheads = o;   o = seq_align(o + N * 2, 16);
+    const size_t o_species = o;   o = seq_align(o + N, 16);
+    const size_t o_seq = o;       o = seq_align(o + nn * cap * 2, 16);
+    const size_t o_gen = o;       o = seq_align(o + 64 * sizeof(SqGen), 16);
+    const size_t o_spoff = o;     o = seq_align(o + 16 * sizeof(int), 16);
+    const bool nbr_in = nc * nn * 4 <= 16384;
+    const size_t o_nbr = o;       if (nbr_in) o = seq_align(o + nc * nn * 4, 16);
+    const size_t o_nbrcnt = o;    if (nbr_in) o = seq_align(o + nc * 4, 16);
+    if (s) {
+        s->o_rows = (int)o_rows; s->o_ccount = (int)o_ccount; s->o_cs = (int)o_cs; s->o_spids = (int)o_spids;
+        s->o_spheads = (int)o_spheads; s->o_species = (int)o_species; s->o_seq = (int)o_seq; s->o_gen = (int)o_gen;
+        s->o_spoff = (int)o_spoff; s->o_nbr = (int)o_nbr; s->o_nbrcnt = (int)o_nbrcnt; s->nbr_in_lds = nbr_in ? 1 : 0;
+    }
+    return o;
+}
+
+#define SQ_LDS_MAX (160 * 1024 - 512)
+#define SQ_LDS_AUTO (64 * 1024)        // auto: chains that leave room for a second workgroup on the CU
+
+static bool seq_lds_fits(const pmc_system *h, size_t limit)
+{
+    if (h->N > 65535 || h->S > 8) return false;
+    if (h->list_type != 1 && h->list_type != 2) return false;
+    const int cap = h->d_cl_items ? h->cl_cap : seq_rows_cap(h);
+    return seq_lds_layout(h, cap, nullptr) <= limit;
+}
+
+static bool seq_lds_compatible(pmc_system **hs, int n)
+{
+    const pmc_system *m = hs[0];
+    for (int r = 1; r < n; r++) {
+        const pmc_system *h = hs[r];
+        for (int q = 0; q < r; q++) if (hs[q] == h) return false;
+        if (h->p.device != m->p.device || h->D != m->D || h->N != m->N || h->S != m->S || h->list_type != m->list_type ||
+            h->ncell_ref != m->ncell_ref || h->nn != m->nn)
+            return false;
+        for (int a = 0; a < h->D; a++)
+            if (h->p.box[a] != m->p.box[a] || h->p.cell[a] != m->p.cell[a] || h->p.ncells[a] != m->p.ncells[a]) return false;
+        if (h->models.size() != m->models.size() || memcmp(h->models.data(), m->models.data(), m->models.size() * sizeof(pmc_pair_model)) != 0)
+            return false;
+    }
+    return true;
+}
+
+// n chains of one shape, nsweeps sweeps each of the reference's sequential chain, in shared launches of k_sq_lds
+static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    pmc_system *m = hs[0];
+    int rc = set_device(m);
+    if (rc) return rc;
+    // rows of one capacity on every chain
+    int cap = seq_rows_cap(m);
+    for (int r = 0; r < n; r++) if (hs[r]->d_cl_items) cap = std::max(cap, hs[r]->cl_cap);
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        if (!h->d_ref_err) {
+            HIPCHK(h, hipMalloc(&h->d_ref_err, 16));
+            HIPCHK(h, hipMemset(h->d_ref_err, 0, 16));
+        }
+        if (h->d_cl_items && h->cl_cap != cap) {
+            (void)hipFree(h->d_cl_items);
+            h->d_cl_items = nullptr;
+        }
+        if (!h->d_cl_items) {
+            h->cl_cap = cap;
+            HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * cap * sizeof(int)));
+            if (h->list_type == 1) h->rows_own = true;
+            h->cells_built = false;
+        }
+        if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
+        if (h->cl_cap != cap) return fail(h, PMC_ERR_STATE, "sequential engine: the chains' cell rows differ in capacity");
+        if (int rs = refresh_stale_energy(h)) return rs;
+        rc = ensure_species_list(h);
+        if (rc) return rc;
+    }
+    SqLdsArgs s;
+    memset(&s, 0, sizeof s);
+    s.a = ref_args(m);
+    for (int q = 0; q < 3; q++) s.invbox[q] = 1.0 / s.a.box[q];
+    s.pool = make_pool(pool, npool);
+    s.reverse = (m->list_type == 1) ? 1 : 0;
+    s.ncell = m->ncell_ref;
+    const size_t lds = seq_lds_layout(m, cap, &s);
+    if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: the chain's state does not fit the LDS");
+    if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<SqChain> tab((size_t)n);
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        SqChain &c = tab[r];
+        memset(&c, 0, sizeof c);
+        c.pos = h->d_pos; c.species = h->d_species;
+        c.cs = h->d_cs; c.head = h->d_head; c.list = h->d_list; c.ccount = h->d_ccount; c.cl_items = h->d_cl_items;
+        c.sp_ids = h->d_sp_ids; c.sp_heads = h->d_sp_heads; c.sp_off = h->d_sp_off;
+        c.key0 = h->key[0]; c.key1 = h->key[1];
+        c.step0 = h->step_ctr;
+        c.energy = h->energy;
+        c.temperature = h->p.temperature;
+    }
+    DevTmp dtab;
+    HIPCHK(m, dtab.alloc((size_t)n * sizeof(SqChain)));
+    s.chains = dtab.as<SqChain>();
+    HIPCHK(m, hipMemcpyAsync(s.chains, tab.data(), (size_t)n * sizeof(SqChain), hipMemcpyHostToDevice, m->stream));
+    for (int r = 1; r < n; r++) HIPCHK(hs[r], hipStreamSynchronize(hs[r]->stream));   // earlier work on the chains' own streams
+    HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
+    const long long total = nsweeps * (int64_t)m->N;          // sweepstep = N, src/ParticlesMC.jl:246
+    const long long chunk = 1 << 18;                          // steps per launch and chain (a launch stays well under a second)
+    long long launches = 0;
+    for (long long done = 0; done < total; done += chunk) {
+        s.nsteps = std::min(chunk, total - done);
+        if (m->D == 3) hipLaunchKernelGGL(k_sq_lds<3>, dim3(n), dim3(64), lds, m->stream, s);
+        else hipLaunchKernelGGL(k_sq_lds<2>, dim3(n), dim3(64), lds, m->stream, s);
+        HIPCHK(m, hipGetLastError());
+        launches++;
+    }
+    HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
+    HIPCHK(m, hipMemcpyAsync(tab.data(), s.chains, (size_t)n * sizeof(SqChain), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, m->ev[0], m->ev[1]);
+    int first = PMC_OK;
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        const SqChain &c = tab[r];
+        h->mc_binned = false;
+        h->e_fix_valid = false;
+        h->img_valid = false;
+        if (c.err) {
+            h->cells_built = false;
+            h->energy_stale = true;
+            if (c.err & 1) { (void)hipFree(h->d_cl_items); h->d_cl_items = nullptr; h->cl_cap = 0; }   // rebuilt larger next time
+            if (!first) first = fail(h, PMC_ERR_STATE, (c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
+            continue;
+        }
+        h->energy = c.energy;
+        h->step_ctr += (uint64_t)total;
+        h->sweep_ctr += (uint64_t)nsweeps;
+        if (out) {
+            pmc_stats &o = out[r];
+            memset(&o, 0, sizeof o);
+            for (int q = 0; q < PMC_MAX_MOVES; q++) { o.attempted[q] = (int64_t)c.att[q]; o.accepted[q] = (int64_t)c.acc[q]; }
+            o.kernel_ms = ms;
+            o.sweep_kernel_ms = ms;
+            o.sweep_kernel_launches = launches;
+            o.energy = h->energy;
+        }
+    }
+    return first;
+}

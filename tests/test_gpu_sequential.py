@@ -169,3 +169,78 @@ def test_config2_one_sweep_bitexact(gpu):
     att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 42, 0, 0, len(pos))
     assert st.accepted[0] == acc[0]
     _same_state(g, o)
+
+
+# ---- engine 3: the chain's state in LDS, one wavefront per chain, many chains per launch ------------------------------------------
+
+@pytest.mark.parametrize("n,rho,sigma", [(6, 0.9, 0.15), (6, 1.0, 0.6), (8, 0.9, 0.3), (10, 0.95, 0.1)])
+def test_lds_engine_lj_bitexact(gpu, n, rho, sigma):
+    """The reference's benchmark system (benchmark/particles_benchmarks.jl:10-28: N = 216 LJ) and its neighbours in size,
+    engine 3 against the oracle; sigma = 0.6 makes a quarter of the trials change cell."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(n, jitter=0.1, seed=3, rho=rho)
+    g = pmc.System(pos, sp, rho, 0.8, pmc.LennardJones(1.0, 1.0), seed=99)
+    o = O.System(pos, sp, rho, 0.8, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    g.set_sequential_engine(3, 0)
+    for call in range(2):
+        st = pmc.mc_sweep(g, [_disp(pmc, sigma)], nsweeps=3, mode="sequential")
+        att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": sigma}]), 99, 0, call * 3 * len(pos), 3 * len(pos))
+        assert st.attempted[0] == att[0] and st.accepted[0] == acc[0], (st.accepted, acc)
+        _same_state(g, o)
+
+
+def test_lds_engine_mixture_with_swaps_and_cell_list(gpu):
+    """Engine 3 on the published mixture's own size (N = 1000, rcut = 4: two cells per side, swaps mostly accepted) with a
+    LinkedList, and on a CellList system."""
+    from oracle import oracle as O
+    from mixture import EPS, SIG, RCUT
+    pmc = gpu
+    N = 1000
+    pos, sp, rho = binary_lattice(N, frac_b=0.5, rho=0.8, jitter=0.05, seed=4)
+    mp = [[pmc.LennardJones(EPS[i][j], SIG[i][j], rcut=RCUT, shift_potential=False) for j in range(2)] for i in range(2)]
+    mo = O.model_matrix(lambda e, s: O.lennard_jones(e, s, RCUT, False), EPS, SIG)
+    g = pmc.System(pos, sp, rho, 1.5, mp, seed=5)
+    o = O.System(pos, sp, rho, 1.5, mo, O.LINKEDLIST)
+    g.set_sequential_engine(3, 0)
+    pool = [_disp(pmc, 0.1, 0.5), _swap(pmc, (1, 2), (N // 2, N // 2), 0.5)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.1, "probability": 0.5},
+                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.5}])
+    st = pmc.mc_sweep(g, pool, nsweeps=2, mode="sequential")
+    att, acc = o.mc_steps(opool, 5, 0, 0, 2 * N)
+    assert np.array_equal(st.attempted, att) and np.array_equal(st.accepted, acc), (st.accepted, acc)
+    _same_state(g, o, species=True)
+    pos, sp, rho = lj_lattice(8, jitter=0.1, seed=11, rho=0.9)
+    g = pmc.System(pos, sp, rho, 0.9, pmc.LennardJones(1.0, 1.0), list_type=pmc.CellList, seed=3)
+    o = O.System(pos, sp, rho, 0.9, O.single(O.lennard_jones(1.0, 1.0)), O.CELLLIST)
+    g.set_sequential_engine(3, 0)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.4)], nsweeps=3, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.4}]), 3, 0, 0, 3 * len(pos))
+    assert st.accepted[0] == acc[0]
+    _same_state(g, o, linked=False)
+    for c in range(1, int(np.prod(o.cell_geometry()[1])) + 1):
+        assert np.array_equal(g.get_cell_members(c), o.cell_members(c)), c
+
+
+def test_many_sequential_chains_in_one_launch(gpu):
+    """pmc_sweep_many(PMC_SEQUENTIAL): the chains of a `parallel = true` run (src/ParticlesMC.jl:164,246) on the reference's
+    own chain, one wavefront per chain in shared launches; every chain equals the oracle's chain of its (seed, chain) and
+    temperature, and the same chain run alone."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(6, jitter=0.1, seed=1, rho=0.9)
+    nch = 24
+    temps = [0.7 + 0.05 * k for k in range(nch)]
+    chains = [pmc.System(pos, sp, rho, temps[k], pmc.LennardJones(1.0, 1.0), seed=17, chain=k) for k in range(nch)]
+    pool = [_disp(pmc, 0.2)]
+    stats = pmc.mc_sweep_many(chains, pool, nsweeps=4, mode="sequential")
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.2}])
+    for k in (0, 1, 7, nch - 1):
+        o = O.System(pos, sp, rho, temps[k], O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+        att, acc = o.mc_steps(opool, 17, k, 0, 4 * len(pos))
+        assert stats[k].accepted[0] == acc[0], k
+        _same_state(chains[k], o)
+    alone = pmc.System(pos, sp, rho, temps[5], pmc.LennardJones(1.0, 1.0), seed=17, chain=5)
+    st = pmc.mc_sweep(alone, pool, nsweeps=4, mode="sequential")
+    assert st.accepted[0] == stats[5].accepted[0] and np.array_equal(alone.position, chains[5].position)
+    assert alone.energy[0] == chains[5].energy[0]
