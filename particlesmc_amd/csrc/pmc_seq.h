@@ -827,6 +827,21 @@ __global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
     dst[nkeep + q] = sl;
 }
 
+// The rows of a LinkedList whose chains already exist (moves have shaped their order: src/neighbours.jl:276-302): the row of
+// a cell is its chain read backwards.  One thread per cell; overflow of a row sets bit 0 of *err.
+PMC_GLOBAL void k_sq_rows_from_chains(int ncell, const int *__restrict__ head, const int *__restrict__ list, int *__restrict__ items,
+                                      int cap, int *__restrict__ ccount, int *__restrict__ err)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    int n = 0;
+    for (int j = head[c]; j != -1; j = list[j]) n++;
+    ccount[c] = n;
+    if (n > cap) { atomicOr(err, 1); return; }
+    int k = n - 1;
+    for (int j = head[c]; j != -1; j = list[j]) items[(size_t)c * cap + k--] = j;
+}
+
 // rows of a LinkedList from the CSR the build leaves (ids ascending inside a cell = the chain read backwards): k_ref_cellvec
 
 // ================================================================================================================================

@@ -33,6 +33,34 @@ static int seq_build_rows(pmc_system *h)
     return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine: a cell holds more particles than the row capacity allows");
 }
 
+// rows for a LinkedList that is already built (and whose chains moves may have reordered): from head / list, not from positions
+static int seq_alloc_rows(pmc_system *h, int cap)
+{
+    if (!h->d_ref_err) {
+        HIPCHK(h, hipMalloc(&h->d_ref_err, 16));
+        HIPCHK(h, hipMemset(h->d_ref_err, 0, 16));
+    }
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (h->d_cl_items) (void)hipFree(h->d_cl_items);
+        h->d_cl_items = nullptr;
+        h->cl_cap = cap;
+        HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * cap * sizeof(int)));
+        h->rows_own = true;
+        if (!h->cells_built) return PMC_OK;            // the next pmc_build_cells fills the rows
+        HIPCHK(h, hipMemsetAsync(h->d_ref_err, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_sq_rows_from_chains, dim3(nblk(h->ncell_ref, 128)), dim3(128), 0, h->stream, h->ncell_ref, h->d_head,
+                           h->d_list, h->d_cl_items, cap, h->d_ccount, h->d_ref_err);
+        HIPCHK(h, hipGetLastError());
+        int e = 0;
+        HIPCHK(h, hipMemcpyAsync(&e, h->d_ref_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!(e & 1)) return PMC_OK;
+        cap *= 2;
+        if ((double)h->ncell_ref * cap * sizeof(int) > 64e9) break;
+    }
+    return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine: a cell holds more particles than the row capacity allows");
+}
+
 static bool seq_pool_ok(const pmc_move *pool, int npool)
 {
     for (int m = 0; m < npool; m++)
@@ -57,10 +85,8 @@ static int seq_ensure(pmc_system *h, int K)
         HIPCHK(h, hipMemset(h->d_ref_err, 0, 16));
     }
     if (h->list_type == 1 && !h->d_cl_items) {
-        h->cl_cap = seq_rows_cap(h);
-        HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * h->cl_cap * sizeof(int)));
-        h->rows_own = true;
-        h->cells_built = false;            // the next build fills the rows
+        const int rc = seq_alloc_rows(h, seq_rows_cap(h));
+        if (rc) return rc;
     }
     if (!h->d_sq_ctl) {
         HIPCHK(h, hipMalloc(&h->d_sq_slots[0], (size_t)SQ_KMAX * sizeof(SqSlot)));
@@ -345,15 +371,9 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
             HIPCHK(h, hipMalloc(&h->d_ref_err, 16));
             HIPCHK(h, hipMemset(h->d_ref_err, 0, 16));
         }
-        if (h->d_cl_items && h->cl_cap != cap) {
-            (void)hipFree(h->d_cl_items);
-            h->d_cl_items = nullptr;
-        }
-        if (!h->d_cl_items) {
-            h->cl_cap = cap;
-            HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * cap * sizeof(int)));
-            if (h->list_type == 1) h->rows_own = true;
-            h->cells_built = false;
+        if (h->list_type == 1 && (!h->d_cl_items || h->cl_cap != cap)) {
+            rc = seq_alloc_rows(h, cap);
+            if (rc) return rc;
         }
         if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
         if (h->cl_cap != cap) return fail(h, PMC_ERR_STATE, "sequential engine: the chains' cell rows differ in capacity");
@@ -416,7 +436,7 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
         if (c.err) {
             h->cells_built = false;
             h->energy_stale = true;
-            if (c.err & 1) { (void)hipFree(h->d_cl_items); h->d_cl_items = nullptr; h->cl_cap = 0; }   // rebuilt larger next time
+            if ((c.err & 1) && h->list_type == 1) { (void)hipFree(h->d_cl_items); h->d_cl_items = nullptr; h->cl_cap = 0; h->rows_own = false; }   // larger next time
             if (!first) first = fail(h, PMC_ERR_STATE, (c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
             continue;
         }
