@@ -177,6 +177,8 @@ def parse_args(argv=None):
     ap.add_argument("--only-headline", action="store_true",
                     help="profiling runs: skip the lattice figure, the other schedules and the long region, so that the LAST "
                          "steps / rounds launches of the sweep kernel are the timed region (profiles/collect.sh)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the bounded block of the other BASELINE configurations and of the reference-order chain (\"other_configs\", \"reference_order_chain\")")
     ap.add_argument("--share-devices", action="store_true",
                     help="functional testing only: allow more ranks than visible GPUs (ranks share devices, gloo reductions)")
     return ap.parse_args(argv)
@@ -351,6 +353,168 @@ def rccl_exchange_check(rank, world, dev_index, dist, rounds=4, timeout=150.0):
                 res = {"n_ranks_rccl": 0, "error": repr(exc)}
         shutil.rmtree(outdir, ignore_errors=True)
     return res
+
+
+def _oracle_rate(make_oracle, pool_o, seed, budget_s=1.5):
+    """Attempted moves/s of the oracle's sequential chain (one host core) on a system, bounded sample."""
+    o = make_oracle()
+    t0 = time.perf_counter()
+    o.mc_steps(pool_o, seed, 0, 0, 4000)
+    r = 4000 / (time.perf_counter() - t0)
+    n = int(max(4000, r * budget_s))
+    t0 = time.perf_counter()
+    o.mc_steps(pool_o, seed, 0, 4000, n)
+    return n / (time.perf_counter() - t0)
+
+
+def _flop_frac(st, seconds):
+    """Counted algorithmic flop (9 per distance test + 9 per pair energy, as the headline's roofline) over the FP64 peak."""
+    tests, inr = float(getattr(st, "pair_tests", 0)), float(getattr(st, "pairs_in_range", 0))
+    if tests <= 0 or seconds <= 0:
+        return None
+    return (tests * FLOP_PER_PAIR_TEST + inr * FLOP_PER_PAIR_ENERGY) / seconds / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+
+
+def _seq_flop_frac(N, d, ncells_ref, rate, in_range_per_eval):
+    """The reference-order chain's algorithmic flop (two traversals of the 3^d neighbour cells per step, src/atoms.jl:81-88,
+    plus the in-range pair energies) over the FP64 peak: this chain is a latency chain, not an arithmetic one."""
+    cand = (3 ** d) * N / float(np.prod(ncells_ref))
+    return (2 * cand * FLOP_PER_PAIR_TEST + 2 * in_range_per_eval * FLOP_PER_PAIR_ENERGY) * rate / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+
+
+def reference_order_chain(pmc, system, pool, nsteps_target=3_000_000):
+    """The reference's own chain -- one particle per step, every step seeing the state all earlier steps left
+    (src/moves.jl:11-20,57-81) -- on the headline's system and state: PMC_SEQUENTIAL, bit-identical to the CPU baseline's
+    chain (tests/test_gpu_sequential.py), so GPU / CPU here is like for like."""
+    N = system.N
+    nsw = max(1, int(nsteps_target // N))
+    pmc.mc_sweep(system, pool, nsweeps=1, mode="sequential")
+    t0 = time.perf_counter()
+    st = pmc.mc_sweep(system, pool, nsweeps=nsw, mode="sequential")
+    dt = time.perf_counter() - t0
+    rounds, evals, window, folded = system.sequential_info()
+    return {"value": nsw * N / dt, "unit": "attempted moves/s", "steps": nsw * N, "acceptance": float(st.accepted[0]) / max(1, st.attempted[0]),
+            "engine": "speculative windows (pmc_seq.h): windows of pending steps evaluated at once, committed in dependency order",
+            "window": window, "rounds": rounds, "steps_per_round": nsw * N / max(1, rounds), "evaluations_per_step": evals / max(1, nsw * N),
+            "us_per_round": 1e3 * st.kernel_ms / max(1, rounds),
+            "note": "same chain as cpu_baseline bit for bit (positions, lists, accept counts, system.energy)"}
+
+
+def other_configs(pmc, budget_cpu_s=1.2):
+    """BASELINE.json's other configurations and the reference's own small-system workload, each on this GPU in a bounded
+    region, with the oracle's sequential chain on one host core beside it.  About a minute in all."""
+    from oracle import oracle as O
+    from particlesmc_amd import tempering
+    from particlesmc_amd.workloads import binary_lattice, lj_lattice
+    rows = []
+
+    def disp(sigma=SIGMA_MOVE, p=1.0):
+        return pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": sigma}, p)
+
+    def cb_leg(system, pool, sweeps, warm, m):
+        system.rounds = m
+        pmc.mc_sweep(system, pool, nsweeps=warm)
+        t0 = time.perf_counter()
+        st = pmc.mc_sweep(system, pool, nsweeps=sweeps)
+        dt = time.perf_counter() - t0
+        att = float(np.sum(st.attempted))
+        return {"moves_per_s": att / dt, "rounds": m, "roofline_frac": _flop_frac(st, st.sweep_kernel_ms * 1e-3),
+                "acceptance": [float(a) / max(1.0, float(b)) for a, b in zip(st.accepted, st.attempted) if b > 0],
+                "running_energy_equals_recomputed": bool(system.total_energy()[1] == st.energy_fix)}
+
+    def seq_leg(system, pool, steps):
+        nsw = max(1, int(steps // system.N))
+        pmc.mc_sweep(system, pool, nsweeps=1, mode="sequential")
+        t0 = time.perf_counter()
+        st = pmc.mc_sweep(system, pool, nsweeps=nsw, mode="sequential")
+        dt = time.perf_counter() - t0
+        return {"moves_per_s": nsw * system.N / dt, "acceptance": [float(a) / max(1.0, float(b)) for a, b in zip(st.accepted, st.attempted) if b > 0]}
+
+    # -- config 2: N = 32768 LJ liquid
+    pos, sp, rho = lj_lattice(32, jitter=0.05, seed=42)
+    s = pmc.System(pos, sp, rho, TEMPERATURE, pmc.LennardJones(1.0, 1.0), seed=42)
+    pool = [disp()]
+    s.total_energy()
+    pmc.mc_sweep(s, pool, nsweeps=300)                           # melt
+    row = {"config": "C2: N=32768 3D LJ rho=1 T=1 rcut=2.5, Displacement sigma=0.05 (liquid: 300 untimed sweeps from the lattice)",
+           "checkerboard_m1": cb_leg(s, pool, 300, 20, 1), "checkerboard_m4": cb_leg(s, pool, 300, 20, 4)}
+    s.rounds = 1
+    state = s.position.copy()
+    row["reference_order_chain"] = seq_leg(s, pool, 1.2e6)
+    row["reference_order_chain"]["roofline_frac"] = _seq_flop_frac(s.N, 3, s.neighbour_list.ncells, row["reference_order_chain"]["moves_per_s"], 62.0)
+    row["cpu_oracle_moves_per_s"] = _oracle_rate(lambda: O.System(state, sp, rho, TEMPERATURE, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST),
+                                                 O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}]), 42, budget_cpu_s)
+    rows.append(row)
+    # -- config 3: Kob-Andersen N = 10^5, 90 % Displacement + 10 % DiscreteSwap
+    pos, sp, rho = binary_lattice(100000, frac_b=0.2, rho=1.2, jitter=0.05, seed=42)
+    s = pmc.System(pos, sp, rho, TEMPERATURE, pmc.KobAndersen(), seed=42)
+    pool = [disp(p=0.9), pmc.Move(pmc.DiscreteSwap([1, 2], s), pmc.DoubleUniform(), [], 0.1)]
+    pool_o = O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE, "probability": 0.9}, {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}])
+    s.total_energy()
+    row = {"config": "C3: Kob-Andersen 80:20 N=100000 rho=1.2 T=1, 90% Displacement + 10% DiscreteSwap (from the lattice)",
+           "checkerboard_m1": cb_leg(s, pool, 100, 10, 1), "checkerboard_m4": cb_leg(s, pool, 100, 12, 4)}
+    s.rounds = 1
+    state, sstate = s.position.copy(), s.species.copy()
+    row["reference_order_chain"] = seq_leg(s, pool, 1.0e6)
+    row["reference_order_chain"]["roofline_frac"] = _seq_flop_frac(s.N, 3, s.neighbour_list.ncells, row["reference_order_chain"]["moves_per_s"], 75.0)
+    row["cpu_oracle_moves_per_s"] = _oracle_rate(lambda: O.System(state, sstate, rho, TEMPERATURE, O.kob_andersen(), O.LINKEDLIST), pool_o, 42, budget_cpu_s)
+    rows.append(row)
+    # -- config 5: 8 tempering replicas of 2-D r^-14 soft spheres on this GPU, exchange every 10 sweeps
+    n, side = 8, 256
+    Nss = side * side
+    L = (Nss / 0.5) ** 0.5
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float64)
+    pos = (g + 0.5) * (L / side) + np.random.default_rng(1).uniform(-0.05, 0.05, (Nss, 2))
+    sp = np.ones(Nss, dtype=np.int32)
+    sp[np.random.default_rng(2).permutation(Nss)[: Nss // 2]] = 2
+    mm = [[pmc.SoftSpheres(1.0, sg, 14) for sg in r_] for r_ in ([1.0, 1.2], [1.2, 1.4])]
+    ladder = np.geomspace(1.0, 1.02, n)
+    systems = [pmc.System(pos, sp, 0.5, ladder[r], mm, seed=5, chain=r) for r in range(n)]
+    for s_ in systems:
+        s_.total_energy()
+    pool = [disp(0.065)]
+    tempering.run_tempering_local(systems, pool, ladder, 20, 10, seed=9)
+    t0 = time.perf_counter()
+    label, acc, att, _ = tempering.run_tempering_local(systems, pool, ladder, 100, 10, seed=9)
+    dt = time.perf_counter() - t0
+    mo = O.model_matrix(lambda e, sg: O.soft_spheres(e, sg, 14), ((1.0, 1.0), (1.0, 1.0)), ((1.0, 1.2), (1.2, 1.4)))
+    rows.append({"config": "C5: 8 replicas of 2-D binary r^-14 soft spheres, N=65536 each, rho=0.5, T=1.0..1.02, replica exchange every 10 sweeps (all on this GPU, shared launches)",
+                 "checkerboard_m1": {"moves_per_s": n * Nss * 100 / dt, "exchange_acceptance": acc / max(1, att), "rounds": 1},
+                 "cpu_oracle_moves_per_s": _oracle_rate(lambda: O.System(pos, sp, 0.5, 1.0, mo, O.LINKEDLIST),
+                                                        O.make_pool([{"kind": "Displacement", "sigma": 0.065}]), 5, budget_cpu_s)})
+    del systems
+    # -- parallel = true: 256 chains of N = 4096 in shared launches (checkerboard schedule)
+    pos, sp, rho = lj_lattice(16, jitter=0.05, seed=42)
+    chains = [pmc.System(pos, sp, rho, TEMPERATURE, pmc.LennardJones(1.0, 1.0), seed=42, chain=k) for k in range(256)]
+    pool = [disp()]
+    pmc.mc_sweep_many(chains, pool, nsweeps=50)
+    t0 = time.perf_counter()
+    sts = pmc.mc_sweep_many(chains, pool, nsweeps=200)
+    dt = time.perf_counter() - t0
+    tests = sum(float(x.pair_tests) for x in sts)
+    inr = sum(float(x.pairs_in_range) for x in sts)
+    rows.append({"config": "256 chains (parallel = true) of N=4096 3D LJ rho=1 T=1, shared launches (pmc_sweep_many)",
+                 "checkerboard_m1": {"moves_per_s": 256 * 4096 * 200 / dt, "rounds": 1,
+                                     "roofline_frac": (tests + inr) * 9.0 / dt / 1e12 / FP64_VECTOR_PEAK_TFLOPS if tests > 0 else None,
+                                     "acceptance": [sum(float(x.accepted[0]) for x in sts) / sum(float(x.attempted[0]) for x in sts)]}})
+    del chains
+    # -- the reference's own benchmark system as many chains on its own (sequential) chain
+    pos, sp, rho = lj_lattice(6, jitter=0.05, seed=42)
+    chains = [pmc.System(pos, sp, rho, TEMPERATURE, pmc.LennardJones(1.0, 1.0), seed=42, chain=k) for k in range(1000)]
+    pmc.mc_sweep_many(chains, pool, nsweeps=5, mode="sequential")
+    t0 = time.perf_counter()
+    sts = pmc.mc_sweep_many(chains, pool, nsweeps=100, mode="sequential")
+    dt = time.perf_counter() - t0
+    rate = 1000 * 216 * 100 / dt
+    rows.append({"config": "1000 chains (parallel = true) of the reference's benchmark system (benchmark/particles_benchmarks.jl:10-28: N=216 3D LJ rho=1), "
+                           "the reference's sequential chain, state in LDS, one wavefront per chain (pmc_sweep_many PMC_SEQUENTIAL)",
+                 "reference_order_chain": {"moves_per_s": rate, "us_per_step_per_chain": 1e6 * dt / (216 * 100),
+                                           "acceptance": [sum(float(x.accepted[0]) for x in sts) / sum(float(x.attempted[0]) for x in sts)],
+                                           "roofline_frac": _seq_flop_frac(216, 3, chains[0].neighbour_list.ncells, rate, 62.0)},
+                 "cpu_oracle_moves_per_s": _oracle_rate(lambda: O.System(pos, sp, rho, TEMPERATURE, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST),
+                                                        O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}]), 42, budget_cpu_s),
+                 "reference_published": "5.1 us per mc_step! on the reference authors' CPU (benchmark/particles_benchmarks.jl:28) = 1.96e5 moves/s per chain"})
+    return rows
 
 
 def run_rank(args):
@@ -553,9 +717,24 @@ def run_rank(args):
             out["n_ranks_rccl"] = rccl.get("n_ranks_rccl", 0)
         if stub:
             out["stub"] = True
+        if ngpus == 1 and not stub and not args.no_others and not args.only_headline:
+            # the reference's own chain on the headline's system (PMC_SEQUENTIAL: bit-identical to cpu_baseline's chain), then the
+            # other configurations; both leave the headline's figures above untouched (they run after them)
+            try:
+                out["reference_order_chain"] = reference_order_chain(pmc, system, pool)
+                out["reference_order_chain"]["roofline_frac"] = _seq_flop_frac(N, 3, ncell_ref, out["reference_order_chain"]["value"], 62.0)
+            except Exception as exc:
+                out["reference_order_chain"] = {"error": repr(exc)}
+            if not args.no_cpu:
+                try:
+                    out["other_configs"] = other_configs(pmc)
+                except Exception as exc:
+                    out["other_configs"] = {"error": repr(exc)}
         if ngpus == 1 and not args.no_cpu and not stub:
             out["cpu_baseline"] = cpu_baseline(head_state, sp, rho, 3_000_000)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            if isinstance(out.get("reference_order_chain"), dict) and "value" in out["reference_order_chain"]:
+                out["reference_order_chain"]["over_cpu_baseline"] = out["reference_order_chain"]["value"] / out["cpu_baseline"]["value"]
             try:
                 out["cpu_baseline_multicore"] = cpu_baseline_multicore(head_state, rho, out["cpu_baseline"]["value"])
             except Exception as exc:      # the single-core figure is the contract; this one is a courtesy
