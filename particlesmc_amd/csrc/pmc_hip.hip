@@ -1557,16 +1557,29 @@ static int cb_minwaves(const pmc_system *h, size_t lds)
         (void)done_;                                                                                            \
     } while (0)
 
+static void ticket_fallback(pmc_system *h)
+{
+    h->ticket_lanes = 1;
+    h->ticket_next = 0;
+    if (h->d_ticket) (void)hipMemset(h->d_ticket, 0, PMC_TICKET_LANES * PMC_TICKET_STRIDE * sizeof(unsigned long long));
+}
+
 static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
 {
     if (st[17] & 1ull)
         return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity (that cell's slots were "
                                             "skipped; moves accepted in other cells are kept and the energy is recomputed on the next call)");
-    if (st[17] & 2ull)
+    bool starved = (st[17] & 2ull) != 0;
+    if (!starved && h->ticket_lanes != 1)
+        if (const char *e = getenv("PMC_TEST_STARVE")) starved = (e[0] == '1');   // test hook: take the fallback after a good launch
+    if (starved)
     {
         // the eight-counter ticket scheme assumes in-order round-robin dispatch to the XCDs for its progress argument (DESIGN.md
-        // 4.3); whatever starved this launch, the handle takes the order-independent single counter from now on
-        h->ticket_lanes = 1;
+        // 4.3); whatever starved this launch, the handle takes the order-independent single counter from now on -- from a
+        // counter that is in step with ticket_next again (the eight per-XCD counters are zeroed by every sweep's first kernel,
+        // the single one is monotonic: after the switch it must not keep the aborted sweep's count).  The stream is idle
+        // here: the caller has just read `st` back.
+        ticket_fallback(h);
         return fail(h, PMC_ERR_STATE, "fused sweep: a cell's completion flag was never seen (positions were modified by a partial "
                                       "sweep: the chain is invalid; upload the configuration again -- the handle now draws its "
                                       "workgroup tickets from the single, dispatch-order-independent counter)");
@@ -2324,6 +2337,8 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         if (rcf) {
             cb_invalidate(h);
             if (!first) first = rcf;
+            if (rcf == PMC_ERR_STATE)      // a shared launch tickets through hs[0]: every chain of it leaves the eight-counter scheme
+                for (int q = 0; q < n; q++) ticket_fallback(hs[q]);
             continue;
         }
         h->e_fix += (long long)st[16];

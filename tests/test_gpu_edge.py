@@ -537,3 +537,42 @@ def test_engines_interleave_without_manual_rebuilds(gpu):
     att, acc = cb.sweeps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 3, 2)
     assert st.accepted[0] == acc[0] and np.array_equal(g.position, cb.positions())
     assert st.energy_fix == cb.energy_fix
+
+
+def test_ticket_fallback_after_a_starved_launch(gpu, monkeypatch):
+    """when a fused launch is declared starved the handle falls back from the eight per-XCD ticket counters to the
+    single monotonic one -- which must restart in step with the host's count, not at the aborted sweep's.  The hook
+    PMC_TEST_STARVE=1 declares a good launch starved; afterwards the chain (re-uploaded, as the error text asks) must follow the
+    oracle's schedule again, alone and in a shared launch."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(16, jitter=0.05, seed=42)
+    pool = [_disp(pmc, 0.05, 1.0)]
+    pool_o = O.make_pool([{"kind": "Displacement", "sigma": 0.05}])
+    g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=9)
+    pmc.mc_sweep(g, pool, nsweeps=2)
+    monkeypatch.setenv("PMC_TEST_STARVE", "1")
+    with pytest.raises(pmc.PMCError):
+        pmc.mc_sweep(g, pool, nsweeps=1)
+    monkeypatch.delenv("PMC_TEST_STARVE")
+    g.upload(pos, sp)
+    g.set_counters(0, 0)
+    cb = O.Checkerboard(pos, sp, g.box, 1.0, O.single(O.lennard_jones(1.0, 1.0)), seed=9)
+    st = pmc.mc_sweep(g, pool, nsweeps=3)
+    att, acc = cb.sweeps(pool_o, 0, 3)
+    assert st.accepted[0] == acc[0] and np.array_equal(g.position, cb.positions()) and st.energy_fix == cb.energy_fix
+    # ... and every chain of a shared launch
+    chains = [pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=9, chain=k) for k in range(3)]
+    pmc.mc_sweep_many(chains, pool, nsweeps=1)
+    monkeypatch.setenv("PMC_TEST_STARVE", "1")
+    with pytest.raises(pmc.PMCError):
+        pmc.mc_sweep_many(chains, pool, nsweeps=1)
+    monkeypatch.delenv("PMC_TEST_STARVE")
+    for k, c in enumerate(chains):
+        c.upload(pos, sp)
+        c.set_counters(0, 0)
+    sts = pmc.mc_sweep_many(chains, pool, nsweeps=2)
+    for k, c in enumerate(chains):
+        cbk = O.Checkerboard(pos, sp, c.box, 1.0, O.single(O.lennard_jones(1.0, 1.0)), seed=9, chain=k)
+        att, acc = cbk.sweeps(pool_o, 0, 2)
+        assert sts[k].accepted[0] == acc[0] and np.array_equal(c.position, cbk.positions())

@@ -244,3 +244,28 @@ def test_many_sequential_chains_in_one_launch(gpu):
     st = pmc.mc_sweep(alone, pool, nsweeps=4, mode="sequential")
     assert st.accepted[0] == stats[5].accepted[0] and np.array_equal(alone.position, chains[5].position)
     assert alone.energy[0] == chains[5].energy[0]
+
+
+@pytest.mark.parametrize("engine", [0, 1, 2, 3])
+def test_config1_readme_three_particles(gpu, engine):
+    """BASELINE config 1: the README's literal system (README.md:72-110: three 2-D LJ particles, density 1, T = 1, sigma_move
+    0.05, 500 Metropolis steps).  Its box (sqrt 3) is smaller than rcut = 2.5, which the LinkedList constructor cannot take
+    (src/neighbours.jl:237-239: ncells = 0; tests/test_abi.py checks the refusal), so the literal numbers run with the
+    reference's EmptyList, and the LinkedList form with the largest legal cutoff (one cell per side).  500 sweeps = 1500 steps
+    of the sequential chain against the oracle, every engine that accepts the list."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos = np.array([[0.1585, 0.4965], [1.7215, 0.7468], [0.7606, 1.1439]])
+    sp = np.ones(3, dtype=np.int32)
+    cases = [(pmc.LinkedList, O.LINKEDLIST, 1.7)]
+    if engine in (0, 1):
+        cases.append((pmc.EmptyList, O.EMPTYLIST, 2.5))
+    for lt_p, lt_o, rcut in cases:
+        g = pmc.System(pos, sp, 1.0, 1.0, pmc.LennardJones(1.0, 1.0, rcut=rcut), list_type=lt_p, seed=10)
+        o = O.System(pos, sp, 1.0, 1.0, O.single(O.lennard_jones(1.0, 1.0, rcut)), lt_o)
+        assert g.energy[0] == o.energy
+        g.set_sequential_engine(engine, 0)
+        st = pmc.mc_sweep(g, [_disp(pmc, 0.05)], nsweeps=500, mode="sequential")
+        att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 10, 0, 0, 1500)
+        assert st.attempted[0] == att[0] == 1500 and st.accepted[0] == acc[0]
+        assert np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
