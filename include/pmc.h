@@ -136,9 +136,19 @@ int pmc_verlet_list_geometry(int32_t d, const double *box, double rcut, double d
 /* -- state ---------------------------------------------------------------- */
 int pmc_upload(pmc_system *h, const double *pos, const int32_t *species);   /* system.position / .species */
 int pmc_download(pmc_system *h, double *pos, int32_t *species);
+/* Checkpoint and restart of a PMC_CHECKERBOARD chain.  Positions are never wrapped (src/moves.jl:46-48); the throughput
+ * engine therefore carries a persistent integer periodic image per particle and dimension, derived as floor(x / L) whenever it
+ * takes a state over (after pmc_upload, per-move verbs, PMC_SEQUENTIAL sweeps) and frozen while it runs (DESIGN.md 2.2
+ * "images").  A plain download + upload re-derives them, which changes the rounding of later moves of particles that have
+ * left the box: to continue a chain bit for bit store pmc_get_images with the positions (and pmc_get_counters), and after
+ * pmc_upload call pmc_set_images (and pmc_set_counters, pmc_set_energy).  img: N*d entries, |k| <= 511. */
+int pmc_get_images(pmc_system *h, int32_t *img);
+int pmc_set_images(pmc_system *h, const int32_t *img);
 int pmc_set_temperature(pmc_system *h, double T);               /* system.temperature */
 int pmc_get_temperature(pmc_system *h, double *T);
-int pmc_set_energy(pmc_system *h, double e);                    /* system.energy[1] */
+int pmc_set_energy(pmc_system *h, double e);                    /* system.energy[1]; not taken (and 0 returned) after a throughput
+                                                                   sweep that failed part-way: the positions have moved, the
+                                                                   library recomputes the energy before its next use */
 int pmc_get_energy(pmc_system *h, double *e);
 int pmc_set_counters(pmc_system *h, uint64_t step, uint64_t sweep);  /* RNG stream position */
 int pmc_get_counters(pmc_system *h, uint64_t *step, uint64_t *sweep);

@@ -75,6 +75,8 @@ SYMBOLS = {
     "pmc_get_verlet_neighbours": (C.c_int, [_h, C.c_int64, _lp, C.c_int64, _lp]),
     "pmc_upload": (C.c_int, [_h, _dp, _ip]),
     "pmc_download": (C.c_int, [_h, _dp, _ip]),
+    "pmc_get_images": (C.c_int, [_h, _ip]),
+    "pmc_set_images": (C.c_int, [_h, _ip]),
     "pmc_set_temperature": (C.c_int, [_h, C.c_double]),
     "pmc_get_temperature": (C.c_int, [_h, _dp]),
     "pmc_set_energy": (C.c_int, [_h, C.c_double]),

@@ -61,6 +61,7 @@ struct pmc_system {
     long long e_fix = 0;
     bool e_fix_valid = false;
     bool energy_stale = false;   // a partial throughput sweep changed positions without folding its dE: recompute before use
+    bool state_invalid = false;  // ... and until that recomputation (or an upload) no caller-side energy is taken (pmc_set_energy)
     bool cb_started = false;     // the current pmc_sweep call has enqueued sweep kernels (errors before that leave the state alone)
     uint64_t step_ctr = 0, sweep_ctr = 0;
     uint32_t key[2] = {0, 0};
@@ -650,6 +651,7 @@ extern "C" int pmc_upload(pmc_system *h, const double *pos, const int32_t *speci
         if (rc) return rc;
     }
     h->img_valid = false;      // (re-derived by the next throughput-engine entry: ensure_images)
+    h->state_invalid = false;
     h->cells_built = false;
     h->mc_binned = false;
     h->e_fix_valid = false;
@@ -726,6 +728,10 @@ static int refresh_stale_energy(pmc_system *h);
 extern "C" int pmc_set_energy(pmc_system *h, double e)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_energy: null handle");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    // After a throughput sweep that failed part-way the positions have moved and the caller's value belongs to the state
+    // before the call: it is not taken, and the running energy stays marked for recomputation (cb_invalidate).
+    if (h->state_invalid) return PMC_OK;
     h->energy = e;
     h->energy_stale = false;
     return PMC_OK;
@@ -1174,6 +1180,7 @@ static int refresh_stale_energy(pmc_system *h)
     h->energy_stale = false;
     const int rc = pmc_total_energy(h, nullptr, nullptr);
     if (rc) h->energy_stale = true;
+    else h->state_invalid = false;
     return rc;
 }
 
@@ -1303,6 +1310,49 @@ static int ensure_images(pmc_system *h)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->any_img = any != 0;
     h->img_valid = true;
+    return PMC_OK;
+}
+
+extern "C" int pmc_get_images(pmc_system *h, int32_t *img)
+{
+    if (!h || !img) return fail(h, PMC_ERR_BADARG, "pmc_get_images: null argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::fill(img, img + (size_t)h->N * h->D, 0);
+    if (!h->mc_ok) return PMC_OK;                  // no throughput grid: no images are ever used
+    rc = ensure_images(h);
+    if (rc) return rc;
+    std::vector<int> t((size_t)h->N);
+    HIPCHK(h, hipMemcpy(t.data(), h->d_img, t.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->N; i++)
+        for (int q = 0; q < h->D; q++) img[(size_t)i * h->D + q] = img_get(t[i], q);
+    return PMC_OK;
+}
+
+extern "C" int pmc_set_images(pmc_system *h, const int32_t *img)
+{
+    if (!h || !img) return fail(h, PMC_ERR_BADARG, "pmc_set_images: null argument");
+    if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
+    if (!h->mc_ok) return PMC_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<int> t((size_t)h->N);
+    bool any = false;
+    for (int i = 0; i < h->N; i++) {
+        int k[3] = {0, 0, 0};
+        for (int q = 0; q < h->D; q++) {
+            k[q] = img[(size_t)i * h->D + q];
+            if (k[q] < -PMC_IMG_MAX || k[q] > PMC_IMG_MAX) return fail(h, PMC_ERR_BADARG, "pmc_set_images: |image| must be <= 511");
+        }
+        t[i] = img_pack(k[0], k[1], k[2]);
+        any = any || t[i] != PMC_IMG_ZERO;
+    }
+    HIPCHK(h, hipMemcpy(h->d_img, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->any_img = any;
+    h->img_valid = true;
+    h->mc_binned = false;
+    h->e_fix_valid = false;
     return PMC_OK;
 }
 
@@ -1779,6 +1829,7 @@ static void cb_invalidate(pmc_system *h)
     h->e_fix_valid = false;
     h->img_valid = false;
     h->energy_stale = true;
+    h->state_invalid = true;
     h->mc_binned = false;
     h->cells_built = false;
     h->count_is_zero = false;
@@ -2512,10 +2563,14 @@ RcclApi *rccl_api()
     static bool tried = false;
     if (!tried) {
         tried = true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (api.lib) break;
-        }
+        // PMC_RCCL_LIB: another library with RCCL's entry points (tests/c/rccl_stub.c lets several processes that share one GPU
+        // drive this path; the real RCCL needs one device per rank)
+        if (const char *over = getenv("PMC_RCCL_LIB")) api.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (api.lib) break;
+            }
         if (api.lib) {
             api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
             api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));

@@ -28,7 +28,7 @@ def run(rank, world, device, outdir, nrounds, nsweeps=5, side=64):
     sp = np.ones(N, dtype=np.int32)
     sp[np.random.default_rng(2).permutation(N)[: N // 2]] = 2
     mm = [[pmc.SoftSpheres(1.0, s, 14) for s in row] for row in ([1.0, 1.2], [1.2, 1.4])]
-    ladder = np.geomspace(1.0, 1.12, world)
+    ladder = 1.016 ** np.arange(world)        # adjacent temperatures 1.6 % apart whatever the world size (8 ranks: 1.0 ... 1.12): exchanges do happen at N = 4096
     system = pmc.System(pos, sp, rho, float(ladder[rank]), mm, seed=5, chain=rank, device=device)   # one device per rank
     system.total_energy()
     comm = tempering.rccl_comm_from_env(device, id_file=os.path.join(outdir, "rccl_id"))

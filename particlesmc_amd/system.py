@@ -261,6 +261,16 @@ class Atoms(Particles):
         _lib.check(_lib.lib().pmc_set_rounds(self._h, int(m)), self._h)
 
 
+    # --- checkpoint / restart of a throughput chain (include/pmc.h: pmc_get_images) -----------------
+    def get_images(self):
+        img = np.zeros((self.N, self.d), dtype=np.int32)
+        _lib.check(_lib.lib().pmc_get_images(self._h, _ip(img)), self._h)
+        return img
+
+    def set_images(self, img):
+        img = np.ascontiguousarray(img, dtype=np.int32).reshape(self.N, self.d)
+        _lib.check(_lib.lib().pmc_set_images(self._h, _ip(img)), self._h)
+
     # --- how PMC_SEQUENTIAL sweeps run (same chain bit for bit; include/pmc.h) --------------------
     def set_sequential_engine(self, engine=0, window=0):
         """engine 0 auto, 1 the one-wavefront literal loop, 2 speculative windows; window: pending steps per round (0 auto)."""

@@ -73,26 +73,50 @@ def _env_int(names, default):
     return default
 
 
+def _launch_key():
+    """What every rank of ONE launch shares and no other launch has: the launcher's run / job id."""
+    import os
+    e = os.environ
+    if e.get("TORCHELASTIC_RUN_ID"):
+        return "te" + e["TORCHELASTIC_RUN_ID"] + "_" + e.get("MASTER_PORT", "")
+    for k in ("PMIX_NAMESPACE", "OMPI_MCA_ess_base_jobid", "OMPI_MCA_orte_ess_jobid"):
+        if e.get(k):
+            return "ompi" + e[k]
+    if e.get("SLURM_JOB_ID"):
+        return "slurm" + e["SLURM_JOB_ID"] + "." + e.get("SLURM_STEP_ID", "0")
+    if e.get("MASTER_PORT"):
+        return "port" + e["MASTER_PORT"]
+    return None
+
+
 def rccl_comm_from_env(device, tag="pmc", id_file=None):
     """One process per GPU without torch or MPI bindings: rank 0 creates the RCCL unique id (pmc_rccl_unique_id) and hands its
     128 bytes to the other ranks of the node through a file; every rank then joins through pmc_rccl_comm_create.
 
     Rank and world size are read from RANK / WORLD_SIZE (torchrun), OMPI_COMM_WORLD_RANK / _SIZE (mpirun) or SLURM_PROCID /
-    SLURM_NTASKS (srun).  The file is `id_file`, else $PMC_RCCL_ID_FILE, else a name in $TMPDIR built from the launcher's
-    run id (TORCHELASTIC_RUN_ID / SLURM_JOB_ID / MASTER_PORT) and, for launchers whose ranks share a parent, that parent's
-    PID.  Rank 0 removes any file of that name BEFORE it creates the id and removes its own file once ncclCommInitRank has
-    returned (it returns only after every rank has joined, i.e. has read the id); the other ranks ignore a file older than
-    five minutes, so an id left behind by a crashed job cannot be joined by accident."""
+    SLURM_NTASKS (srun).  The file is `id_file`, else $PMC_RCCL_ID_FILE, else a name in $TMPDIR built from the launch key (the
+    launcher's run / job id: TORCHELASTIC_RUN_ID, PMIX_NAMESPACE, SLURM_JOB_ID.SLURM_STEP_ID, MASTER_PORT) and, for launchers
+    whose ranks share a parent, that parent's PID; a world of more than one rank with NO launch key must name the file
+    (nothing would tell this launch's id from a crashed or concurrent job's).  The file carries, after the 128 bytes, the launch
+    key and rank 0's start time: a rank only takes a file whose key is its own and whose stamp is not older than its own start
+    by more than two minutes.  Rank 0 removes any file of that name BEFORE it creates the id and removes its own file once
+    ncclCommInitRank has returned (it returns only after every rank has joined, i.e. has read the id)."""
     import os
+    import struct
     import time
+    t_start = time.time()
     rank = _env_int(("RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID"), 0)
     world = _env_int(("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS"), 1)
     path = id_file or os.environ.get("PMC_RCCL_ID_FILE")
+    key = _launch_key() or ""
     if not path:
-        run = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("MASTER_PORT", "0")
+        if world > 1 and not key:
+            raise RuntimeError("rccl_comm_from_env: more than one rank and no launcher run id in the environment: name the id "
+                               "file (PMC_RCCL_ID_FILE or id_file=), one per launch")
         shared_parent = "RANK" in os.environ and "OMPI_COMM_WORLD_RANK" not in os.environ and "SLURM_PROCID" not in os.environ
         owner = os.getpid() if world == 1 else (os.getppid() if shared_parent else 0)
-        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"{tag}_rccl_id_{run}_{owner}")
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"{tag}_rccl_id_{key or 'single'}_{owner}")
+    kbytes = key.encode()[:64].ljust(64, b"\0")
     if rank == 0:
         try:
             os.remove(path)                      # a stale id of an earlier job with this name
@@ -100,20 +124,20 @@ def rccl_comm_from_env(device, tag="pmc", id_file=None):
             pass
         uid = RcclComm.unique_id()
         with open(path + ".tmp", "wb") as f:
-            f.write(uid)
+            f.write(uid + kbytes + struct.pack("<d", t_start))
         os.replace(path + ".tmp", path)
     else:
         t0 = time.time()
         while True:
             try:
-                if time.time() - os.path.getmtime(path) < 300.0:
-                    uid = open(path, "rb").read()
-                    if len(uid) == 128:
-                        break
+                blob = open(path, "rb").read()
+                if len(blob) == 128 + 64 + 8 and blob[128:192] == kbytes and struct.unpack("<d", blob[192:])[0] > t_start - 120.0:
+                    uid = blob[:128]
+                    break
             except FileNotFoundError:
                 pass
             if time.time() - t0 > 120:
-                raise TimeoutError(f"no fresh RCCL id from rank 0 at {path}")
+                raise TimeoutError(f"no RCCL id of this launch from rank 0 at {path}")
             time.sleep(0.05)
     comm = RcclComm(uid, rank, world, device)    # collective: returns once every rank has joined
     if rank == 0:

@@ -95,3 +95,30 @@ def test_unwrapped_input_takes_the_fast_path(gpu):
     assert abs(rates[1][1] - rates[0][1]) < 0.01 * rates[0][1]
     assert abs(rates[1][2] - rates[0][2]) < 0.01 * rates[0][2]
     assert rates[1][0] > 0.9 * rates[0][0], rates
+
+
+def test_checkpoint_restart_with_images_is_bit_identical(gpu):
+    """a chain that starts folded keeps k = 0 while its particles diffuse out of the box; download + upload
+    re-derives k = floor(x / L) and the restarted chain rounds differently.  With pmc_get_images / pmc_set_images (and the
+    counters and the energy) in the checkpoint, the restarted chain is the uninterrupted one bit for bit."""
+    pmc = gpu
+    pos, sp, rho = lj_lattice(16, jitter=0.05, seed=42)
+    pool = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.15}, 1.0)]
+    a = pmc.System(pos, sp, rho, 1.5, pmc.LennardJones(1.0, 1.0), seed=3)
+    pmc.mc_sweep(a, pool, nsweeps=400)
+    L = a.box[0]
+    p1 = a.position
+    assert ((p1 < 0) | (p1 >= L)).any(), "no particle has left the box: the test would prove nothing"
+    img, ctr, e1 = a.get_images(), a.get_counters(), a.energy[0]
+    assert not img.any()                                   # the run started folded: frozen at 0
+    sa = pmc.mc_sweep(a, pool, nsweeps=10)
+    b = pmc.System(p1, sp, rho, 1.5, pmc.LennardJones(1.0, 1.0), seed=3)     # restart WITH the checkpointed images
+    b.set_images(img)
+    b.set_counters(*ctr)
+    sb = pmc.mc_sweep(b, pool, nsweeps=10)
+    assert np.array_equal(a.position, b.position) and sa.accepted[0] == sb.accepted[0]
+    c = pmc.System(p1, sp, rho, 1.5, pmc.LennardJones(1.0, 1.0), seed=3)     # ... and without: images re-derived, another chain
+    c.set_counters(*ctr)
+    assert c.get_images().any()
+    pmc.mc_sweep(c, pool, nsweeps=10)
+    assert not np.array_equal(a.position, c.position)
