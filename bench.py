@@ -647,6 +647,26 @@ def run_rank(args):
         legs[m] = leg(stm, elm, args.steps, m)
         if m == args.rounds:
             st, elapsed = stm, elm
+    # call granularity: the same 64 sweeps as 64 calls of one sweep, 16 of four, one of 64 (every call ends with a counter fold
+    # and a synchronisation; with m > 1 a call shorter than m sweeps is a shorter pass: DESIGN.md 2.2 "passes and calls")
+    by_call = None
+    if not args.only_headline and not stub:
+        by_call = {}
+        for m in sorted({1, args.rounds}):
+            set_rounds(m)
+            sweep(max(4, m))
+            by_call[str(m)] = {}
+            for per_call in (1, 4, 64):
+                ncalls = 64 // per_call
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(ncalls):
+                    sweep(per_call)
+                sync()
+                el = time.perf_counter() - t0
+                barrier()
+                by_call[str(m)][str(per_call)] = float(N) * 64 * ngpus / el
+        set_rounds(args.rounds)
     long_run = None
     if args.long_steps > 0 and not args.only_headline:
         set_rounds(args.rounds)
@@ -708,6 +728,9 @@ def run_rank(args):
             "by_rounds": {str(m): legs[m] for m in sorted(legs)},
             "roofline": roofline_objects(N, timed_steps, st, avg_launch_s, moves_per_launch, ncell_ref),
         }
+        if by_call is not None:
+            out["by_call_size"] = {"unit": "attempted moves/s over 64 sweeps issued as calls of 1 / 4 / 64 sweeps (rank 0's clock)",
+                                   "by_rounds": by_call}
         if long_run is not None:
             out["long_run"] = long_run
         if from_lattice is not None:

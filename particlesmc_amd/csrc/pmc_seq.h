@@ -174,8 +174,32 @@ __device__ __forceinline__ double sq_vector_1d(double c1, double c2, double L, d
     const double dx = c1 - c2;
     const double q = dx * invL;
     double n = rint(q);
-    if (fabs(fabs(q - n) - 0.5) <= (fabs(q) + 1.0) * 0x1p-48) n = rint(dx / L);
+    // q is within |q| 2^-51 of dx / L: below 2^20 boxes that is < 2^-31, so the two can only round apart when q is within
+    // 1e-4 of a half-integer (a generous band: the division costs nothing when it is not taken)
+    if (fabs(q - n) > 0.4999 || fabs(q) > 1048576.0) n = rint(dx / L);
     return dx - n * L;
+}
+
+// get_cell + cell_index (src/neighbours.jl:178-180, 79-88) of a position: Julia's float fld is floor(x / cell) computed through
+// mod (ref_cell_of: an fmod and two roundings).  Away from a cell edge the plain quotient's floor is the same integer; within
+// rounding distance of an edge the reference's own sequence of operations decides.
+template <int D>
+__device__ __forceinline__ int sq_cell_of(const RefArgs &a, const double *x)
+{
+    long long c = 0, stride = 1;
+    bool edge = false;
+#pragma unroll
+    for (int q = D - 1; q >= 0; q--) {
+        const double qv = x[q] / a.cell[q];
+        const double f = floor(qv);
+        const double r = qv - f;
+        const double tol = fabs(qv) * 0x1p-48 + 0x1p-60;
+        edge = edge || r < tol || 1.0 - r < tol || !(fabs(qv) < 4.0e15);
+        const long long mc = (long long)f;
+        c += (mc - dev_fld_i(mc, a.nc[q]) * a.nc[q]) * stride;
+        stride *= a.nc[q];
+    }
+    return edge ? ref_cell_of<D>(a, x) : (int)c;
 }
 
 template <int D>
@@ -198,16 +222,68 @@ __device__ __forceinline__ int __reduce_max_sync_compat(int v)
     return v;
 }
 
-// acc += u for the lanes whose u is not 0, in lane order (a zero term leaves an FP64 sum as it is)
-__device__ __forceinline__ double sq_ordered_add(double acc, double u)
+// Ordered FP64 sums through LDS.  The chain acc += u_k must run in iterator order, one rounding per term; terms that are 0 can
+// be left out.  Lanes deposit their non-zero terms, in lane order, behind the terms already there (sq_terms_push); the sum is
+// then one chain of dependent additions fed by LDS reads that do not depend on it (sq_terms_sum): ~10 cycles per term, where
+// a ballot / readlane loop over the lanes of a register takes ~100.  Buffers hold SQ_TERMS terms and are summed down whenever
+// the next 64 might not fit, which keeps the order.
+#define SQ_TERMS 192
+#define SQ_TERMS_PAD 8
+#define SQ_TERMS_BUF (SQ_TERMS + 64 + SQ_TERMS_PAD)     // doubles of one buffer
+
+__device__ __forceinline__ double sq_terms_sum(double *buf, int n, double acc)
 {
-    unsigned long long mk = __ballot(u != 0.0);
-    while (mk) {
-        const int k = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mk));
-        acc += readlane_double(u, k);
-        mk &= mk - 1;
+    const int lane = wave_lane();
+    if (lane < SQ_TERMS_PAD) buf[n + lane] = 0.0;               // (+0.0 leaves the sum as it is: the loop runs in blocks of 8)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the terms are in LDS
+    for (int k = 0; k < n; k += SQ_TERMS_PAD) {
+        const double t0 = buf[k], t1 = buf[k + 1], t2 = buf[k + 2], t3 = buf[k + 3];
+        const double t4 = buf[k + 4], t5 = buf[k + 5], t6 = buf[k + 6], t7 = buf[k + 7];
+        acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; acc += t6; acc += t7;
     }
     return acc;
+}
+
+// two sums at once: their chains are independent and interleave
+__device__ __forceinline__ void sq_terms_sum2(double *bufa, int na, double &acca, double *bufb, int nb, double &accb)
+{
+    const int lane = wave_lane();
+    if (lane < SQ_TERMS_PAD) { bufa[na + lane] = 0.0; bufb[nb + lane] = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    double a = acca, b = accb;
+    const int n = max(na, nb);
+    // (both buffers are SQ_TERMS + 64 + 8 long: reading one past its own terms is safe, and masked)
+    for (int k = 0; k < n; k += SQ_TERMS_PAD) {
+        double ta[SQ_TERMS_PAD], tb[SQ_TERMS_PAD];
+#pragma unroll
+        for (int q = 0; q < SQ_TERMS_PAD; q++) { ta[q] = bufa[k + q]; tb[q] = bufb[k + q]; }     // sixteen reads in flight
+        const bool ina = k < na, inb = k < nb;              // (a block that starts inside the terms ends inside their zero padding)
+#pragma unroll
+        for (int q = 0; q < SQ_TERMS_PAD; q++) {
+            a += ina ? ta[q] : 0.0;
+            b += inb ? tb[q] : 0.0;
+        }
+    }
+    acca = a;
+    accb = b;
+}
+
+__device__ __forceinline__ void sq_terms_push(double *buf, int &n, double u)
+{
+    const unsigned long long mk = __ballot(u != 0.0);
+    if (mk) {
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (u != 0.0) buf[n + rank] = u;
+        n += __popcll(mk);
+    }
+}
+
+// the evaluation's dynamic LDS: ids_cap ints of neighbour ids, then the two term buffers
+__device__ __forceinline__ double *sq_terms_buffer(const SqArgs &s, int *lds_ids)
+{
+    return reinterpret_cast<double *>(lds_ids + ((s.ids_cap + 3) & ~3));
 }
 
 // The ids the iterator of the list yields for a particle in cell c, in order, into LDS (i itself is among them where the
@@ -267,7 +343,9 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
     const RefArgs &a = s.a;
     const int lane = wave_lane();
     const int total = sq_sequence<D>(s, c, lds_ids);
+    double *bufa = sq_terms_buffer(s, lds_ids), *bufb = bufa + SQ_TERMS_BUF;
     double acc_a = 0.0, acc_b = 0.0;
+    int na = 0, nb = 0;
     for (int base = 0; base < total; base += SQ_CHUNK * PMC_WAVE) {
         int j[SQ_CHUNK], sj[SQ_CHUNK];
         double xj[SQ_CHUNK][3];
@@ -296,10 +374,15 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
                     if (!(r2b > m.rcut2)) ub = dev_potential_dyn(r2b, m);
                 }
             }
-            acc_a = sq_ordered_add(acc_a, ua);
-            if (BOTH) acc_b = sq_ordered_add(acc_b, ub);
+            if (na > SQ_TERMS || nb > SQ_TERMS) {                // the next 64 terms might not fit: sum down, in order
+                sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
+                na = nb = 0;
+            }
+            sq_terms_push(bufa, na, ua);
+            if (BOTH) sq_terms_push(bufb, nb, ub);
         }
     }
+    sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
     ea = acc_a;
     eb = acc_b;
 }
@@ -313,7 +396,9 @@ __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int 
     const RefArgs &a = s.a;
     const int lane = wave_lane();
     const int total = sq_sequence<D>(s, c, lds_ids);
+    double *bufa = sq_terms_buffer(s, lds_ids), *bufb = bufa + SQ_TERMS_BUF;
     double acc_a = 0.0, acc_b = 0.0;
+    int na = 0, nb = 0;
     for (int base = 0; base < total; base += SQ_CHUNK * PMC_WAVE) {
         int j[SQ_CHUNK], sj[SQ_CHUNK];
         double xj[SQ_CHUNK][3];
@@ -340,10 +425,15 @@ __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int 
                 const DevModel &m2 = a.models[sp2 * a.S + (j[u] == other ? sp1 : sj[u])];
                 if (!(r2 > m2.rcut2)) ub = dev_potential_dyn(r2, m2);
             }
-            acc_a = sq_ordered_add(acc_a, ua);
-            acc_b = sq_ordered_add(acc_b, ub);
+            if (na > SQ_TERMS || nb > SQ_TERMS) {
+                sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
+                na = nb = 0;
+            }
+            sq_terms_push(bufa, na, ua);
+            sq_terms_push(bufb, nb, ub);
         }
     }
+    sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
     e_before = acc_a;
     e_after = acc_b;
 }
@@ -373,7 +463,7 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
             xr[q] = xn[q] + (-sl.d[q]);                // ... and the reverted position (src/moves.jl:76-90)
         }
         const int c0 = sl.c0, c1 = sl.c1;
-        const int c2 = ref_cell_of<D>(a, xr);
+        const int c2 = sq_cell_of<D>(a, xr);
         const int spi = a.S > 1 ? a.species[i] : 0;
         if (c1 == c0) {
             sq_pass<D, true>(s, c0, i, spi, x, xn, lds_ids, e1, e2);
@@ -819,8 +909,8 @@ __global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
         sl.xr[k] = 0.0;
     }
     if (i >= 0) {                                       // (a null step has no cells and interacts with nothing)
-        sl.c0 = ref_cell_of<D>(a, sl.x);
-        sl.c1 = ref_cell_of<D>(a, sl.xn);
+        sl.c0 = sq_cell_of<D>(a, sl.x);
+        sl.c1 = sq_cell_of<D>(a, sl.xn);
         sl.c2 = sl.c0;
         sq_pack_cells<D>(a, sl.c0, sl.c1, sl.pk);
     }
@@ -879,9 +969,17 @@ struct SqLdsArgs {
     int reverse;
     int ncell;
     // byte offsets of the arrays inside the dynamic LDS block
-    int o_rows, o_ccount, o_cs, o_spids, o_spheads, o_species, o_seq, o_gen, o_nbr, o_nbrcnt, o_spoff;
+    int o_rows, o_ccount, o_cs, o_spids, o_spheads, o_species, o_seq, o_gen, o_nbr, o_nbrcnt, o_spoff, o_terms, o_tmask, o_esum;
     int nbr_in_lds;
+    int max_trips;           // trips of 64 candidates a neighbourhood can have (3^d rows of cl_cap ids)
+    int dbg;                 // PMC_SEQ_DBG, timing experiments only (results invalid): 1 no cell of the trial position, 2 no ordered sums, 4 no pair terms, 8 no sequence
 };
+
+#ifdef SQ_TIMING
+#define SQT(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sqt_acc[k] += now_ - sqt_last; sqt_last = now_; } while (0)
+#else
+#define SQT(k)
+#endif
 
 struct SqLdsView {
     double *pos;
@@ -890,13 +988,21 @@ struct SqLdsView {
     SqGen *gen;
     const int *nbr, *nbrcnt;
     int *spoff;
+    double *terms;               // the non-zero pair terms of the two sums of a pass, packed in iterator order (sq_terms_push)
+    int *tcount;                 // NW > 1: [2][trips] terms per trip
+    double *esum;                // [4]: results of the ordered sums
 };
 
-template <int D>
+// NW wavefronts per chain: team helpers (NW == 1: no barrier instructions beyond the wave's own)
+template <int NW> __device__ __forceinline__ int sql_wave() { return NW == 1 ? 0 : (int)(threadIdx.x >> 6); }
+
+// The ids the iterator yields for a particle in cell c, in order, into v.seq; returns their number.  Row l is copied by wavefront
+// l mod NW.
+template <int D, int NW>
 __device__ __forceinline__ int sql_sequence(const SqLdsArgs &s, const SqLdsView &v, int c)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
-    const int lane = wave_lane();
+    const int lane = wave_lane(), wv = sql_wave<NW>();
     const int cap = s.a.cl_cap;
     const int cnt = v.nbrcnt[c];
     const int cc = (lane < cnt) ? v.nbr[(size_t)c * s.a.nnmax + lane] : 0;
@@ -909,22 +1015,19 @@ __device__ __forceinline__ int sql_sequence(const SqLdsArgs &s, const SqLdsView 
     }
     const int off = incl - len;
     const int total = __shfl(incl, 31, PMC_WAVE);
-    const int maxlen = __reduce_max_sync_compat(len);
-    __syncthreads();
+    __syncthreads();                               // the previous pass has read v.seq
 #pragma unroll
     for (int l = 0; l < NN; l++) {
+        if (NW > 1 && (l % NW) != wv) continue;
         const int len_l = __builtin_amdgcn_readlane(len, l);
         const int cc_l = __builtin_amdgcn_readlane(cc, l);
         const int off_l = __builtin_amdgcn_readlane(off, l);
         for (int k = lane; k < len_l; k += PMC_WAVE)
             v.seq[off_l + (s.reverse ? len_l - 1 - k : k)] = v.rows[cc_l * cap + k];
     }
-    (void)maxlen;
     __syncthreads();
     return total;
 }
-
-__device__ __forceinline__ double sql_vector_1d(double c1, double c2, double L, double invL) { return sq_vector_1d(c1, c2, L, invL); }
 
 template <int D>
 __device__ __forceinline__ double sql_dist2(const SqLdsArgs &s, const double *xi, const double *xj)
@@ -940,19 +1043,25 @@ __device__ __forceinline__ double sql_dist2(const SqLdsArgs &s, const double *xi
 }
 
 // compute_energy_particle at xa (and xb when BOTH) over the neighbourhood of cell c; species spa at xa, spb at xb; `other`
-// (a swap partner, or -1) is seen with species sp_other at xb (src/moves.jl:159-167)
-template <int D, bool BOTH>
+// (a swap partner, or -1) is seen with species sp_other at xb (src/moves.jl:159-167).  The trips of 64 candidates are dealt to
+// the NW wavefronts; the two sums are then taken in iterator order by wavefront 0 (ea) and wavefront 1 (eb).
+template <int D, bool BOTH, int NW>
 __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v, int c, int i, int spa, int spb, int other, int sp_other,
                                          const double *xa, const double *xb, double &ea, double &eb)
 {
-    const int lane = wave_lane();
+    const int lane = wave_lane(), wv = sql_wave<NW>();
     const int S = s.a.S;
-    const int total = sql_sequence<D>(s, v, c);
+    const int total = (s.dbg & 8) ? 216 : sql_sequence<D, NW>(s, v, c);
+    const int ntrip = (total + PMC_WAVE - 1) / PMC_WAVE;
+    constexpr int SEG = PMC_WAVE + SQ_TERMS_PAD;                  // NW > 1: one segment of packed terms per trip and sum
+    constexpr int BUF = SQ_TERMS + PMC_WAVE + SQ_TERMS_PAD;      // NW == 1: one buffer per sum, summed down when nearly full
     double acc_a = 0.0, acc_b = 0.0;
-    for (int base = 0; base < total; base += PMC_WAVE) {
-        const int t = base + lane;
+    int na = 0, nb = 0;
+    double *bufa = v.terms, *bufb = v.terms + (NW == 1 ? BUF : s.max_trips * SEG);
+    for (int tr = (NW == 1 ? 0 : wv); tr < ntrip; tr += NW) {
+        const int t = tr * PMC_WAVE + lane;
         double ua = 0.0, ub = 0.0;
-        if (t < total) {
+        if (t < total && !(s.dbg & 4)) {
             const int j = v.seq[t];
             if (j != i) {
                 double xj[3] = {0, 0, 0};
@@ -969,22 +1078,51 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
                 }
             }
         }
-        acc_a = sq_ordered_add(acc_a, ua);
-        if (BOTH) acc_b = sq_ordered_add(acc_b, ub);
+        if (s.dbg & 2) continue;
+        if (NW == 1) {
+            if (na > SQ_TERMS || nb > SQ_TERMS) {                // the next 64 terms might not fit: sum down, in order
+                sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
+                na = nb = 0;
+            }
+            sq_terms_push(bufa, na, ua);
+            if (BOTH) sq_terms_push(bufb, nb, ub);
+        } else {
+            int ca = 0, cb = 0;
+            sq_terms_push(bufa + tr * SEG, ca, ua);
+            if (BOTH) sq_terms_push(bufb + tr * SEG, cb, ub);
+            if (lane == 0) { v.tcount[tr] = ca; if (BOTH) v.tcount[s.max_trips + tr] = cb; }
+        }
+    }
+    if (NW == 1) {
+        if (!(s.dbg & 2)) sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
+    } else {
+        __syncthreads();
+        if ((wv == 0 || (BOTH && wv == 1)) && !(s.dbg & 2)) {
+            double *seg = wv == 0 ? bufa : bufb;
+            double acc = 0.0;
+            for (int tr = 0; tr < ntrip; tr++) acc = sq_terms_sum(seg + tr * SEG, v.tcount[wv * s.max_trips + tr], acc);
+            if (lane == 0) v.esum[wv] = acc;
+        }
+        __syncthreads();
+        acc_a = v.esum[0];
+        if (BOTH) acc_b = v.esum[1];
     }
     ea = acc_a;
     eb = acc_b;
 }
 
+// update_neighbour_list!: i leaves the row of `from` (order kept) and is appended to the row of `to`.  Wavefront 0 works, every
+// wavefront of the chain takes part in the barriers.
+template <int NW>
 __device__ __forceinline__ void sql_row_move(const SqLdsArgs &s, const SqLdsView &v, int from, int to, int i)
 {
-    // update_neighbour_list!: i leaves the row of `from` (order kept) and is appended to the row of `to`
     const int lane = wave_lane();
+    const bool w0 = sql_wave<NW>() == 0;
     const int cap = s.a.cl_cap;
     unsigned short *row = v.rows + from * cap;
     const int n = v.ccount[from];
     int p = -1;
-    for (int base = 0; base < n; base += PMC_WAVE) {
+    for (int base = 0; base < n; base += PMC_WAVE) {        // (every wavefront searches: p stays uniform over the chain's threads)
         const int k = base + lane;
         const unsigned long long mk = __ballot(k < n && row[k] == i);
         if (mk) { p = base + (int)__builtin_ctzll(mk); break; }
@@ -994,13 +1132,13 @@ __device__ __forceinline__ void sql_row_move(const SqLdsArgs &s, const SqLdsView
         for (int base = p; base < n - 1; base += PMC_WAVE) {
             const int k = base + lane;
             unsigned short t = 0;
-            if (k < n - 1) t = row[k + 1];
+            if (w0 && k < n - 1) t = row[k + 1];
             __syncthreads();
-            if (k < n - 1) row[k] = t;
+            if (w0 && k < n - 1) row[k] = t;
             __syncthreads();
         }
     }
-    if (lane == 0) {
+    if (w0 && lane == 0) {
         const int nfrom = (p >= 0) ? n - 1 : n;
         v.ccount[from] = (unsigned short)nfrom;
         const int n2 = (from == to) ? nfrom : (int)v.ccount[to];
@@ -1016,13 +1154,13 @@ __device__ __forceinline__ void sql_row_move(const SqLdsArgs &s, const SqLdsView
     __syncthreads();
 }
 
-template <int D>
-__global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sql_smem[];
     const RefArgs &a = s.a;
     SqChain &ch = s.chains[blockIdx.x];
-    const int lane = wave_lane();
+    const int tid = threadIdx.x, nth = NW * 64;
     const int N = a.N, S = a.S, cap = a.cl_cap;
     SqLdsView v;
     v.pos = reinterpret_cast<double *>(sql_smem);
@@ -1035,27 +1173,30 @@ __global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
     v.seq = reinterpret_cast<unsigned short *>(sql_smem + s.o_seq);
     v.gen = reinterpret_cast<SqGen *>(sql_smem + s.o_gen);
     v.spoff = reinterpret_cast<int *>(sql_smem + s.o_spoff);
+    v.terms = reinterpret_cast<double *>(sql_smem + s.o_terms);
+    v.tcount = reinterpret_cast<int *>(sql_smem + s.o_tmask);
+    v.esum = reinterpret_cast<double *>(sql_smem + s.o_esum);
     if (s.nbr_in_lds) {
         int *lnbr = reinterpret_cast<int *>(sql_smem + s.o_nbr), *lcnt = reinterpret_cast<int *>(sql_smem + s.o_nbrcnt);
-        for (int k = lane; k < s.ncell * a.nnmax; k += PMC_WAVE) lnbr[k] = a.nbr[k];
-        for (int k = lane; k < s.ncell; k += PMC_WAVE) lcnt[k] = a.nbrcnt[k];
+        for (int k = tid; k < s.ncell * a.nnmax; k += nth) lnbr[k] = a.nbr[k];
+        for (int k = tid; k < s.ncell; k += nth) lcnt[k] = a.nbrcnt[k];
         v.nbr = lnbr; v.nbrcnt = lcnt;
     } else {
         v.nbr = a.nbr; v.nbrcnt = a.nbrcnt;
     }
     // -- the chain's state into LDS
-    for (int k = lane; k < N * D; k += PMC_WAVE) v.pos[k] = ch.pos[k];
-    for (int k = lane; k < N; k += PMC_WAVE) {
+    for (int k = tid; k < N * D; k += nth) v.pos[k] = ch.pos[k];
+    for (int k = tid; k < N; k += nth) {
         v.species[k] = (unsigned char)ch.species[k];
         v.cs[k] = (unsigned short)ch.cs[k];
         v.spids[k] = (unsigned short)ch.sp_ids[k];
         v.spheads[k] = (unsigned short)ch.sp_heads[k];
     }
-    for (int k = lane; k <= S; k += PMC_WAVE) v.spoff[k] = ch.sp_off[k];
+    for (int k = tid; k <= S; k += nth) v.spoff[k] = ch.sp_off[k];
     for (int c = 0; c < s.ncell; c++) {
         const int n = ch.ccount[c];
-        if (lane == 0) v.ccount[c] = (unsigned short)n;
-        for (int k = lane; k < n; k += PMC_WAVE) v.rows[c * cap + k] = (unsigned short)ch.cl_items[(size_t)c * cap + k];
+        if (tid == 0) v.ccount[c] = (unsigned short)n;
+        for (int k = tid; k < n; k += nth) v.rows[c * cap + k] = (unsigned short)ch.cl_items[(size_t)c * cap + k];
     }
     __syncthreads();
     double E = ch.energy;
@@ -1064,10 +1205,11 @@ __global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
 #pragma unroll
     for (int q = 0; q < 8; q++) { att[q] = 0; acc[q] = 0; }
     const unsigned long long gend = ch.step0 + (unsigned long long)s.nsteps;
-    for (unsigned long long g0 = ch.step0; g0 < gend; g0 += PMC_WAVE) {
-        // -- random parts of the next 64 steps, one per lane: the words and operations of k_ref_ops for step g
+    constexpr int NGEN = NW * 64;                           // random parts generated at once, one step per thread
+    for (unsigned long long g0 = ch.step0; g0 < gend; g0 += NGEN) {
         {
-            const unsigned long long g = g0 + (unsigned long long)lane;
+            // the words and operations of k_ref_ops for step g
+            const unsigned long long g = g0 + (unsigned long long)tid;
             uint32_t R[4], Q[4];
             philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, ch.key0, ch.key1, R);
             philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ1, ch.key0, ch.key1, Q);
@@ -1083,10 +1225,10 @@ __global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
                 for (int q = 0; q < 3; q++) o.d[q] = s.pool.sigma[o.m] * z[q];
             }
             __syncthreads();
-            v.gen[lane] = o;
+            v.gen[tid] = o;
             __syncthreads();
         }
-        const int nt = (int)min((unsigned long long)PMC_WAVE, gend - g0);
+        const int nt = (int)min((unsigned long long)NGEN, gend - g0);
         for (int t = 0; t < nt; t++) {
             const SqGen ge = v.gen[t];
             const int m = ge.m;
@@ -1101,30 +1243,30 @@ __global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
                     xr[q] = xn[q] + (-ge.d[q]);
                 }
                 const int c0 = v.cs[i];                       // the list is current: cs[i] is the cell of x_i
-                const int c1 = ref_cell_of<D>(a, xn);
+                const int c1 = (s.dbg & 1) ? c0 : sq_cell_of<D>(a, xn);
                 const int spi = (S > 1) ? (int)v.species[i] : 0;
                 double e1, e2, dummy;
                 if (c1 == c0) {
-                    sql_pass<D, true>(s, v, c0, i, spi, spi, -1, 0, x, xn, e1, e2);
+                    sql_pass<D, true, NW>(s, v, c0, i, spi, spi, -1, 0, x, xn, e1, e2);
                 } else {
-                    sql_pass<D, false>(s, v, c0, i, spi, spi, -1, 0, x, x, e1, dummy);
-                    sql_pass<D, false>(s, v, c1, i, spi, spi, -1, 0, xn, xn, e2, dummy);
+                    sql_pass<D, false, NW>(s, v, c0, i, spi, spi, -1, 0, x, x, e1, dummy);
+                    sql_pass<D, false, NW>(s, v, c1, i, spi, spi, -1, 0, xn, xn, e2, dummy);
                 }
                 double de = 0.0;
                 if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }           // src/moves.jl:13-18
                 ok = ge.lnu < -(e2 - e1) / T;
                 if (ok) {
-                    if (lane < D) v.pos[i * D + lane] = xn[lane];
-                    if (c1 != c0) sql_row_move(s, v, c0, c1, i);
+                    if (tid < D) v.pos[i * D + tid] = xn[tid];
+                    if (c1 != c0) sql_row_move<NW>(s, v, c0, c1, i);
                 } else {
                     E -= de;                                                         // src/moves.jl:79
                     bool chg = false;
 #pragma unroll
                     for (int q = 0; q < D; q++) chg |= sq_bits_differ(xr[q], x[q]);
-                    if (chg && lane < D) v.pos[i * D + lane] = xr[lane];
-                    const int c2 = chg ? ref_cell_of<D>(a, xr) : c0;
-                    if (c1 != c0) sql_row_move(s, v, c0, c1, i);
-                    if (c2 != c1) sql_row_move(s, v, c1, c2, i);
+                    if (chg && tid < D) v.pos[i * D + tid] = xr[tid];
+                    const int c2 = chg ? sq_cell_of<D>(a, xr) : c0;
+                    if (c1 != c0) sql_row_move<NW>(s, v, c0, c1, i);
+                    if (c2 != c1) sql_row_move<NW>(s, v, c1, c2, i);
                 }
                 __syncthreads();
             } else {
@@ -1138,14 +1280,14 @@ __global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
                     for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
                     const int spi = v.species[i], spj = v.species[j];
                     double e1i, e2i, e1j, e2j;
-                    sql_pass<D, true>(s, v, v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
-                    sql_pass<D, true>(s, v, v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
+                    sql_pass<D, true, NW>(s, v, v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
+                    sql_pass<D, true, NW>(s, v, v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
                     const double e1 = e1i + e1j, e2 = e2i + e2j;
                     double de = 0.0;
                     if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
                     ok = ge.lnu < -(e2 - e1) / T;
                     if (ok) {
-                        if (lane == 0) {
+                        if (tid == 0) {
                             v.species[i] = (unsigned char)spj;
                             v.species[j] = (unsigned char)spi;
                             // update_species_list!, src/moves.jl:175-179
@@ -1170,8 +1312,8 @@ __global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
     }
     // -- back to global memory: positions, species, SpeciesList, rows, cs, ccount, and head / list rebuilt from the rows
     __syncthreads();
-    for (int k = lane; k < N * D; k += PMC_WAVE) ch.pos[k] = v.pos[k];
-    for (int k = lane; k < N; k += PMC_WAVE) {
+    for (int k = tid; k < N * D; k += nth) ch.pos[k] = v.pos[k];
+    for (int k = tid; k < N; k += nth) {
         ch.species[k] = v.species[k];
         ch.cs[k] = v.cs[k];
         ch.sp_ids[k] = v.spids[k];
@@ -1179,17 +1321,17 @@ __global__ __launch_bounds__(64) void k_sq_lds(SqLdsArgs s)
     }
     for (int c = 0; c < s.ncell; c++) {
         const int n = v.ccount[c];
-        if (lane == 0) {
+        if (tid == 0) {
             ch.ccount[c] = n;
             if (s.reverse) ch.head[c] = n > 0 ? (int)v.rows[c * cap + n - 1] : -1;
         }
-        for (int k = lane; k < n; k += PMC_WAVE) {
+        for (int k = tid; k < n; k += nth) {
             const int id = v.rows[c * cap + k];
             ch.cl_items[(size_t)c * cap + k] = id;
             if (s.reverse) ch.list[id] = k > 0 ? (int)v.rows[c * cap + k - 1] : -1;   // the chain is the row read backwards
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         ch.energy = E;
         ch.step0 = gend;                         // the next launch of the call continues here
         for (int q = 0; q < 8; q++) { ch.att[q] += att[q]; ch.acc[q] += acc[q]; }

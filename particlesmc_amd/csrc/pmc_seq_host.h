@@ -186,7 +186,7 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
     s.reverse = (h->list_type == 1) ? 1 : 0;
     s.ids_cap = h->nn * h->cl_cap;
     if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
-    const size_t lds = (size_t)s.ids_cap * sizeof(int);
+    const size_t lds = (size_t)((s.ids_cap + 3) & ~3) * sizeof(int) + 2 * (size_t)SQ_TERMS_BUF * sizeof(double);   // ids + the two term buffers
     if (lds > 160 * 1024 - 256) return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
     if (lds > 48 * 1024) {
         if (h->D == 3) HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_round_a<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -304,7 +304,7 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
 static size_t seq_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // LDS bytes of k_sq_lds for this system's shape (and the offsets of its arrays)
-static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s)
+static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw = 1)
 {
     const size_t N = (size_t)h->N, nc = (size_t)h->ncell_ref, nn = (size_t)h->nn;
     size_t o = seq_align(N * h->D * sizeof(double), 16);
@@ -315,7 +315,11 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s)
     const size_t o_spheads = o;   o = seq_align(o + N * 2, 16);
     const size_t o_species = o;   o = seq_align(o + N, 16);
     const size_t o_seq = o;       o = seq_align(o + nn * cap * 2, 16);
-    const size_t o_gen = o;       o = seq_align(o + 64 * sizeof(SqGen), 16);
+    const size_t o_gen = o;       o = seq_align(o + (size_t)nw * 64 * sizeof(SqGen), 16);
+    const size_t trips = (nn * cap + 63) / 64;
+    const size_t o_terms = o;     o = seq_align(o + (nw > 1 ? 2 * trips * (64 + SQ_TERMS_PAD) : 2 * (size_t)(SQ_TERMS + 64 + SQ_TERMS_PAD)) * sizeof(double), 16);
+    const size_t o_tmask = o;     if (nw > 1) o = seq_align(o + 2 * trips * sizeof(int), 16);
+    const size_t o_esum = o;      o = seq_align(o + 4 * sizeof(double), 16);
     const size_t o_spoff = o;     o = seq_align(o + 16 * sizeof(int), 16);
     const bool nbr_in = nc * nn * 4 <= 16384;
     const size_t o_nbr = o;       if (nbr_in) o = seq_align(o + nc * nn * 4, 16);
@@ -324,6 +328,7 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s)
         s->o_rows = (int)o_rows; s->o_ccount = (int)o_ccount; s->o_cs = (int)o_cs; s->o_spids = (int)o_spids;
         s->o_spheads = (int)o_spheads; s->o_species = (int)o_species; s->o_seq = (int)o_seq; s->o_gen = (int)o_gen;
         s->o_spoff = (int)o_spoff; s->o_nbr = (int)o_nbr; s->o_nbrcnt = (int)o_nbrcnt; s->nbr_in_lds = nbr_in ? 1 : 0;
+        s->o_terms = (int)o_terms; s->o_tmask = (int)o_tmask; s->o_esum = (int)o_esum; s->max_trips = (int)trips;
     }
     return o;
 }
@@ -388,10 +393,17 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     s.pool = make_pool(pool, npool);
     s.reverse = (m->list_type == 1) ? 1 : 0;
     s.ncell = m->ncell_ref;
-    const size_t lds = seq_lds_layout(m, cap, &s);
+    if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
+    // wavefronts per chain: four split the pair loop and the two ordered sums of a step while the chains alone would leave SIMDs
+    // idle; from a thousand chains on, one wavefront per chain fills the chip and wastes nothing on barriers (PMC_SEQ_WAVES: A/B)
+    int nw = (n <= 512) ? 4 : 1;
+    if (const char *e = getenv("PMC_SEQ_WAVES")) nw = (atoi(e) == 4) ? 4 : 1;
+    if (nw == 4 && seq_lds_layout(m, cap, nullptr, 4) > SQ_LDS_MAX) nw = 1;
+    const size_t lds = seq_lds_layout(m, cap, &s, nw);
     if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: the chain's state does not fit the LDS");
-    if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void *kfn = (m->D == 3) ? (nw == 4 ? (const void *)k_sq_lds<3, 4> : (const void *)k_sq_lds<3, 1>)
+                                  : (nw == 4 ? (const void *)k_sq_lds<2, 4> : (const void *)k_sq_lds<2, 1>);
+    HIPCHK(m, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<SqChain> tab((size_t)n);
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
@@ -416,8 +428,13 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     long long launches = 0;
     for (long long done = 0; done < total; done += chunk) {
         s.nsteps = std::min(chunk, total - done);
-        if (m->D == 3) hipLaunchKernelGGL(k_sq_lds<3>, dim3(n), dim3(64), lds, m->stream, s);
-        else hipLaunchKernelGGL(k_sq_lds<2>, dim3(n), dim3(64), lds, m->stream, s);
+        if (m->D == 3) {
+            if (nw == 4) hipLaunchKernelGGL((k_sq_lds<3, 4>), dim3(n), dim3(256), lds, m->stream, s);
+            else hipLaunchKernelGGL((k_sq_lds<3, 1>), dim3(n), dim3(64), lds, m->stream, s);
+        } else {
+            if (nw == 4) hipLaunchKernelGGL((k_sq_lds<2, 4>), dim3(n), dim3(256), lds, m->stream, s);
+            else hipLaunchKernelGGL((k_sq_lds<2, 1>), dim3(n), dim3(64), lds, m->stream, s);
+        }
         HIPCHK(m, hipGetLastError());
         launches++;
     }

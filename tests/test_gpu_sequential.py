@@ -173,8 +173,9 @@ def test_config2_one_sweep_bitexact(gpu):
 
 # ---- engine 3: the chain's state in LDS, one wavefront per chain, many chains per launch ------------------------------------------
 
+@pytest.mark.parametrize("waves", [1, 4])
 @pytest.mark.parametrize("n,rho,sigma", [(6, 0.9, 0.15), (6, 1.0, 0.6), (8, 0.9, 0.3), (10, 0.95, 0.1)])
-def test_lds_engine_lj_bitexact(gpu, n, rho, sigma):
+def test_lds_engine_lj_bitexact(gpu, n, rho, sigma, waves, monkeypatch):
     """The reference's benchmark system (benchmark/particles_benchmarks.jl:10-28: N = 216 LJ) and its neighbours in size,
     engine 3 against the oracle; sigma = 0.6 makes a quarter of the trials change cell."""
     from oracle import oracle as O
@@ -183,6 +184,7 @@ def test_lds_engine_lj_bitexact(gpu, n, rho, sigma):
     g = pmc.System(pos, sp, rho, 0.8, pmc.LennardJones(1.0, 1.0), seed=99)
     o = O.System(pos, sp, rho, 0.8, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
     g.set_sequential_engine(3, 0)
+    monkeypatch.setenv("PMC_SEQ_WAVES", str(waves))         # wavefronts per chain (the library picks by the number of chains)
     for call in range(2):
         st = pmc.mc_sweep(g, [_disp(pmc, sigma)], nsweeps=3, mode="sequential")
         att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": sigma}]), 99, 0, call * 3 * len(pos), 3 * len(pos))
@@ -190,12 +192,14 @@ def test_lds_engine_lj_bitexact(gpu, n, rho, sigma):
         _same_state(g, o)
 
 
-def test_lds_engine_mixture_with_swaps_and_cell_list(gpu):
+@pytest.mark.parametrize("waves", [1, 4])
+def test_lds_engine_mixture_with_swaps_and_cell_list(gpu, waves, monkeypatch):
     """Engine 3 on the published mixture's own size (N = 1000, rcut = 4: two cells per side, swaps mostly accepted) with a
     LinkedList, and on a CellList system."""
     from oracle import oracle as O
     from mixture import EPS, SIG, RCUT
     pmc = gpu
+    monkeypatch.setenv("PMC_SEQ_WAVES", str(waves))
     N = 1000
     pos, sp, rho = binary_lattice(N, frac_b=0.5, rho=0.8, jitter=0.05, seed=4)
     mp = [[pmc.LennardJones(EPS[i][j], SIG[i][j], rcut=RCUT, shift_potential=False) for j in range(2)] for i in range(2)]
