@@ -138,11 +138,28 @@ end
 # revert_action! -> pmc_displacement_revert(h, action.i, action.δ (already inverted), action.δe)      src/moves.jl:76-81
 # DiscreteSwap   -> pmc_swap_perform(h, i, j, e1, e2, de) / pmc_swap_revert(h, i, j, δe)               src/moves.jl:187-207
 
+# ASSUMPTIONS about Arianna (not in the reference tree, never executed here; INTEGRATION.md section 4): the supertype
+# `Arianna.Algorithm`, the per-tick hook `Arianna.make_step!(simulation, algorithm)` and the fields of `Arianna.Move`.
 struct HIPMetropolis <: Arianna.Algorithm
     pool::Vector{CMove}; mode::Int32            # 0 = sequential (reference chain), 1 = checkerboard (throughput)
     sweeps_per_step::Int64                      # sweeps per scheduler tick: one library call (one sync, one counter fold) per tick,
 end                                             # so coarse schedulers should tick in blocks (INTEGRATION.md section 4)
-HIPMetropolis(pool, mode) = HIPMetropolis(pool, mode, 1)
+# default: four passes per tick, whatever the handle's schedule parameter m (a pass never spans calls: include/pmc.h)
+HIPMetropolis(pool, mode; rounds=1) = HIPMetropolis(pool, mode, 4 * rounds)
+
+# how mode = 0 runs: 0 the library's choice, 1 one wavefront, 2 speculative windows, 3 the chain's state in LDS (include/pmc.h)
+set_sequential_engine!(system, engine, window=0) =
+    check(ccall((:pmc_set_sequential_engine, LIB), Cint, (Ptr{Cvoid}, Int32, Int32), system.neighbour_list.handle, engine, window),
+          system.neighbour_list.handle)
+
+# checkpoint / restart of a mode = 1 chain: the periodic images travel with the positions (include/pmc.h: pmc_get_images)
+function get_images(system)
+    img = Vector{Int32}(undef, system.N * system.d)
+    check(ccall((:pmc_get_images, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}), system.neighbour_list.handle, img), system.neighbour_list.handle)
+    return img
+end
+set_images!(system, img::Vector{Int32}) =
+    check(ccall((:pmc_set_images, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}), system.neighbour_list.handle, img), system.neighbour_list.handle)
 cmove(m::Arianna.Move{<:ParticlesMC.Displacement}) = CMove(0, (0, 0), m.weight, m.parameters.σ)
 cmove(m::Arianna.Move{<:ParticlesMC.DiscreteSwap}) = CMove(1, Int32.(m.action.species), m.weight, 0.0)
 

@@ -143,7 +143,7 @@ struct pmc_system {
     SqSlot *d_sq_slots[2] = {nullptr, nullptr};
     SqGen *d_sq_gen = nullptr;
     unsigned long long *d_sq_M = nullptr, *d_sq_cp = nullptr;
-    int *d_sq_moveto = nullptr;
+    int *d_sq_moveto = nullptr, *d_sq_cellhead = nullptr, *d_sq_cellnext = nullptr;
     SqLog *d_sq_log = nullptr, *h_sq_log = nullptr;
     int sq_ring = 0;             // records the log ring holds (a power of two)
     SqCtl *d_sq_ctl = nullptr, *h_sq_ctl = nullptr;
@@ -584,7 +584,7 @@ extern "C" int pmc_destroy(pmc_system *h)
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
                     h->d_sz, h->d_ssp, h->d_stats, h->d_cbtab, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m, h->d_img, h->d_simg,
                     h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last,
-                    h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_cp, h->d_sq_moveto, h->d_sq_log, h->d_sq_ctl};
+                    h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_cp, h->d_sq_moveto, h->d_sq_cellhead, h->d_sq_cellnext, h->d_sq_log, h->d_sq_ctl};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_sq_ctl) (void)hipHostFree(h->h_sq_ctl);

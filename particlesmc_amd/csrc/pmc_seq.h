@@ -102,6 +102,8 @@ struct SqArgs {
     SqSlot *slots[2];
     const SqGen *gen;
     unsigned long long *M;        // [K][SQ_KW] conflict bits with earlier slots
+    int *cellhead;                // [cells] pending steps by cell: head of a chain of entries 2 slot + which (-1: none); clean between rounds
+    int *cellnext;                // [2 K] the chains
     unsigned long long *cp;       // [SQ_KW]: slot changes state or has an earlier potential conflict
     int *moveto;                  // [K] k_sq_fill -> k_sq_prep: new index of an old slot, -1 if it committed
     int *cand;                    // [K][3] ... and the admitted steps: i, j, flags
@@ -518,76 +520,45 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 
 // ---- which earlier pending steps could a step interact with -----------------------------------------------------------------
 // Two steps interact iff a cell one of them writes is a neighbour cell (periodic, +-1 in every dimension) of a cell the other one
-// reads from, i.e. iff some cell of one is within one cell of some cell of the other.
-__device__ __forceinline__ bool sq_near(int u, int v, int nc)
+// reads from, i.e. iff some cell of one is within one cell of some cell of the other.  k_sq_prep has entered every pending
+// step under its cell(s) (cellhead / cellnext); step w walks the chains of the neighbour cells of its own cell(s) and sets bit
+// t of its row of M for every EARLIER step t it meets.
+__device__ __forceinline__ void sq_conflicts(const SqArgs &s, int w, int c0, int c1)
 {
-    int dd = u - v;
-    dd = dd < 0 ? -dd : dd;
-    return min(dd, nc - dd) <= 1;
-}
-
-template <int D>
-__device__ __forceinline__ bool sq_cells_near(const RefArgs &a, int ux, int uy, int uz, int vx, int vy, int vz)
-{
-    bool hit = sq_near(ux, vx, a.nc[0]) && sq_near(uy, vy, a.nc[1]);
-    if (D == 3) hit = hit && sq_near(uz, vz, a.nc[2]);
-    return hit;
-}
-
-template <int D>
-__device__ __forceinline__ void sq_pairs(const SqArgs &s, int wordw, int wordt)
-{
+    const RefArgs &a = s.a;
     const int lane = wave_lane();
-    const int nslots = s.ctl->nslots;
-    const SqSlot *slots = s.slots[s.cur];
-    const int w = wordw * 64 + lane;
-    unsigned long long bits = 0;
-    if (wordt <= wordw && wordt * 64 < nslots) {
-        int p0 = 0, p1 = 0, p2 = 0, has = 0;
-        if (w < nslots) { p0 = slots[w].pk[0]; p1 = slots[w].pk[1]; p2 = slots[w].pk[2]; has = slots[w].pk[3]; }
-        const int wx0 = p0 & 0xffff, wy0 = (p0 >> 16) & 0xffff, wz0 = p1 & 0xffff;
-        const int wx1 = (p1 >> 16) & 0xffff, wy1 = p2 & 0xffff, wz1 = (p2 >> 16) & 0xffff;
-        const bool wtwo = has && (wx1 != wx0 || wy1 != wy0 || wz1 != wz0);
-        const bool anytwo = __any(wtwo);                   // most steps stay in their cell: one cell pair to test, not four
-        const int tend = min(64, nslots - wordt * 64);
-        int t0 = 0, t1 = 0, t2 = 0, t3 = 0;                  // lane l holds the cells of slot wordt * 64 + l
-        if (lane < tend) {
-            const SqSlot &ts = slots[wordt * 64 + lane];
-            t0 = ts.pk[0]; t1 = ts.pk[1]; t2 = ts.pk[2]; t3 = ts.pk[3];
-        }
-        for (int tt = 0; tt < tend; tt++) {
-            const int t = wordt * 64 + tt;
-            const int thas = __builtin_amdgcn_readlane(t3, tt);
-            if (!thas) continue;
-            const int q0 = __builtin_amdgcn_readlane(t0, tt), q1 = __builtin_amdgcn_readlane(t1, tt), q2 = __builtin_amdgcn_readlane(t2, tt);
-            const int tx0 = q0 & 0xffff, ty0 = (q0 >> 16) & 0xffff, tz0 = q1 & 0xffff;
-            const int tx1 = (q1 >> 16) & 0xffff, ty1 = q2 & 0xffff, tz1 = (q2 >> 16) & 0xffff;
-            bool hit = sq_cells_near<D>(s.a, wx0, wy0, wz0, tx0, ty0, tz0);
-            if (anytwo) hit = hit || sq_cells_near<D>(s.a, wx1, wy1, wz1, tx0, ty0, tz0);
-            if (tx1 != tx0 || ty1 != ty0 || tz1 != tz0) {
-                hit = hit || sq_cells_near<D>(s.a, wx0, wy0, wz0, tx1, ty1, tz1);
-                if (anytwo) hit = hit || sq_cells_near<D>(s.a, wx1, wy1, wz1, tx1, ty1, tz1);
+    unsigned long long *row = s.M + (size_t)w * SQ_KW;
+    const int nw = (w >> 6) + 1;                       // words that can hold an earlier step
+    if (lane < nw) row[lane] = 0;
+    __threadfence();                                   // the zeroes are in L2 before the atomics below reach it
+    __syncthreads();
+    bool any = false;
+    for (int pass = 0; pass < (c1 != c0 ? 2 : 1); pass++) {
+        const int c = pass ? c1 : c0;
+        const int cnt = a.nbrcnt[c];
+        int e = (lane < cnt) ? s.cellhead[a.nbr[(size_t)c * a.nnmax + lane]] : -1;
+        while (__any(e >= 0)) {
+            if (e >= 0) {
+                const int t = e >> 1;
+                if (t < w) { atomicOr(&row[t >> 6], 1ull << (t & 63)); any = true; }
+                e = s.cellnext[e];
             }
-            if (hit && has && t < w) bits |= 1ull << tt;
         }
     }
-    if (w < s.K) s.M[(size_t)w * SQ_KW + wordt] = bits;
-    const unsigned long long any = __ballot(bits != 0);
-    if (lane == 0 && any) atomicOr(&s.cp[wordw], any);       // P: the slot has an earlier potential conflict
+    const bool p = __any(any);
+    if (lane == 0 && p) atomicOr(&s.cp[w >> 6], 1ull << (w & 63));       // P: the step has an earlier potential conflict
 }
 
-// ---- round, third launch: evaluation of every pending step | pair matrix --------------------------------------
+// ---- round, third launch: every pending step finds the earlier steps it could interact with and is evaluated --------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void k_sq_round_a(SqArgs s)
 {
     extern __shared__ int sq_lds[];
     const int b = blockIdx.x;
-    const int kw = s.K / 64;
-    if (b < s.K) {
-        if (b < s.ctl->nslots && !(s.dbg & 4)) sq_eval<D>(s, b, sq_lds);
-    } else {
-        const int t = b - s.K;
-        if (!(s.dbg & 2)) sq_pairs<D>(s, t / kw, t % kw);
+    if (b < s.ctl->nslots) {
+        const SqSlot &sl = s.slots[s.cur][b];
+        if (sl.pk[3] && !(s.dbg & 2)) sq_conflicts(s, b, sl.c0, sl.c1);
+        if (!(s.dbg & 4)) sq_eval<D>(s, b, sq_lds);
     }
 }
 
@@ -656,6 +627,10 @@ __global__ __launch_bounds__(64) void k_sq_commit(SqArgs s)
     SqCtl *ctl = s.ctl;
     if (w >= ctl->nslots) return;
     SqSlot &sl = s.slots[s.cur][w];
+    if (lane == 0 && sl.pk[3]) {                        // the cell table is rebuilt by the next round's k_sq_prep
+        s.cellhead[sl.c0] = -1;
+        s.cellhead[sl.c1] = -1;
+    }
     // held back iff an earlier pending step it could interact with changes the state or is itself uncertain
     const int nw = (w >> 6) + 1;
     unsigned long long hit = 0;
@@ -885,7 +860,14 @@ __global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
     SqSlot *dst = s.slots[s.cur];
     if (t < nold) {
         const int to = s.moveto[t];
-        if (to >= 0) dst[to] = s.slots[s.cur ^ 1][t];
+        if (to >= 0) {
+            const SqSlot sl = s.slots[s.cur ^ 1][t];
+            dst[to] = sl;
+            if (sl.pk[3]) {                             // entered under its cell(s): sq_conflicts walks these chains
+                s.cellnext[2 * to] = atomicExch(&s.cellhead[sl.c0], 2 * to);
+                if (sl.c1 != sl.c0) s.cellnext[2 * to + 1] = atomicExch(&s.cellhead[sl.c1], 2 * to + 1);
+            }
+        }
         return;
     }
     const int q = t - nold;
@@ -912,7 +894,10 @@ __global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
         sl.c0 = sq_cell_of<D>(a, sl.x);
         sl.c1 = sq_cell_of<D>(a, sl.xn);
         sl.c2 = sl.c0;
-        sq_pack_cells<D>(a, sl.c0, sl.c1, sl.pk);
+        sl.pk[3] = 1;
+        const int to = nkeep + q;
+        s.cellnext[2 * to] = atomicExch(&s.cellhead[sl.c0], 2 * to);
+        if (sl.c1 != sl.c0) s.cellnext[2 * to + 1] = atomicExch(&s.cellhead[sl.c1], 2 * to + 1);
     }
     dst[nkeep + q] = sl;
 }

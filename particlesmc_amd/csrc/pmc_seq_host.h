@@ -73,7 +73,6 @@ static bool seq_fast_applicable(const pmc_system *h, const pmc_move *pool, int n
     if (h->seq_engine == 1) return false;
     if (h->list_type != 1 && h->list_type != 2) return false;      // EmptyList: every step reads everything; VerletList: own update rule
     if (!seq_pool_ok(pool, npool)) return false;
-    for (int a = 0; a < h->D; a++) if (h->p.ncells[a] > 65535) return false;   // 16-bit cell coordinates in the pair test
     if ((double)h->ncell_ref * seq_rows_cap(h) * sizeof(int) > 32e9) return false;   // dilute giants: rows would not fit
     return true;
 }
@@ -95,6 +94,8 @@ static int seq_ensure(pmc_system *h, int K)
         HIPCHK(h, hipMalloc(&h->d_sq_M, (size_t)SQ_KMAX * SQ_KW * sizeof(unsigned long long)));
         HIPCHK(h, hipMalloc(&h->d_sq_cp, (size_t)SQ_KW * sizeof(unsigned long long)));
         HIPCHK(h, hipMalloc(&h->d_sq_moveto, (size_t)SQ_KMAX * 4 * sizeof(int)));
+        HIPCHK(h, hipMalloc(&h->d_sq_cellnext, (size_t)SQ_KMAX * 2 * sizeof(int)));
+        HIPCHK(h, hipMalloc(&h->d_sq_cellhead, (size_t)h->ncell_ref * sizeof(int)));
         HIPCHK(h, hipHostMalloc(&h->h_sq_ctl, sizeof(SqCtl)));
         HIPCHK(h, hipMalloc(&h->d_sq_ctl, sizeof(SqCtl)));
     }
@@ -174,6 +175,8 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
     s.slots[1] = h->d_sq_slots[1];
     s.gen = h->d_sq_gen;
     s.M = h->d_sq_M;
+    s.cellhead = h->d_sq_cellhead;
+    s.cellnext = h->d_sq_cellnext;
     s.cp = h->d_sq_cp;
     s.log = h->d_sq_log;
     s.ring_mask = ring - 1;
@@ -205,13 +208,13 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
     *h->h_sq_ctl = c0;
     HIPCHK(h, hipMemcpyAsync(h->d_sq_ctl, h->h_sq_ctl, sizeof(SqCtl), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_sq_log, 0, (size_t)ring * sizeof(SqLog), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sq_cellhead, 0xff, (size_t)h->ncell_ref * sizeof(int), h->stream));   // (clean after every round; cheap insurance per call)
     HIPCHK(h, hipStreamSynchronize(h->stream));            // the pinned block is reused for the read-backs below
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     unsigned long long gen_hi = c0.next, next_known = c0.next, prefix = c0.prefix;
     unsigned long long att[8] = {0}, acc[8] = {0};
     double energy = h->energy;
-    const int kw = K / 64;
-    const int grid_a = K + kw * kw;
+    const int grid_a = K;
     double per_round = 0.5 * K;                             // steps a round finishes: learnt from the batches
     int cur = 0;
     long long guard = 0;

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round 4: profiles of the reference-order chain (PMC_SEQUENTIAL; pmc_seq.h).  Run through gpurun from the repo root:
+#   gpurun --timeout 1800 -- 'bash profiles/collect_seq.sh'
+# It summarises ON the box (the raw traces exceed what gpurun merges back) into gpurun_out/seq_summary/; then, here:
+#   cp gpurun_out/seq_summary/* profiles/
+cd /tmp; export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
+P=gpurun_out/prof
+mkdir -p $P
+# ---- round 4: the reference-order chain (PMC_SEQUENTIAL; pmc_seq.h) ----------------------------------------------------------
+# engine 2 (speculative windows) on the headline system, engine 3 (state in LDS) on 1000 chains of the reference's benchmark system
+rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write
+export STEPS=3000000 NO_ENGINE1=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/seq_trace -- python3 examples/seq_rate.py 100 > $P/seq_rate.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/seq_many_trace -- python3 examples/seq_many.py 6 1000 100 > $P/seq_many.log 2>&1
+export STEPS=1000000
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/seq_sq -- python3 examples/seq_rate.py 100 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/seq_fetch -- python3 examples/seq_rate.py 100 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/seq_write -- python3 examples/seq_rate.py 100 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/seq_many_sq -- python3 examples/seq_many.py 6 1000 20 > /dev/null 2>&1
+python3 examples/seq_rate.py 16 32 48 64 100 > gpurun_out/seq_rate_table.jsonl 2>&1
+for n in 1 64 256 1000 4000; do python3 examples/seq_many.py 6 $n 100; done > gpurun_out/seq_many_table.jsonl 2>&1
+python3 examples/seq_many.py 10 256 20 >> gpurun_out/seq_many_table.jsonl 2>&1
+mkdir -p gpurun_out/seq_summary
+PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py r04 --seq-only
+rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write
+ls gpurun_out/seq_summary
