@@ -289,10 +289,12 @@ __device__ __forceinline__ double *sq_terms_buffer(const SqArgs &s, int *lds_ids
 }
 
 // The ids the iterator of the list yields for a particle in cell c, in order, into LDS (i itself is among them where the
-// current rows have it: its term is 0 wherever it stands).  Returns their number.  One row = one coalesced load, and the
-// loads of all 3^d rows are in flight together.
+// current rows have it: its term is 0 wherever it stands).  Returns their number.  Everything that only needs the neighbour
+// cells is requested at once -- the populations, the first 64 ids of every row (speculatively: which of them exist is known when
+// the populations arrive) and, for step w >= 0, the heads of the cells' chains of pending steps -- one round trip to memory
+// instead of three.  Earlier pending steps found in those chains are recorded in row w of the conflict matrix (sq_conflicts).
 template <int D>
-__device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids)
+__device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids, int w = -1)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
     const RefArgs &a = s.a;
@@ -300,23 +302,24 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids)
     const int cnt = a.nbrcnt[c];
     const int cc = (lane < cnt) ? a.nbr[(size_t)c * a.nnmax + lane] : 0;
     const int len = (lane < cnt) ? a.ccount[cc] : 0;
+    int e = (w >= 0 && lane < cnt) ? s.cellhead[cc] : -1;
+    const int lane_in_row = lane < a.cl_cap ? lane : 0;
+    int v[NN];
+#pragma unroll
+    for (int l = 0; l < NN; l++) {
+        const int cc_l = __builtin_amdgcn_readlane(cc, l);
+        v[l] = a.cl_items[(size_t)cc_l * a.cl_cap + lane_in_row];
+    }
     int incl = len;
 #pragma unroll
     for (int sft = 1; sft < 32; sft <<= 1) {
-        const int v = __shfl_up(incl, sft, PMC_WAVE);
-        if (lane >= sft) incl += v;
+        const int t = __shfl_up(incl, sft, PMC_WAVE);
+        if (lane >= sft) incl += t;
     }
     const int off = incl - len;
     const int total = __shfl(incl, 31, PMC_WAVE);
     const int maxlen = __reduce_max_sync_compat(len);
     __syncthreads();                              // the previous pass has read its ids
-    int v[NN];
-#pragma unroll
-    for (int l = 0; l < NN; l++) {
-        const int len_l = __builtin_amdgcn_readlane(len, l);
-        const int cc_l = __builtin_amdgcn_readlane(cc, l);
-        v[l] = a.cl_items[(size_t)cc_l * a.cl_cap + (lane < len_l ? lane : 0)];
-    }
 #pragma unroll
     for (int l = 0; l < NN; l++) {
         const int len_l = __builtin_amdgcn_readlane(len, l);
@@ -330,21 +333,35 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids)
                 lds_ids[off_l + (s.reverse ? len_l - 1 - k : k)] = a.cl_items[(size_t)cc_l * a.cl_cap + k];
         }
     }
+    if (w >= 0) {
+        // two steps interact iff some cell of one is within one cell of some cell of the other: every pending step is entered
+        // under its cell(s) (k_sq_prep); bit t of row w for every EARLIER step t in the chains of this cell's neighbour cells
+        unsigned long long *row = s.M + (size_t)w * SQ_KW;   // (zeroed by k_sq_prep)
+        bool any = false;
+        while (__any(e >= 0)) {
+            if (e >= 0) {
+                const int t = e >> 1;
+                if (t < w) { atomicOr(&row[t >> 6], 1ull << (t & 63)); any = true; }
+                e = s.cellnext[e];
+            }
+        }
+        if (__any(any) && lane == 0) atomicOr(&s.cp[w >> 6], 1ull << (w & 63));   // P: the step has an earlier potential conflict
+    }
     __syncthreads();
     return total;
 }
 
-#define SQ_CHUNK 4          // trips of 64 candidates whose position loads are in flight together
+#define SQ_CHUNK 8          // trips of 64 candidates whose position loads are in flight together
 
 // compute_energy_particle (src/atoms.jl:81-88) of particle i, species spi, at xa (and, when BOTH, at xb over the same
 // neighbour sequence) for a particle whose iterator runs over the neighbourhood of cell c
 template <int D, bool BOTH>
 __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, const double *xa, const double *xb, int *lds_ids,
-                                        double &ea, double &eb)
+                                        double &ea, double &eb, int w)
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
-    const int total = sq_sequence<D>(s, c, lds_ids);
+    const int total = sq_sequence<D>(s, c, lds_ids, w);
     double *bufa = sq_terms_buffer(s, lds_ids), *bufb = bufa + SQ_TERMS_BUF;
     double acc_a = 0.0, acc_b = 0.0;
     int na = 0, nb = 0;
@@ -393,11 +410,11 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
 // (species sp2, and the partner `other`, if it is a neighbour, with the species sp1 it then has)
 template <int D>
 __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int sp1, int sp2, int other, const double *xi,
-                                             int *lds_ids, double &e_before, double &e_after)
+                                             int *lds_ids, double &e_before, double &e_after, int w)
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
-    const int total = sq_sequence<D>(s, c, lds_ids);
+    const int total = sq_sequence<D>(s, c, lds_ids, w);
     double *bufa = sq_terms_buffer(s, lds_ids), *bufb = bufa + SQ_TERMS_BUF;
     double acc_a = 0.0, acc_b = 0.0;
     int na = 0, nb = 0;
@@ -468,11 +485,11 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
         const int c2 = sq_cell_of<D>(a, xr);
         const int spi = a.S > 1 ? a.species[i] : 0;
         if (c1 == c0) {
-            sq_pass<D, true>(s, c0, i, spi, x, xn, lds_ids, e1, e2);
+            sq_pass<D, true>(s, c0, i, spi, x, xn, lds_ids, e1, e2, w);
         } else {
             double dummy;
-            sq_pass<D, false>(s, c0, i, spi, x, x, lds_ids, e1, dummy);
-            sq_pass<D, false>(s, c1, i, spi, xn, xn, lds_ids, e2, dummy);
+            sq_pass<D, false>(s, c0, i, spi, x, x, lds_ids, e1, dummy, w);
+            sq_pass<D, false>(s, c1, i, spi, xn, xn, lds_ids, e2, dummy, w);
             flags |= SQF_CROSSED;
         }
         const bool ok = sl.lnu < -(e2 - e1) / a.temperature;    // src/utils.jl:8-10 (forward / backward log q cancel)
@@ -494,8 +511,8 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
         for (int q = 0; q < D; q++) { xi[q] = sl.x[q]; xj[q] = sl.xn[q]; }
         const int spi = a.species[i], spj = a.species[j];
         double e1i, e2i, e1j, e2j;
-        sq_pass_swap<D>(s, sl.c0, i, spi, spj, j, xi, lds_ids, e1i, e2i);
-        sq_pass_swap<D>(s, sl.c1, j, spj, spi, i, xj, lds_ids, e1j, e2j);
+        sq_pass_swap<D>(s, sl.c0, i, spi, spj, j, xi, lds_ids, e1i, e2i, w);
+        sq_pass_swap<D>(s, sl.c1, j, spj, spi, i, xj, lds_ids, e1j, e2j, w);
         e1 = e1i + e1j;                                 // src/moves.jl:166
         e2 = e2i + e2j;
         const bool ok = sl.lnu < -(e2 - e1) / a.temperature;
@@ -518,37 +535,6 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
     }
 }
 
-// ---- which earlier pending steps could a step interact with -----------------------------------------------------------------
-// Two steps interact iff a cell one of them writes is a neighbour cell (periodic, +-1 in every dimension) of a cell the other one
-// reads from, i.e. iff some cell of one is within one cell of some cell of the other.  k_sq_prep has entered every pending
-// step under its cell(s) (cellhead / cellnext); step w walks the chains of the neighbour cells of its own cell(s) and sets bit
-// t of its row of M for every EARLIER step t it meets.
-__device__ __forceinline__ void sq_conflicts(const SqArgs &s, int w, int c0, int c1)
-{
-    const RefArgs &a = s.a;
-    const int lane = wave_lane();
-    unsigned long long *row = s.M + (size_t)w * SQ_KW;
-    const int nw = (w >> 6) + 1;                       // words that can hold an earlier step
-    if (lane < nw) row[lane] = 0;
-    __threadfence();                                   // the zeroes are in L2 before the atomics below reach it
-    __syncthreads();
-    bool any = false;
-    for (int pass = 0; pass < (c1 != c0 ? 2 : 1); pass++) {
-        const int c = pass ? c1 : c0;
-        const int cnt = a.nbrcnt[c];
-        int e = (lane < cnt) ? s.cellhead[a.nbr[(size_t)c * a.nnmax + lane]] : -1;
-        while (__any(e >= 0)) {
-            if (e >= 0) {
-                const int t = e >> 1;
-                if (t < w) { atomicOr(&row[t >> 6], 1ull << (t & 63)); any = true; }
-                e = s.cellnext[e];
-            }
-        }
-    }
-    const bool p = __any(any);
-    if (lane == 0 && p) atomicOr(&s.cp[w >> 6], 1ull << (w & 63));       // P: the step has an earlier potential conflict
-}
-
 // ---- round, third launch: every pending step finds the earlier steps it could interact with and is evaluated --------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void k_sq_round_a(SqArgs s)
@@ -556,8 +542,6 @@ __global__ __launch_bounds__(64) void k_sq_round_a(SqArgs s)
     extern __shared__ int sq_lds[];
     const int b = blockIdx.x;
     if (b < s.ctl->nslots) {
-        const SqSlot &sl = s.slots[s.cur][b];
-        if (sl.pk[3] && !(s.dbg & 2)) sq_conflicts(s, b, sl.c0, sl.c1);
         if (!(s.dbg & 4)) sq_eval<D>(s, b, sq_lds);
     }
 }
@@ -631,7 +615,10 @@ __global__ __launch_bounds__(64) void k_sq_commit(SqArgs s)
         s.cellhead[sl.c0] = -1;
         s.cellhead[sl.c1] = -1;
     }
-    // held back iff an earlier pending step it could interact with changes the state or is itself uncertain
+    // held back iff an earlier pending step it could interact with changes the state or is itself uncertain: "changes the state or
+    // has any earlier potential conflict" is a superset of "is held back" that needs no recursion.  (Resolving the recursion
+    // exactly -- every wavefront running it over a window of <= 256 steps -- was measured in round 4: 17 % more steps per round
+    // at N = 32768 for a commit kernel 9 us longer: slower.)
     const int nw = (w >> 6) + 1;
     unsigned long long hit = 0;
     if (lane < nw) hit = s.M[(size_t)w * SQ_KW + lane] & s.cp[lane];
@@ -858,6 +845,10 @@ __global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
     const int nold = ctl->f_nold, nkeep = ctl->f_nkeep;
     const int nadm = ctl->nslots - nkeep;
     SqSlot *dst = s.slots[s.cur];
+    if (t < ctl->nslots) {                              // row t of the conflict matrix: the words that can hold an earlier step
+        unsigned long long *row = s.M + (size_t)t * SQ_KW;
+        for (int k = 0; k <= (t >> 6); k++) row[k] = 0;
+    }
     if (t < nold) {
         const int to = s.moveto[t];
         if (to >= 0) {

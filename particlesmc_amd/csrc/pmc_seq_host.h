@@ -92,7 +92,7 @@ static int seq_ensure(pmc_system *h, int K)
         HIPCHK(h, hipMalloc(&h->d_sq_slots[1], (size_t)SQ_KMAX * sizeof(SqSlot)));
         HIPCHK(h, hipMalloc(&h->d_sq_gen, (size_t)SQ_GEN * sizeof(SqGen)));
         HIPCHK(h, hipMalloc(&h->d_sq_M, (size_t)SQ_KMAX * SQ_KW * sizeof(unsigned long long)));
-        HIPCHK(h, hipMalloc(&h->d_sq_cp, (size_t)SQ_KW * sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc(&h->d_sq_cp, (size_t)2 * SQ_KW * sizeof(unsigned long long)));
         HIPCHK(h, hipMalloc(&h->d_sq_moveto, (size_t)SQ_KMAX * 4 * sizeof(int)));
         HIPCHK(h, hipMalloc(&h->d_sq_cellnext, (size_t)SQ_KMAX * 2 * sizeof(int)));
         HIPCHK(h, hipMalloc(&h->d_sq_cellhead, (size_t)h->ncell_ref * sizeof(int)));
