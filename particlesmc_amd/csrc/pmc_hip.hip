@@ -148,6 +148,10 @@ struct pmc_system {
     int sq_ring = 0;             // records the log ring holds (a power of two)
     SqCtl *d_sq_ctl = nullptr, *h_sq_ctl = nullptr;
     SqCtl sq_last{};             // control block of the last fast sequential call (diagnostics: rounds, evaluations)
+    hipGraphExec_t sq_graph = nullptr;   // SQ_GRAPH_ROUNDS rounds of the windows, captured for sq_graph_args / sq_graph_K
+    SqArgs sq_graph_args;
+    int sq_graph_K = 0;
+    SqArgs *d_sq_args = nullptr;         // the chain's entry of the rounds' argument table (a group of one)
 };
 
 #define HIPCHK(h, call)                                                                         \
@@ -584,11 +588,12 @@ extern "C" int pmc_destroy(pmc_system *h)
                     h->d_fill, h->d_tmp_ids, h->d_arrival, h->d_tile_sum, h->d_order, h->d_hist, h->d_start_ref, h->d_ids_ref, h->d_start, h->d_ids, h->d_sx, h->d_sy,
                     h->d_sz, h->d_ssp, h->d_stats, h->d_cbtab, h->d_result, h->d_done, h->d_ticket, h->d_slot_f, h->d_slot_w, h->d_slot_m, h->d_img, h->d_simg,
                     h->d_cl_items, h->d_vl_nb, h->d_vl_cnt, h->d_ref_err, h->d_vl_last,
-                    h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_cp, h->d_sq_moveto, h->d_sq_cellhead, h->d_sq_cellnext, h->d_sq_log, h->d_sq_ctl};
+                    h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_cp, h->d_sq_moveto, h->d_sq_cellhead, h->d_sq_cellnext, h->d_sq_log, h->d_sq_ctl, h->d_sq_args};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_sq_ctl) (void)hipHostFree(h->h_sq_ctl);
     if (h->h_sq_log) (void)hipHostFree(h->h_sq_log);
+    if (h->sq_graph) (void)hipGraphExecDestroy(h->sq_graph);
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (hipEvent_t e : h->pass_ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2216,6 +2221,16 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             if (e == 1 || e == 2 || !seq_lds_fits(hs[r], e == 3 ? SQ_LDS_MAX : SQ_LDS_AUTO)) lds_ok = false;
         }
         if (lds_ok) return sweep_sequential_lds(hs, n, pool, npool, nsweeps, out);
+    }
+    if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0) {
+        // larger chains on the speculative windows: every chain's rounds are enqueued before any is waited for
+        bool fast = true;
+        for (int r = 0; r < n; r++) {
+            if (hs[r]->seq_engine == 1 || hs[r]->seq_engine == 3 || !seq_fast_applicable(hs[r], pool, npool)) fast = false;
+            if (hs[r]->p.device != hs[0]->p.device || hs[r]->D != hs[0]->D) fast = false;
+            for (int q = 0; q < r; q++) if (hs[q] == hs[r]) fast = false;
+        }
+        if (fast) return sweep_sequential_fast_many(hs, n, pool, npool, nsweeps, out);
     }
     if (mode != PMC_CHECKERBOARD || n == 1 || nsweeps == 0 || !many_compatible(hs, n)) {
         // different shapes, large systems (they fill the chip on their own) or the reference-order engine: one stream per handle

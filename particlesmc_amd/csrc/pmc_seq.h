@@ -12,9 +12,9 @@
 //     apart commute EXACTLY: same e1, e2, same accept decision, same list order, whatever the order they run in.
 //
 // A WINDOW of K pending steps is therefore evaluated at once, one wavefront per step, against the current state
-// (k_sq_round_a: "eval"), a K x K bit matrix records which earlier pending steps a step could interact with
-// ("pairs"), and a step COMMITS in this round iff no earlier pending step that could interact with it changes the
-// state or is itself held back (k_sq_commit).  Steps that are held back stay in the window and are evaluated again
+// (k_sq_round_a), a K x K bit matrix records which earlier pending steps a step could interact with (found through a
+// table of the pending steps by cell), and a step COMMITS in this round iff no earlier pending step that could interact
+// with it changes the state or is itself held back (k_sq_commit).  Steps that are held back stay in the window and are evaluated again
 // next round against the state that then exists; the window is refilled in step order (k_sq_fill).  The oldest pending
 // step never has a predecessor, so every round makes progress, and the result is the sequential chain's, bit for bit:
 //
@@ -37,6 +37,9 @@
 //
 // No two steps of a window share a particle (k_sq_fill stops admitting at the first repeat), so the particle(s), the
 // position before the step and the cells of every pending step are exact whatever the other pending steps do.
+//
+// Every kernel of a round reads its arguments from a device table, one entry per chain (chain = blockIdx.y): the chains of a
+// `parallel = true` run (src/ParticlesMC.jl:164,246) share every launch of a round (pmc_sweep_many), each with its own window.
 #pragma once
 #include "pmc_kernels.h"
 
@@ -93,6 +96,9 @@ struct SqCtl {
     int err;                      // 1: a cell row overflowed, 2: a particle was not in its row
     unsigned long long rounds, evals, commits;   // diagnostics
     int f_nold, f_nkeep;          // k_sq_fill -> k_sq_prep: slots of the old window, held-back steps among them
+    int cur;                      // slots[cur] is the current window (k_sq_fill builds the next one in slots[cur ^ 1] and flips)
+    int pad_cur;
+    unsigned long long gen_hi;    // steps < gen_hi have their random part in the ring (the host moves it between batches)
     unsigned long long f_next0;   // ... and the step of the first candidate
 };
 
@@ -112,10 +118,8 @@ struct SqArgs {
     SqCtl *ctl;
     MovePool pool;
     int K;                        // window slots in use (<= SQ_KMAX, multiple of 64)
-    int cur;                      // slots[cur] is the window this kernel works on
     int reverse;                  // 1: LinkedList (chain = row read backwards), 0: CellList (vector order)
     int ids_cap;                  // ints of dynamic LDS of the evaluation (>= 3^d * cl_cap)
-    unsigned long long gen_hi;    // steps < gen_hi have their random part in the ring
     int dbg;                      // PMC_SEQ_DBG (timing experiments only): 1 no energy fold inside the rounds, 2 no pair matrix, 4 no evaluation
 };
 
@@ -467,7 +471,7 @@ template <int D>
 __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 {
     const RefArgs &a = s.a;
-    SqSlot &sl = s.slots[s.cur][w];
+    SqSlot &sl = s.slots[s.ctl->cur][w];
     const int lane = wave_lane();
     int flags = sl.flags & (SQF_SWAP | SQF_NULL);
     if (flags & SQF_NULL) return;
@@ -537,8 +541,9 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 
 // ---- round, third launch: every pending step finds the earlier steps it could interact with and is evaluated --------------------------------------
 template <int D>
-__global__ __launch_bounds__(64) void k_sq_round_a(SqArgs s)
+__global__ __launch_bounds__(64) void k_sq_round_a(const SqArgs *__restrict__ tab)
 {
+    const SqArgs &s = tab[blockIdx.y];
     extern __shared__ int sq_lds[];
     const int b = blockIdx.x;
     if (b < s.ctl->nslots) {
@@ -603,14 +608,15 @@ __device__ __forceinline__ void sq_row_append(const SqArgs &s, int c, int i)
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void k_sq_commit(SqArgs s)
+__global__ __launch_bounds__(64) void k_sq_commit(const SqArgs *__restrict__ tab)
 {
+    const SqArgs &s = tab[blockIdx.y];
     const RefArgs &a = s.a;
     const int w = blockIdx.x;
     const int lane = wave_lane();
     SqCtl *ctl = s.ctl;
     if (w >= ctl->nslots) return;
-    SqSlot &sl = s.slots[s.cur][w];
+    SqSlot &sl = s.slots[ctl->cur][w];
     if (lane == 0 && sl.pk[3]) {                        // the cell table is rebuilt by the next round's k_sq_prep
         s.cellhead[sl.c0] = -1;
         s.cellhead[sl.c1] = -1;
@@ -714,20 +720,22 @@ __device__ __forceinline__ int sq_table_owner(const int *keys, const int *vals, 
 }
 
 template <int D>
-__global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(SqArgs s)
+__global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__restrict__ tab)
 {
+    const SqArgs &s = tab[blockIdx.y];
     extern __shared__ int sq_table[];            // keys[4 K], vals[4 K]
     __shared__ int lds[SQ_FILL_THREADS / 64 + 2];
     const RefArgs &a = s.a;
     SqCtl *ctl = s.ctl;
-    const SqSlot *src = s.slots[s.cur];
+    const int cur = ctl->cur;
+    const SqSlot *src = s.slots[cur];
     const int tid = threadIdx.x;
     const unsigned tmask = (unsigned)(4 * s.K - 1);          // the host keeps K a power of two
     int *keys = sq_table, *vals = sq_table + 4 * s.K;
     const int nold = ctl->nslots;
     const unsigned long long next = ctl->next;
     unsigned long long lim = ctl->gend;
-    if (s.gen_hi < lim) lim = s.gen_hi;
+    if (ctl->gen_hi < lim) lim = ctl->gen_hi;
     if (ctl->prefix + s.ring_mask + 1 < lim) lim = ctl->prefix + s.ring_mask + 1;
     const int maxcand = (lim <= next) ? 0 : (int)min((unsigned long long)s.K, lim - next);
     for (int k = tid; k < 4 * s.K; k += SQ_FILL_THREADS) { keys[k] = -1; vals[k] = INT_MAX; }
@@ -821,6 +829,7 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(SqArgs s)
     }
     if (tid < SQ_KW) s.cp[tid] = 0;
     if (tid == 0) {
+        ctl->cur = cur ^ 1;                       // (k_sq_prep fills it from slots[cur])
         ctl->f_nold = nold;
         ctl->f_nkeep = nkeep;
         ctl->f_next0 = next;
@@ -837,14 +846,16 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(SqArgs s)
 // ---- round, second launch: the new window -- held-back steps moved up, admitted steps built (position, trial position, cells) ------
 // one thread per old slot and per admitted step; writes slots[cur] from slots[cur ^ 1] (the host has flipped cur)
 template <int D>
-__global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
+__global__ __launch_bounds__(256) void k_sq_prep(const SqArgs *__restrict__ tab)
 {
+    const SqArgs &s = tab[blockIdx.y];
     const RefArgs &a = s.a;
     const SqCtl *ctl = s.ctl;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nold = ctl->f_nold, nkeep = ctl->f_nkeep;
     const int nadm = ctl->nslots - nkeep;
-    SqSlot *dst = s.slots[s.cur];
+    const int cur = ctl->cur;
+    SqSlot *dst = s.slots[cur];
     if (t < ctl->nslots) {                              // row t of the conflict matrix: the words that can hold an earlier step
         unsigned long long *row = s.M + (size_t)t * SQ_KW;
         for (int k = 0; k <= (t >> 6); k++) row[k] = 0;
@@ -852,7 +863,7 @@ __global__ __launch_bounds__(256) void k_sq_prep(SqArgs s)
     if (t < nold) {
         const int to = s.moveto[t];
         if (to >= 0) {
-            const SqSlot sl = s.slots[s.cur ^ 1][t];
+            const SqSlot sl = s.slots[cur ^ 1][t];
             dst[to] = sl;
             if (sl.pk[3]) {                             // entered under its cell(s): sq_conflicts walks these chains
                 s.cellnext[2 * to] = atomicExch(&s.cellhead[sl.c0], 2 * to);

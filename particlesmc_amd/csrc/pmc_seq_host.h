@@ -154,10 +154,91 @@ static unsigned long long seq_fold(const SqLog *log, unsigned long long mask, un
 }
 
 // mc_sweep!(system, pool, rng; mc_steps = nsweeps N) as the reference runs it -- one particle per step, every step seeing
-// the state all earlier steps left (src/moves.jl:11-20,57-81,187-207) -- in speculative windows (pmc_seq.h).
-static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+// the state all earlier steps left (src/moves.jl:11-20,57-81,187-207) -- in speculative windows (pmc_seq.h).  One call is a
+// sequence of BATCHES of rounds.  The chains of a pmc_sweep_many call form a GROUP: they share every launch of a round (the
+// kernels take the chain from blockIdx.y and their arguments from a device table), on the first chain's stream; a chain that
+// has finished its steps idles in the launches that are left.  pmc_sweep is a group of one.
+struct SeqRun {
+    pmc_system *h = nullptr;
+    SqArgs s;
+    SqCtl c0, c;
+    unsigned long long ring = 0, gen_hi = 0, next_known = 0, prefix = 0;
+    unsigned long long att[8] = {0}, acc[8] = {0};
+    double energy = 0.0, per_round = 0.0;
+    long long guard = 0, nsteps = 0;
+    int64_t nsweeps = 0;
+    bool done = false, failed = false;
+};
+
+struct SeqGroup {
+    std::vector<SeqRun> runs;
+    pmc_system *lead = nullptr;       // its stream carries the group's launches, its events time them
+    SqArgs *d_tab = nullptr;          // device table of the chains' arguments
+    int n = 0, K = 0;
+    size_t lds = 0, lds_fill = 0;
+    long long rounds_last = 0;
+    hipGraphExec_t graph = nullptr;   // SQ_GRAPH_ROUNDS rounds, captured once per call (a group of one caches it on the handle)
+    bool own_graph = false;
+    ~SeqGroup()
+    {
+        if (d_tab && n > 1) (void)hipFree(d_tab);
+        if (graph && own_graph) (void)hipGraphExecDestroy(graph);
+    }
+};
+
+#define SQ_GRAPH_ROUNDS 16
+
+static void seq_launch_round(const SeqGroup &g)
 {
-    const int K = seq_window(h);
+    pmc_system *h = g.lead;
+    const int K = g.K, n = g.n;
+    if (h->D == 3) {
+        hipLaunchKernelGGL(k_sq_fill<3>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
+        hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
+        hipLaunchKernelGGL(k_sq_round_a<3>, dim3(K, n), dim3(64), g.lds, h->stream, g.d_tab);
+        hipLaunchKernelGGL(k_sq_commit<3>, dim3(K, n), dim3(64), 0, h->stream, g.d_tab);
+    } else {
+        hipLaunchKernelGGL(k_sq_fill<2>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
+        hipLaunchKernelGGL(k_sq_prep<2>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
+        hipLaunchKernelGGL(k_sq_round_a<2>, dim3(K, n), dim3(64), g.lds, h->stream, g.d_tab);
+        hipLaunchKernelGGL(k_sq_commit<2>, dim3(K, n), dim3(64), 0, h->stream, g.d_tab);
+    }
+}
+
+// SQ_GRAPH_ROUNDS rounds as one graph launch: the arguments of a round never change within a call (which window buffer is
+// current and how far the random parts reach live in the device's control blocks), and four kernels per round enqueued one
+// by one cost the host more than the device needs to run them
+static int seq_graph(SeqGroup &g)
+{
+    pmc_system *h = g.lead;
+    if (g.graph) return PMC_OK;
+    if (g.n == 1 && h->sq_graph && h->sq_graph_K == g.K && memcmp(&h->sq_graph_args, &g.runs[0].s, sizeof(SqArgs)) == 0) {
+        g.graph = h->sq_graph;
+        return PMC_OK;
+    }
+    hipGraph_t gr = nullptr;
+    hipGraphExec_t ex = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int q = 0; q < SQ_GRAPH_ROUNDS; q++) seq_launch_round(g);
+    HIPCHK(h, hipStreamEndCapture(h->stream, &gr));
+    const hipError_t e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(gr);
+    if (e != hipSuccess) return fail(h, PMC_ERR_HIP, "hipGraphInstantiate failed");
+    g.graph = ex;
+    if (g.n == 1) {                                          // kept with the handle: the next call with the same arguments reuses it
+        if (h->sq_graph) (void)hipGraphExecDestroy(h->sq_graph);
+        h->sq_graph = ex;
+        h->sq_graph_args = g.runs[0].s;
+        h->sq_graph_K = g.K;
+    } else {
+        g.own_graph = true;
+    }
+    return PMC_OK;
+}
+
+static int seq_run_begin(SeqRun &r, pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, int K, hipStream_t stream)
+{
+    r.h = h;
     int rc = seq_ensure(h, K);
     if (rc) return rc;
     if (!h->cells_built) {
@@ -165,9 +246,10 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
         if (rc) return rc;
     }
     if (int rs = refresh_stale_energy(h)) return rs;
-    const long long nsteps = nsweeps * (int64_t)h->N;      // sweepstep = N, src/ParticlesMC.jl:246
-    const unsigned long long ring = (unsigned long long)h->sq_ring;
-    SqArgs s;
+    r.nsweeps = nsweeps;
+    r.nsteps = nsweeps * (int64_t)h->N;                    // sweepstep = N, src/ParticlesMC.jl:246
+    r.ring = (unsigned long long)h->sq_ring;
+    SqArgs &s = r.s;
     memset(&s, 0, sizeof s);
     s.a = ref_args(h);
     for (int q = 0; q < 3; q++) s.invbox[q] = 1.0 / s.a.box[q];
@@ -179,127 +261,234 @@ static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool,
     s.cellnext = h->d_sq_cellnext;
     s.cp = h->d_sq_cp;
     s.log = h->d_sq_log;
-    s.ring_mask = ring - 1;
+    s.ring_mask = r.ring - 1;
     s.moveto = h->d_sq_moveto;
     s.cand = h->d_sq_moveto + SQ_KMAX;
     s.ctl = h->d_sq_ctl;
     s.pool = make_pool(pool, npool);
     s.K = K;
-    s.cur = 0;
     s.reverse = (h->list_type == 1) ? 1 : 0;
     s.ids_cap = h->nn * h->cl_cap;
     if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
-    const size_t lds = (size_t)((s.ids_cap + 3) & ~3) * sizeof(int) + 2 * (size_t)SQ_TERMS_BUF * sizeof(double);   // ids + the two term buffers
-    if (lds > 160 * 1024 - 256) return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
-    if (lds > 48 * 1024) {
-        if (h->D == 3) HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_round_a<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_round_a<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    memset(&r.c0, 0, sizeof r.c0);
+    r.c0.next = r.c0.prefix = h->step_ctr;
+    r.c0.gend = h->step_ctr + (unsigned long long)r.nsteps;
+    r.c0.trunc = INT_MAX;
+    r.c0.gen_hi = r.c0.next;
+    *h->h_sq_ctl = r.c0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));            // earlier work on the chain's own stream
+    HIPCHK(h, hipMemcpyAsync(h->d_sq_ctl, h->h_sq_ctl, sizeof(SqCtl), hipMemcpyHostToDevice, stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sq_log, 0, (size_t)r.ring * sizeof(SqLog), stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sq_cellhead, 0xff, (size_t)h->ncell_ref * sizeof(int), stream));   // (clean after every round; cheap insurance per call)
+    HIPCHK(h, hipStreamSynchronize(stream));               // the pinned block is reused for the read-backs below
+    r.gen_hi = r.next_known = r.c0.next;
+    r.prefix = r.c0.prefix;
+    r.energy = h->energy;
+    r.per_round = 0.5 * K;                                  // steps a round finishes: learnt from the batches
+    r.c = r.c0;
+    r.done = r.prefix >= r.c0.gend;
+    return PMC_OK;
+}
+
+static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *pool, int npool, int64_t nsweeps)
+{
+    g.n = n;
+    g.lead = hs[0];
+    g.runs.resize((size_t)n);
+    pmc_system *m = g.lead;
+    int rc = set_device(m);
+    if (rc) return rc;
+    g.K = 0;
+    for (int k = 0; k < n; k++) g.K = std::max(g.K, seq_window(hs[k]));
+    for (int k = 0; k < n; k++) {
+        rc = seq_run_begin(g.runs[k], hs[k], pool, npool, nsweeps, g.K, m->stream);
+        if (rc) return rc;
     }
-    const size_t lds_fill = (size_t)8 * K * sizeof(int);    // keys[4 K] + vals[4 K]
-    if (lds_fill > 48 * 1024) {
-        if (h->D == 3) HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_fill<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill));
-        else HIPCHK(h, hipFuncSetAttribute((const void *)k_sq_fill<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill));
+    int ids_cap = 0;
+    for (int k = 0; k < n; k++) ids_cap = std::max(ids_cap, g.runs[k].s.ids_cap);
+    for (int k = 0; k < n; k++) g.runs[k].s.ids_cap = ids_cap;     // one LDS layout for the launch
+    g.lds = (size_t)((ids_cap + 3) & ~3) * sizeof(int) + 2 * (size_t)SQ_TERMS_BUF * sizeof(double);   // ids + the two term buffers
+    if (g.lds > 160 * 1024 - 256) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
+    if (g.lds > 48 * 1024) {
+        if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_round_a<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_round_a<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
     }
-    SqCtl c0;
-    memset(&c0, 0, sizeof c0);
-    c0.next = c0.prefix = h->step_ctr;
-    c0.gend = h->step_ctr + (unsigned long long)nsteps;
-    c0.trunc = INT_MAX;
-    *h->h_sq_ctl = c0;
-    HIPCHK(h, hipMemcpyAsync(h->d_sq_ctl, h->h_sq_ctl, sizeof(SqCtl), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_sq_log, 0, (size_t)ring * sizeof(SqLog), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_sq_cellhead, 0xff, (size_t)h->ncell_ref * sizeof(int), h->stream));   // (clean after every round; cheap insurance per call)
-    HIPCHK(h, hipStreamSynchronize(h->stream));            // the pinned block is reused for the read-backs below
-    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    unsigned long long gen_hi = c0.next, next_known = c0.next, prefix = c0.prefix;
-    unsigned long long att[8] = {0}, acc[8] = {0};
-    double energy = h->energy;
-    const int grid_a = K;
-    double per_round = 0.5 * K;                             // steps a round finishes: learnt from the batches
-    int cur = 0;
-    long long guard = 0;
-    SqCtl c = c0;
-    while (prefix < c0.gend) {
+    g.lds_fill = (size_t)8 * g.K * sizeof(int);            // keys[4 K] + vals[4 K]
+    if (g.lds_fill > 48 * 1024) {
+        if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_fill<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
+        else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_fill<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
+    }
+    // the table of arguments: a group of one keeps it with the handle
+    std::vector<SqArgs> tab((size_t)n);
+    for (int k = 0; k < n; k++) tab[k] = g.runs[k].s;
+    if (n == 1) {
+        if (!m->d_sq_args) HIPCHK(m, hipMalloc(&m->d_sq_args, sizeof(SqArgs)));
+        g.d_tab = m->d_sq_args;
+    } else {
+        HIPCHK(m, hipMalloc(&g.d_tab, (size_t)n * sizeof(SqArgs)));
+    }
+    HIPCHK(m, hipMemcpy(g.d_tab, tab.data(), (size_t)n * sizeof(SqArgs), hipMemcpyHostToDevice));
+    HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
+    return PMC_OK;
+}
+
+static bool seq_group_done(const SeqGroup &g)
+{
+    for (const SeqRun &r : g.runs) if (!r.done && !r.failed) return false;
+    return true;
+}
+
+// one batch of rounds for every chain of the group onto the lead's stream; returns without waiting
+static int seq_group_enqueue(SeqGroup &g)
+{
+    pmc_system *m = g.lead;
+    const int K = g.K;
+    int rc = set_device(m);
+    if (rc) return rc;
+    long long rounds = 1;
+    for (SeqRun &r : g.runs) {
+        if (r.done || r.failed) continue;
+        pmc_system *h = r.h;
         // random parts ahead of the admission front (the ring holds SQ_GEN steps; admitted steps have been copied out)
-        unsigned long long target = std::min<unsigned long long>(c0.gend, next_known + SQ_GEN);
-        if (gen_hi < target) {
-            unsigned long long g0 = gen_hi;
+        const unsigned long long target = std::min<unsigned long long>(r.c0.gend, r.next_known + SQ_GEN);
+        if (r.gen_hi < target) {
+            unsigned long long g0 = r.gen_hi;
             while (g0 < target) {
-                const int n = (int)std::min<unsigned long long>(target - g0, 1u << 20);
-                hipLaunchKernelGGL(k_sq_gen, dim3(nblk(n, 256)), dim3(256), 0, h->stream, h->d_sq_gen, g0, n, h->key[0], h->key[1], s.pool);
-                g0 += (unsigned long long)n;
+                const int nn = (int)std::min<unsigned long long>(target - g0, 1u << 20);
+                hipLaunchKernelGGL(k_sq_gen, dim3(nblk(nn, 256)), dim3(256), 0, m->stream, h->d_sq_gen, g0, nn, h->key[0], h->key[1], r.s.pool);
+                g0 += (unsigned long long)nn;
             }
-            gen_hi = target;
+            r.gen_hi = target;
+            HIPCHK(h, hipMemcpyAsync(&h->d_sq_ctl->gen_hi, &r.gen_hi, sizeof r.gen_hi, hipMemcpyHostToDevice, m->stream));
         }
-        s.gen_hi = gen_hi;
-        const double left = (double)(c0.gend - prefix);
-        long long rounds = (long long)(left / std::max(per_round, 1.0)) + 2;
-        rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)((gen_hi - next_known) / (unsigned long long)K)));
-        rounds = std::min<long long>(rounds, (long long)(ring / (2ull * K)));    // the log ring holds a batch and the window
-        rounds = std::max<long long>(rounds, 1);
-        for (long long r = 0; r < rounds; r++) {
-            s.cur = cur;
-            if (h->D == 3) hipLaunchKernelGGL(k_sq_fill<3>, dim3(1), dim3(SQ_FILL_THREADS), lds_fill, h->stream, s);
-            else hipLaunchKernelGGL(k_sq_fill<2>, dim3(1), dim3(SQ_FILL_THREADS), lds_fill, h->stream, s);
-            cur ^= 1;
-            s.cur = cur;
-            if (h->D == 3) {
-                hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256), dim3(256), 0, h->stream, s);
-                hipLaunchKernelGGL(k_sq_round_a<3>, dim3(grid_a), dim3(64), lds, h->stream, s);
-                hipLaunchKernelGGL(k_sq_commit<3>, dim3(K), dim3(64), 0, h->stream, s);
-            } else {
-                hipLaunchKernelGGL(k_sq_prep<2>, dim3((2 * K + 255) / 256), dim3(256), 0, h->stream, s);
-                hipLaunchKernelGGL(k_sq_round_a<2>, dim3(grid_a), dim3(64), lds, h->stream, s);
-                hipLaunchKernelGGL(k_sq_commit<2>, dim3(K), dim3(64), 0, h->stream, s);
-            }
-        }
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(h->h_sq_ctl, h->d_sq_ctl, sizeof(SqCtl), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        c = *h->h_sq_ctl;
-        if (c.err) {
+        const double left = (double)(r.c0.gend - r.prefix);
+        long long want = (long long)(left / std::max(r.per_round, 1.0)) + 2;
+        want = std::min<long long>(want, std::max<long long>(1, (long long)((r.gen_hi - r.next_known) / (unsigned long long)K)));
+        want = std::min<long long>(want, (long long)(r.ring / (2ull * K)));    // the log ring holds a batch and the window
+        rounds = std::max(rounds, want);
+    }
+    for (SeqRun &r : g.runs)                                 // ... and no chain's ring may overflow in the batch
+        if (!r.done && !r.failed) rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)(r.ring / (2ull * K))));
+    g.rounds_last = rounds;
+    long long q = 0;
+    if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH")) {
+        if (int rg = seq_graph(g)) return rg;
+        for (; q + SQ_GRAPH_ROUNDS <= rounds; q += SQ_GRAPH_ROUNDS) HIPCHK(m, hipGraphLaunch(g.graph, m->stream));
+    }
+    for (; q < rounds; q++) seq_launch_round(g);
+    HIPCHK(m, hipGetLastError());
+    for (SeqRun &r : g.runs)
+        if (!r.done && !r.failed)
+            HIPCHK(r.h, hipMemcpyAsync(r.h->h_sq_ctl, r.h->d_sq_ctl, sizeof(SqCtl), hipMemcpyDeviceToHost, m->stream));
+    return PMC_OK;
+}
+
+// waits for the batch, folds every chain's log into its system.energy and counters (seq_fold), tells the device how far
+static int seq_group_collect(SeqGroup &g)
+{
+    pmc_system *m = g.lead;
+    int rc = set_device(m);
+    if (rc) return rc;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    int first = PMC_OK;
+    bool copies = false;
+    for (SeqRun &r : g.runs) {
+        if (r.done || r.failed) continue;
+        pmc_system *h = r.h;
+        r.c = *h->h_sq_ctl;
+        if (r.c.err) {
             h->cells_built = false;
             h->energy_stale = true;
-            return fail(h, PMC_ERR_STATE, (c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
+            r.failed = true;
+            const int e = fail(h, PMC_ERR_STATE, (r.c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
+            if (!first) first = e;
+            continue;
         }
         // the log records of [prefix, next): at most two contiguous pieces of the ring
-        if (c.next > prefix) {
-            const unsigned long long lo = prefix & s.ring_mask, n = c.next - prefix;
-            const unsigned long long n1 = std::min<unsigned long long>(n, ring - lo);
-            HIPCHK(h, hipMemcpyAsync(h->h_sq_log + lo, h->d_sq_log + lo, (size_t)n1 * sizeof(SqLog), hipMemcpyDeviceToHost, h->stream));
-            if (n > n1) HIPCHK(h, hipMemcpyAsync(h->h_sq_log, h->d_sq_log, (size_t)(n - n1) * sizeof(SqLog), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (r.c.next > r.prefix) {
+            const unsigned long long lo = r.prefix & r.s.ring_mask, nrec = r.c.next - r.prefix;
+            const unsigned long long n1 = std::min<unsigned long long>(nrec, r.ring - lo);
+            HIPCHK(h, hipMemcpyAsync(h->h_sq_log + lo, h->d_sq_log + lo, (size_t)n1 * sizeof(SqLog), hipMemcpyDeviceToHost, m->stream));
+            if (nrec > n1) HIPCHK(h, hipMemcpyAsync(h->h_sq_log, h->d_sq_log, (size_t)(nrec - n1) * sizeof(SqLog), hipMemcpyDeviceToHost, m->stream));
+            copies = true;
         }
-        const unsigned long long before = prefix;
-        prefix = seq_fold(h->h_sq_log, s.ring_mask, prefix, c.next, &energy, att, acc);
-        HIPCHK(h, hipMemcpyAsync(&h->d_sq_ctl->prefix, &prefix, sizeof prefix, hipMemcpyHostToDevice, h->stream));
-        const double done = (double)(prefix - before);
-        if (done > 0) per_round = std::max(1.0, done / (double)rounds);
-        next_known = c.next;
-        if (done == 0 && ++guard > 8) return fail(h, PMC_ERR_STATE, "sequential engine: no progress");
-        if (done > 0) guard = 0;
     }
-    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    HIPCHK(h, hipEventSynchronize(h->ev[1]));
-    c.prefix = prefix;
-    h->sq_last = c;
-    h->energy = energy;
-    h->step_ctr += (uint64_t)nsteps;
-    h->sweep_ctr += (uint64_t)nsweeps;
-    h->mc_binned = false;
-    h->e_fix_valid = false;
-    h->img_valid = false;
-    if (out) {
-        for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)att[m]; out->accepted[m] = (int64_t)acc[m]; }
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
-        out->kernel_ms = ms;
-        out->sweep_kernel_ms = ms;
-        out->sweep_kernel_launches = (int64_t)c.rounds;
-        out->energy = h->energy;
-        out->energy_fix = 0;
+    if (copies) HIPCHK(m, hipStreamSynchronize(m->stream));
+    for (SeqRun &r : g.runs) {
+        if (r.done || r.failed) continue;
+        pmc_system *h = r.h;
+        const unsigned long long before = r.prefix;
+        r.prefix = seq_fold(h->h_sq_log, r.s.ring_mask, r.prefix, r.c.next, &r.energy, r.att, r.acc);
+        HIPCHK(h, hipMemcpyAsync(&h->d_sq_ctl->prefix, &r.prefix, sizeof r.prefix, hipMemcpyHostToDevice, m->stream));
+        const double done = (double)(r.prefix - before);
+        if (done > 0) r.per_round = std::max(1.0, done / (double)g.rounds_last);
+        r.next_known = r.c.next;
+        if (done == 0 && ++r.guard > 8) {
+            r.failed = true;
+            const int e = fail(h, PMC_ERR_STATE, "sequential engine: no progress");
+            if (!first) first = e;
+            continue;
+        }
+        if (done > 0) r.guard = 0;
+        r.done = r.prefix >= r.c0.gend;
+    }
+    return first;
+}
+
+static int seq_group_end(SeqGroup &g, pmc_stats *out)
+{
+    pmc_system *m = g.lead;
+    int rc = set_device(m);
+    if (rc) return rc;
+    HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
+    HIPCHK(m, hipEventSynchronize(m->ev[1]));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, m->ev[0], m->ev[1]);
+    for (int k = 0; k < g.n; k++) {
+        SeqRun &r = g.runs[k];
+        pmc_system *h = r.h;
+        h->mc_binned = false;
+        h->e_fix_valid = false;
+        h->img_valid = false;
+        if (r.failed) continue;
+        r.c.prefix = r.prefix;
+        h->sq_last = r.c;
+        h->energy = r.energy;
+        h->step_ctr += (uint64_t)r.nsteps;
+        h->sweep_ctr += (uint64_t)r.nsweeps;
+        if (out) {
+            pmc_stats &o = out[k];
+            memset(&o, 0, sizeof o);
+            for (int q = 0; q < PMC_MAX_MOVES; q++) { o.attempted[q] = (int64_t)r.att[q]; o.accepted[q] = (int64_t)r.acc[q]; }
+            o.kernel_ms = ms;
+            o.sweep_kernel_ms = ms;
+            o.sweep_kernel_launches = (int64_t)r.c.rounds;
+            o.energy = h->energy;
+        }
     }
     return PMC_OK;
+}
+
+static int sweep_sequential_fast_many(pmc_system **hs, int n, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    SeqGroup g;
+    int rc = seq_group_begin(g, hs, n, pool, npool, nsweeps);
+    if (rc) return rc;
+    int first = PMC_OK;
+    while (!seq_group_done(g)) {
+        rc = seq_group_enqueue(g);
+        if (rc) return rc;
+        rc = seq_group_collect(g);
+        if (rc && !first) first = rc;
+    }
+    rc = seq_group_end(g, out);
+    return first ? first : rc;
+}
+
+static int sweep_sequential_fast(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    pmc_system *one[1] = {h};
+    return sweep_sequential_fast_many(one, 1, pool, npool, nsweeps, out);
 }
 
 // ---- engine 3: chains whose whole state fits the LDS, one wavefront per chain, any number of chains per launch (pmc_seq.h) ----

@@ -273,3 +273,24 @@ def test_config1_readme_three_particles(gpu, engine):
         att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 10, 0, 0, 1500)
         assert st.attempted[0] == att[0] == 1500 and st.accepted[0] == acc[0]
         assert np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
+
+
+def test_many_larger_chains_interleaved_windows(gpu):
+    """pmc_sweep_many(PMC_SEQUENTIAL) for chains too large for the LDS engine: every chain runs the speculative windows on its
+    own stream and all chains' batches are enqueued before any is waited for.  Every chain equals the oracle's chain of its
+    (seed, chain) and temperature."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = lj_lattice(16, jitter=0.08, seed=2, rho=0.95)          # N = 4096: 98 KB of positions
+    nch = 5
+    temps = [0.8 + 0.1 * k for k in range(nch)]
+    chains = [pmc.System(pos, sp, rho, temps[k], pmc.LennardJones(1.0, 1.0), seed=23, chain=k) for k in range(nch)]
+    pool = [_disp(pmc, 0.1)]
+    stats = pmc.mc_sweep_many(chains, pool, nsweeps=2, mode="sequential")
+    assert chains[0].sequential_info()[0] > 0                              # engine 2 ran (rounds of windows)
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.1}])
+    for k in range(nch):
+        o = O.System(pos, sp, rho, temps[k], O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+        att, acc = o.mc_steps(opool, 23, k, 0, 2 * len(pos))
+        assert stats[k].accepted[0] == acc[0] and stats[k].attempted[0] == att[0], k
+        _same_state(chains[k], o)
