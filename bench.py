@@ -497,6 +497,19 @@ def other_configs(pmc, budget_cpu_s=1.2):
                  "checkerboard_m1": {"moves_per_s": 256 * 4096 * 200 / dt, "rounds": 1,
                                      "roofline_frac": (tests + inr) * 9.0 / dt / 1e12 / FP64_VECTOR_PEAK_TFLOPS if tests > 0 else None,
                                      "acceptance": [sum(float(x.accepted[0]) for x in sts) / sum(float(x.attempted[0]) for x in sts)]}})
+    # ... and the same kind of run on the reference's own (sequential) chain: 32 chains, speculative windows, shared rounds
+    chains = chains[:32]
+    for c_ in chains:
+        c_.rounds = 1
+    pmc.mc_sweep_many(chains, pool, nsweeps=2, mode="sequential")
+    t0 = time.perf_counter()
+    sts = pmc.mc_sweep_many(chains, pool, nsweeps=20, mode="sequential")
+    dt = time.perf_counter() - t0
+    rate = 32 * 4096 * 20 / dt
+    rows.append({"config": "32 chains (parallel = true) of N=4096 3D LJ rho=1 T=1 on the reference's sequential chain: speculative windows, every "
+                           "launch of a round shared by the chains (pmc_sweep_many PMC_SEQUENTIAL)",
+                 "reference_order_chain": {"moves_per_s": rate, "acceptance": [sum(float(x.accepted[0]) for x in sts) / sum(float(x.attempted[0]) for x in sts)],
+                                           "roofline_frac": _seq_flop_frac(4096, 3, chains[0].neighbour_list.ncells, rate, 62.0)}})
     del chains
     # -- the reference's own benchmark system as many chains on its own (sequential) chain
     pos, sp, rho = lj_lattice(6, jitter=0.05, seed=42)
