@@ -1787,7 +1787,9 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
         (h->seq_engine == 3 || (h->ncell_ref <= 343 && seq_lds_fits(h, SQ_LDS_AUTO)))) {
         // few cells per side: every step interacts with every other, and the whole state fits the LDS (pmc_seq.h, engine 3)
         pmc_system *one[1] = {h};
-        return sweep_sequential_lds(one, 1, pool, npool, nsweeps, out);
+        const int rl = sweep_sequential_lds(one, 1, pool, npool, nsweeps, out);
+        // (a crowded cell can make the rows outgrow the LDS after all: nothing has run then, and the windows take over)
+        if (rl != PMC_ERR_UNSUPPORTED || h->seq_engine == 3) return rl;
     }
     if (nsweeps > 0 && h->seq_engine != 3 && seq_fast_applicable(h, pool, npool)) return sweep_sequential_fast(h, pool, npool, nsweeps, out);
     if (!h->cells_built) {
@@ -2220,7 +2222,10 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             const int e = hs[r]->seq_engine;
             if (e == 1 || e == 2 || !seq_lds_fits(hs[r], e == 3 ? SQ_LDS_MAX : SQ_LDS_AUTO)) lds_ok = false;
         }
-        if (lds_ok) return sweep_sequential_lds(hs, n, pool, npool, nsweeps, out);
+        if (lds_ok) {
+            const int rl = sweep_sequential_lds(hs, n, pool, npool, nsweeps, out);
+            if (rl != PMC_ERR_UNSUPPORTED) return rl;
+        }
     }
     if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0) {
         // larger chains on the speculative windows: every chain's rounds are enqueued before any is waited for

@@ -559,20 +559,24 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     pmc_system *m = hs[0];
     int rc = set_device(m);
     if (rc) return rc;
-    // rows of one capacity on every chain
+    // rows of one capacity on every chain (a crowded cell makes a chain's rows grow: then every chain's do)
     int cap = seq_rows_cap(m);
-    for (int r = 0; r < n; r++) if (hs[r]->d_cl_items) cap = std::max(cap, hs[r]->cl_cap);
+    for (int pass = 0; pass < 4; pass++) {
+        for (int r = 0; r < n; r++) if (hs[r]->d_cl_items) cap = std::max(cap, hs[r]->cl_cap);
+        bool same = true;
+        for (int r = 0; r < n; r++) {
+            pmc_system *h = hs[r];
+            if (h->list_type == 1 && (!h->d_cl_items || h->cl_cap != cap)) {
+                rc = seq_alloc_rows(h, cap);
+                if (rc) return rc;
+            }
+            if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
+            if (h->cl_cap != cap) same = false;
+        }
+        if (same) break;
+    }
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
-        if (!h->d_ref_err) {
-            HIPCHK(h, hipMalloc(&h->d_ref_err, 16));
-            HIPCHK(h, hipMemset(h->d_ref_err, 0, 16));
-        }
-        if (h->list_type == 1 && (!h->d_cl_items || h->cl_cap != cap)) {
-            rc = seq_alloc_rows(h, cap);
-            if (rc) return rc;
-        }
-        if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
         if (h->cl_cap != cap) return fail(h, PMC_ERR_STATE, "sequential engine: the chains' cell rows differ in capacity");
         if (int rs = refresh_stale_energy(h)) return rs;
         rc = ensure_species_list(h);

@@ -294,3 +294,35 @@ def test_many_larger_chains_interleaved_windows(gpu):
         att, acc = o.mc_steps(opool, 23, k, 0, 2 * len(pos))
         assert stats[k].accepted[0] == acc[0] and stats[k].attempted[0] == att[0], k
         _same_state(chains[k], o)
+
+
+@pytest.mark.parametrize("engine", [2, 3])
+def test_dilute_gas_and_dense_cluster(gpu, engine):
+    """Edges of the window logic: a dilute gas (many more cells than particles: the window is larger than the number of
+    particles, so admission is cut by repeated particles all the time) and a system with one crowded region (rows of very
+    different lengths), large displacements so that most trials change cell."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, rho = random_gas(300, 0.02, 3, seed=4, min_dist=1.0)
+    rng = np.random.default_rng(3)
+    pos[:60] = pos[0] + rng.uniform(-1.6, 1.6, (60, 3)) * np.linspace(0.4, 1.0, 60)[:, None]     # a droplet around particle 0
+    sp = np.ones(len(pos), dtype=np.int32)
+    T = 2.0
+    try:
+        o = O.System(pos, sp, rho, T, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST)
+    except ValueError:
+        pytest.skip("the droplet has overlapping particles for this seed")
+    g = pmc.System(pos, sp, rho, T, pmc.LennardJones(1.0, 1.0), seed=31)
+    assert g.energy[0] == o.energy
+    if engine == 3 and int(np.prod(g.neighbour_list.ncells)) * 4 > 60000:
+        pytest.skip("too many cells for the LDS engine")
+    try:
+        g.set_sequential_engine(engine, 0)
+    except pmc.PMCError:
+        pytest.skip("the state does not fit the LDS")
+    pool = [_disp(pmc, 0.8)]
+    for call in range(2):
+        st = pmc.mc_sweep(g, pool, nsweeps=5, mode="sequential")
+        att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.8}]), 31, 0, call * 5 * len(pos), 5 * len(pos))
+        assert st.accepted[0] == acc[0], (st.accepted, acc)
+        _same_state(g, o)
