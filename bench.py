@@ -527,6 +527,33 @@ def other_configs(pmc, budget_cpu_s=1.2):
                  "cpu_oracle_moves_per_s": _oracle_rate(lambda: O.System(pos, sp, rho, TEMPERATURE, O.single(O.lennard_jones(1.0, 1.0)), O.LINKEDLIST),
                                                         O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}]), 42, budget_cpu_s),
                  "reference_published": "5.1 us per mc_step! on the reference authors' CPU (benchmark/particles_benchmarks.jl:28) = 1.96e5 moves/s per chain"})
+    # -- the system of the reference's ONLY published timing, as published: N = 216 3-D 50:50 BHHP soft spheres (n = 12),
+    #    rho = 0.5342, T = 0.2, sigma_move = 0.1, EmptyList (all pairs, id order): 5.114 us per mc_step! on its authors' CPU
+    from particlesmc_amd.workloads import random_gas
+    posb, _ = random_gas(216, 0.5342, 3, seed=42, min_dist=0.85)
+    spb = np.ones(216, dtype=np.int32)
+    spb[np.random.default_rng(42).permutation(216)[:108]] = 2
+    poolb = [disp(0.1)]
+    one = pmc.System(posb, spb, 0.5342, 0.2, pmc.BHHP(), list_type=pmc.EmptyList, seed=42)
+    pmc.mc_sweep(one, poolb, nsweeps=200, mode="sequential")
+    t0 = time.perf_counter()
+    stb = pmc.mc_sweep(one, poolb, nsweeps=1000, mode="sequential")
+    dt1 = time.perf_counter() - t0
+    chains = [pmc.System(posb, spb, 0.5342, 0.2, pmc.BHHP(), list_type=pmc.EmptyList, seed=42, chain=k) for k in range(1000)]
+    pmc.mc_sweep_many(chains, poolb, nsweeps=5, mode="sequential")
+    t0 = time.perf_counter()
+    pmc.mc_sweep_many(chains, poolb, nsweeps=100, mode="sequential")
+    dtn = time.perf_counter() - t0
+    mob = O.model_matrix(lambda e, sg: O.soft_spheres(e, sg, 12), ((1.0, 1.0), (1.0, 1.0)), ((1.0, 1.2), (1.2, 1.4)))
+    cpu = _oracle_rate(lambda: O.System(posb, spb, 0.5342, 0.2, mob, O.EMPTYLIST), O.make_pool([{"kind": "Displacement", "sigma": 0.1}]), 42, budget_cpu_s)
+    rows.append({"config": "the reference's published benchmark as published (benchmark/particles_benchmarks.jl:10-28): N=216 3D 50:50 BHHP soft spheres n=12, "
+                           "rho=0.5342, T=0.2, sigma_move=0.1, EmptyList; the reference's sequential chain, state in LDS",
+                 "reference_order_chain": {"us_per_step_one_chain": 1e6 * dt1 / (216 * 1000), "moves_per_s_one_chain": 216 * 1000 / dt1,
+                                           "moves_per_s_1000_chains": 1000 * 216 * 100 / dtn,
+                                           "acceptance": [float(stb.accepted[0]) / max(1.0, float(stb.attempted[0]))]},
+                 "cpu_oracle_moves_per_s": cpu, "cpu_oracle_us_per_step": 1e6 / cpu,
+                 "reference_published": {"us_per_mc_step": 5.114, "us_per_step_in_mc_sweep": 1737.0 / 216, "hardware": "not stated (source comment)",
+                                         "source": "benchmark/particles_benchmarks.jl:28-29"}})
     return rows
 
 

@@ -955,6 +955,7 @@ struct SqLdsArgs {
     long long nsteps;
     int reverse;
     int ncell;
+    int empty;               // EmptyList (src/neighbours.jl:13-44): every particle is a neighbour, j in 1:N; no cells, no rows
     // byte offsets of the arrays inside the dynamic LDS block
     int o_rows, o_ccount, o_cs, o_spids, o_spheads, o_species, o_seq, o_gen, o_nbr, o_nbrcnt, o_spoff, o_terms, o_tmask, o_esum;
     int nbr_in_lds;
@@ -1038,7 +1039,8 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
 {
     const int lane = wave_lane(), wv = sql_wave<NW>();
     const int S = s.a.S;
-    const int total = (s.dbg & 8) ? 216 : sql_sequence<D, NW>(s, v, c);
+    const int total = s.empty ? s.a.N : ((s.dbg & 8) ? 216 : sql_sequence<D, NW>(s, v, c));
+    if (s.empty && NW > 1) __syncthreads();                        // (the barrier sql_sequence ends with: the previous pass has read its terms)
     const int ntrip = (total + PMC_WAVE - 1) / PMC_WAVE;
     constexpr int SEG = PMC_WAVE + SQ_TERMS_PAD;                  // NW > 1: one segment of packed terms per trip and sum
     constexpr int BUF = SQ_TERMS + PMC_WAVE + SQ_TERMS_PAD;      // NW == 1: one buffer per sum, summed down when nearly full
@@ -1049,7 +1051,7 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
         const int t = tr * PMC_WAVE + lane;
         double ua = 0.0, ub = 0.0;
         if (t < total && !(s.dbg & 4)) {
-            const int j = v.seq[t];
+            const int j = s.empty ? t : (int)v.seq[t];
             if (j != i) {
                 double xj[3] = {0, 0, 0};
 #pragma unroll
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
         v.spheads[k] = (unsigned short)ch.sp_heads[k];
     }
     for (int k = tid; k <= S; k += nth) v.spoff[k] = ch.sp_off[k];
-    for (int c = 0; c < s.ncell; c++) {
+    for (int c = 0; c < (s.empty ? 0 : s.ncell); c++) {
         const int n = ch.ccount[c];
         if (tid == 0) v.ccount[c] = (unsigned short)n;
         for (int k = tid; k < n; k += nth) v.rows[c * cap + k] = (unsigned short)ch.cl_items[(size_t)c * cap + k];
@@ -1229,8 +1231,8 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                     xn[q] = x[q] + ge.d[q];
                     xr[q] = xn[q] + (-ge.d[q]);
                 }
-                const int c0 = v.cs[i];                       // the list is current: cs[i] is the cell of x_i
-                const int c1 = (s.dbg & 1) ? c0 : sq_cell_of<D>(a, xn);
+                const int c0 = s.empty ? 0 : (int)v.cs[i];    // the list is current: cs[i] is the cell of x_i
+                const int c1 = (s.empty || (s.dbg & 1)) ? c0 : sq_cell_of<D>(a, xn);
                 const int spi = (S > 1) ? (int)v.species[i] : 0;
                 double e1, e2, dummy;
                 if (c1 == c0) {
@@ -1251,7 +1253,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
 #pragma unroll
                     for (int q = 0; q < D; q++) chg |= sq_bits_differ(xr[q], x[q]);
                     if (chg && tid < D) v.pos[i * D + tid] = xr[tid];
-                    const int c2 = chg ? sq_cell_of<D>(a, xr) : c0;
+                    const int c2 = (chg && !s.empty) ? sq_cell_of<D>(a, xr) : c0;
                     if (c1 != c0) sql_row_move<NW>(s, v, c0, c1, i);
                     if (c2 != c1) sql_row_move<NW>(s, v, c1, c2, i);
                 }
@@ -1267,8 +1269,8 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                     for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
                     const int spi = v.species[i], spj = v.species[j];
                     double e1i, e2i, e1j, e2j;
-                    sql_pass<D, true, NW>(s, v, v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
-                    sql_pass<D, true, NW>(s, v, v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
+                    sql_pass<D, true, NW>(s, v, s.empty ? 0 : (int)v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
+                    sql_pass<D, true, NW>(s, v, s.empty ? 0 : (int)v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
                     const double e1 = e1i + e1j, e2 = e2i + e2j;
                     double de = 0.0;
                     if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
@@ -1306,7 +1308,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
         ch.sp_ids[k] = v.spids[k];
         ch.sp_heads[k] = v.spheads[k];
     }
-    for (int c = 0; c < s.ncell; c++) {
+    for (int c = 0; c < (s.empty ? 0 : s.ncell); c++) {
         const int n = v.ccount[c];
         if (tid == 0) {
             ch.ccount[c] = n;

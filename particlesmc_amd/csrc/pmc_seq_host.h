@@ -498,7 +498,9 @@ static size_t seq_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // LDS bytes of k_sq_lds for this system's shape (and the offsets of its arrays)
 static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw = 1)
 {
-    const size_t N = (size_t)h->N, nc = (size_t)h->ncell_ref, nn = (size_t)h->nn;
+    const bool empty = h->list_type == 0;                       // EmptyList: no cells, no rows; the neighbours are 1:N
+    const size_t N = (size_t)h->N, nc = empty ? 1 : (size_t)h->ncell_ref, nn = empty ? 1 : (size_t)h->nn;
+    if (empty) cap = 1;
     size_t o = seq_align(N * h->D * sizeof(double), 16);
     const size_t o_rows = o;      o = seq_align(o + nc * cap * 2, 16);
     const size_t o_ccount = o;    o = seq_align(o + nc * 2, 16);
@@ -508,12 +510,12 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw 
     const size_t o_species = o;   o = seq_align(o + N, 16);
     const size_t o_seq = o;       o = seq_align(o + nn * cap * 2, 16);
     const size_t o_gen = o;       o = seq_align(o + (size_t)nw * 64 * sizeof(SqGen), 16);
-    const size_t trips = (nn * cap + 63) / 64;
+    const size_t trips = empty ? (N + 63) / 64 : (nn * cap + 63) / 64;
     const size_t o_terms = o;     o = seq_align(o + (nw > 1 ? 2 * trips * (64 + SQ_TERMS_PAD) : 2 * (size_t)(SQ_TERMS + 64 + SQ_TERMS_PAD)) * sizeof(double), 16);
     const size_t o_tmask = o;     if (nw > 1) o = seq_align(o + 2 * trips * sizeof(int), 16);
     const size_t o_esum = o;      o = seq_align(o + 4 * sizeof(double), 16);
     const size_t o_spoff = o;     o = seq_align(o + 16 * sizeof(int), 16);
-    const bool nbr_in = nc * nn * 4 <= 16384;
+    const bool nbr_in = !empty && nc * nn * 4 <= 16384;
     const size_t o_nbr = o;       if (nbr_in) o = seq_align(o + nc * nn * 4, 16);
     const size_t o_nbrcnt = o;    if (nbr_in) o = seq_align(o + nc * 4, 16);
     if (s) {
@@ -531,7 +533,7 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw 
 static bool seq_lds_fits(const pmc_system *h, size_t limit)
 {
     if (h->N > 65535 || h->S > 8) return false;
-    if (h->list_type != 1 && h->list_type != 2) return false;
+    if (h->list_type == 3) return false;                        // VerletList: its own update rule (engine 1)
     const int cap = h->d_cl_items ? h->cl_cap : seq_rows_cap(h);
     return seq_lds_layout(h, cap, nullptr) <= limit;
 }
@@ -571,13 +573,13 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
                 if (rc) return rc;
             }
             if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
-            if (h->cl_cap != cap) same = false;
+            if (h->list_type != 0 && h->cl_cap != cap) same = false;
         }
         if (same) break;
     }
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
-        if (h->cl_cap != cap) return fail(h, PMC_ERR_STATE, "sequential engine: the chains' cell rows differ in capacity");
+        if (h->list_type != 0 && h->cl_cap != cap) return fail(h, PMC_ERR_STATE, "sequential engine: the chains' cell rows differ in capacity");
         if (int rs = refresh_stale_energy(h)) return rs;
         rc = ensure_species_list(h);
         if (rc) return rc;
@@ -589,6 +591,7 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     s.pool = make_pool(pool, npool);
     s.reverse = (m->list_type == 1) ? 1 : 0;
     s.ncell = m->ncell_ref;
+    s.empty = (m->list_type == 0) ? 1 : 0;
     if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
     // wavefronts per chain: four split the pair loop and the two ordered sums of a step while the chains alone would leave SIMDs
     // idle; from a thousand chains on, one wavefront per chain fills the chip and wastes nothing on barriers (PMC_SEQ_WAVES: A/B)

@@ -326,3 +326,35 @@ def test_dilute_gas_and_dense_cluster(gpu, engine):
         att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.8}]), 31, 0, call * 5 * len(pos), 5 * len(pos))
         assert st.accepted[0] == acc[0], (st.accepted, acc)
         _same_state(g, o)
+
+
+@pytest.mark.parametrize("waves", [1, 4])
+def test_reference_benchmark_system_empty_list(gpu, waves, monkeypatch):
+    """The system of the reference's ONLY published timing (benchmark/particles_benchmarks.jl:10-28: N = 216 3-D 50:50 BHHP soft
+    spheres, rho = 0.5342, T = 0.2, sigma_move = 0.1, the default EmptyList -- every particle a neighbour, summed in id order):
+    engine 3 keeps it in LDS too (no cells, no rows), alone and as many chains, against the oracle's EmptyList chain."""
+    from oracle import oracle as O
+    pmc = gpu
+    monkeypatch.setenv("PMC_SEQ_WAVES", str(waves))
+    N, rho, T = 216, 0.5342, 0.2
+    pos, _ = random_gas(N, rho, 3, seed=42, min_dist=0.85)
+    sp = np.ones(N, dtype=np.int32)
+    sp[np.random.default_rng(42).permutation(N)[: N // 2]] = 2
+    g = pmc.System(pos, sp, rho, T, pmc.BHHP(), list_type=pmc.EmptyList, seed=42)
+    o = O.System(pos, sp, rho, T, O.bhhp(), O.EMPTYLIST)
+    assert g.energy[0] == o.energy
+    pool = [_disp(pmc, 0.1)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.1}])
+    st = pmc.mc_sweep(g, pool, nsweeps=10, mode="sequential")           # engine: the library's choice (3)
+    att, acc = o.mc_steps(opool, 42, 0, 0, 10 * N)
+    assert st.accepted[0] == acc[0] and np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
+    g.set_sequential_engine(1, 0)                                        # ... and the literal loop continues the same chain
+    st = pmc.mc_sweep(g, pool, nsweeps=1, mode="sequential")
+    att, acc = o.mc_steps(opool, 42, 0, 10 * N, N)
+    assert st.accepted[0] == acc[0] and np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
+    chains = [pmc.System(pos, sp, rho, T, pmc.BHHP(), list_type=pmc.EmptyList, seed=42, chain=k) for k in range(6)]
+    sts = pmc.mc_sweep_many(chains, pool, nsweeps=3, mode="sequential")
+    for k in (0, 5):
+        ok_ = O.System(pos, sp, rho, T, O.bhhp(), O.EMPTYLIST)
+        att, acc = ok_.mc_steps(opool, 42, k, 0, 3 * N)
+        assert sts[k].accepted[0] == acc[0] and np.array_equal(chains[k].position, ok_.positions()) and chains[k].energy[0] == ok_.energy
