@@ -21,7 +21,11 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 python3 examples/seq_rate.py 16 32 48 64 100 > gpurun_out/seq_rate_table.jsonl 2>&1
 for n in 1 64 256 1000 4000; do python3 examples/seq_many.py 6 $n 100; done > gpurun_out/seq_many_table.jsonl 2>&1
 python3 examples/seq_many.py 10 256 20 >> gpurun_out/seq_many_table.jsonl 2>&1
+# the team-of-8 instance of the throughput kernel (config 2), counters for DESIGN 8b / VERDICT r03 item 4
+rm -rf $P/teams_sq $P/teams_trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/teams_trace -- python3 profiles/c2_run.py > $P/teams_run.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/teams_sq -- python3 profiles/c2_run.py > /dev/null 2>&1
 mkdir -p gpurun_out/seq_summary
 PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py r04 --seq-only
-rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write
+rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace
 ls gpurun_out/seq_summary

@@ -141,6 +141,23 @@ def _seq_summary():
                 pmc[kk][c] = {"mean_per_launch": sum(vals) / max(1, len(vals)), "launches": len(vals), "sum": sum(vals)}
     if pmc:
         out["pmc"] = pmc
+    # the team-of-8 instance of k_cb_pass on BASELINE config 2 (N = 32768): the last 40 launches are the timed sweeps
+    teams = {}
+    for k, v in counters("teams_sq").items():
+        if "k_cb_pass" in k:
+            teams["kernel"] = k
+            for c, vals in v.items():
+                vals = vals[-40:]
+                teams[c] = {"mean_per_launch": sum(vals) / max(1, len(vals)), "launches": len(vals)}
+    st = sorted(glob.glob(os.path.join(SRC, "teams_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if st:
+        for r in csv.DictReader(open(st[-1])):
+            if "k_cb_pass" in r["Name"]:
+                teams["avg_launch_us_all_launches"] = float(r["AverageNs"]) / 1e3
+    if teams:
+        if "SQ_INSTS_VALU" in teams:
+            teams["valu_wave_instructions_per_move"] = teams["SQ_INSTS_VALU"]["mean_per_launch"] / 32768.0
+        json.dump(teams, open(os.path.join(OUT, f"{tag}_pmc_teams.json"), "w"), indent=1)
     if out:
         json.dump(out, open(os.path.join(OUT, f"{tag}_seq.json"), "w"), indent=1)
         print(f"wrote profiles/{tag}_seq.json")
