@@ -120,6 +120,7 @@ struct SqArgs {
     int K;                        // window slots in use (<= SQ_KMAX, multiple of 64)
     int reverse;                  // 1: LinkedList (chain = row read backwards), 0: CellList (vector order)
     int ids_cap;                  // ints of dynamic LDS of the evaluation (>= 3^d * cl_cap)
+    int arith_nbr;                // every dimension has >= 3 cells: the neighbour cells of a cell follow from its coordinates
     int dbg;                      // PMC_SEQ_DBG (timing experiments only): 1 no energy fold inside the rounds, 2 no pair matrix, 4 no evaluation
 };
 
@@ -303,8 +304,29 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
     constexpr int NN = (D == 3) ? 27 : 9;
     const RefArgs &a = s.a;
     const int lane = wave_lane();
-    const int cnt = a.nbrcnt[c];
-    const int cc = (lane < cnt) ? a.nbr[(size_t)c * a.nnmax + lane] : 0;
+    // the neighbour cells in the reference's order (src/neighbours.jl:94-111: offsets -1, 0, +1, first dimension fastest).  With
+    // three or more cells per side no two of them coincide (`unique!` removes nothing) and they follow from the cell's own
+    // coordinates: no table, one memory round trip less; smaller grids read the table (entry and count in one round trip).
+    int cnt, cc;
+    if (s.arith_nbr) {
+        cnt = NN;
+        int f[3] = {0, 0, 0}, r = c;
+#pragma unroll
+        for (int q = D - 1; q >= 0; q--) { f[q] = r % a.nc[q]; r /= a.nc[q]; }       // last dimension fastest (:79-88)
+        int o = lane < NN ? lane : 0, lin = 0;
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            int g = f[q] + (o % 3) - 1;
+            o /= 3;
+            g = g < 0 ? g + a.nc[q] : (g >= a.nc[q] ? g - a.nc[q] : g);
+            lin = lin * a.nc[q] + g;
+        }
+        cc = lane < NN ? lin : 0;
+    } else {
+        const int raw = (lane < NN) ? a.nbr[(size_t)c * a.nnmax + lane] : 0;
+        cnt = a.nbrcnt[c];
+        cc = (lane < cnt) ? raw : 0;
+    }
     const int len = (lane < cnt) ? a.ccount[cc] : 0;
     int e = (w >= 0 && lane < cnt) ? s.cellhead[cc] : -1;
     const int lane_in_row = lane < a.cl_cap ? lane : 0;

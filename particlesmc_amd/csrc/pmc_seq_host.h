@@ -269,6 +269,9 @@ static int seq_run_begin(SeqRun &r, pmc_system *h, const pmc_move *pool, int npo
     s.K = K;
     s.reverse = (h->list_type == 1) ? 1 : 0;
     s.ids_cap = h->nn * h->cl_cap;
+    s.arith_nbr = 1;
+    for (int q = 0; q < h->D; q++) if (h->p.ncells[q] < 3) s.arith_nbr = 0;
+    if (getenv("PMC_SEQ_NBRTABLE")) s.arith_nbr = 0;
     if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
     memset(&r.c0, 0, sizeof r.c0);
     r.c0.next = r.c0.prefix = h->step_ctr;
