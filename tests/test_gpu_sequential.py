@@ -358,3 +358,38 @@ def test_reference_benchmark_system_empty_list(gpu, waves, monkeypatch):
         ok_ = O.System(pos, sp, rho, T, O.bhhp(), O.EMPTYLIST)
         att, acc = ok_.mc_steps(opool, 42, k, 0, 3 * N)
         assert sts[k].accepted[0] == acc[0] and np.array_equal(chains[k].position, ok_.positions()) and chains[k].energy[0] == ok_.energy
+
+
+@pytest.mark.parametrize("engine", [2, 3])
+def test_every_model_kind_on_the_fast_engines(gpu, engine):
+    """The reference's only known answer (test/runtests.jl:36-38: config_0 under JBB, SmoothLennardJones, 2-D ternary) and soft
+    spheres with an odd exponent (the Float64-power branch, src/models.jl:66) on the sequential chain of engines 2 and 3."""
+    import os
+    from oracle import oracle as O
+    pmc = gpu
+    gold = os.path.join(os.path.dirname(__file__), "golden", "config_0.lmp")
+    s = pmc.load_chains(gold, args={"temperature": [0.231], "model": ["JBB"], "list_type": "LinkedList"})[0]
+    assert abs(s.energy[0] / len(s) - (-2.676832)) < 1e-6
+    cfg = pmc.load_configuration(gold)
+    pos = pmc.fold_back(cfg["position"], cfg["box"])
+    rho = cfg["N"] / np.prod(cfg["box"])
+    g = pmc.System(pos, cfg["species"], rho, 0.231, pmc.JBB(), seed=10)
+    o = O.System(pos, cfg["species"], rho, 0.231, O.jbb(), O.LINKEDLIST)
+    assert g.energy[0] == o.energy
+    g.set_sequential_engine(engine, 0)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.05)], nsweeps=3, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.05}]), 10, 0, 0, 3 * len(pos))
+    assert st.accepted[0] == acc[0]
+    _same_state(g, o)
+    pos, sp, rho = binary_lattice(1000, frac_b=0.5, rho=0.8, jitter=0.05, seed=12)
+    mm = [[pmc.SoftSpheres(1.0, sg, 9) for sg in row] for row in ([1.0, 1.1], [1.1, 1.2])]
+    mo = O.model_matrix(lambda e, sg: O.soft_spheres(e, sg, 9), [[1.0, 1.0], [1.0, 1.0]], [[1.0, 1.1], [1.1, 1.2]])
+    g = pmc.System(pos, sp, rho, 1.0, mm, seed=2)
+    o = O.System(pos, sp, rho, 1.0, mo, O.LINKEDLIST)
+    g.set_sequential_engine(engine, 0)
+    pool = [_disp(pmc, 0.08, 0.8), _swap(pmc, (1, 2), (500, 500), 0.2)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.08, "probability": 0.8}, {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.2}])
+    st = pmc.mc_sweep(g, pool, nsweeps=3, mode="sequential")
+    att, acc = o.mc_steps(opool, 2, 0, 0, 3 * len(pos))
+    assert np.array_equal(st.accepted, acc), (st.accepted, acc)
+    _same_state(g, o, species=True)
