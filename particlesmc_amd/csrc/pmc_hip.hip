@@ -146,6 +146,7 @@ struct pmc_system {
     int *d_sq_moveto = nullptr, *d_sq_cellhead = nullptr, *d_sq_cellnext = nullptr;
     SqLog *d_sq_log = nullptr, *h_sq_log = nullptr;
     int sq_ring = 0;             // records the log ring holds (a power of two)
+    int sq_cap_K = 0, sq_gen = 0;   // window the per-slot buffers are allocated for; steps the ring of random parts holds
     SqCtl *d_sq_ctl = nullptr, *h_sq_ctl = nullptr;
     SqCtl sq_last{};             // control block of the last fast sequential call (diagnostics: rounds, evaluations)
     hipGraphExec_t sq_graph = nullptr;   // SQ_GRAPH_ROUNDS rounds of the windows, captured for sq_graph_args / sq_graph_K

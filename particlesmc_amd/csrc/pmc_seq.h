@@ -46,7 +46,7 @@
 #define SQ_KMAX 4096                 // window slots (bit-matrix rows of SQ_KMAX / 64 words)
 #define SQ_KW (SQ_KMAX / 64)
 #define SQ_RING_MAX (1 << 20)        // per-step log ring (de, flags): the host folds it into system.energy in step order
-#define SQ_GEN 262144                // ring of pre-generated random parts
+#define SQ_GEN_MAX 262144            // ring of pre-generated random parts: 128 windows' worth, at most this many steps
 #define SQ_FILL_THREADS 1024
 
 enum {
@@ -115,6 +115,7 @@ struct SqArgs {
     int *cand;                    // [K][3] ... and the admitted steps: i, j, flags
     SqLog *log;                   // [ring_mask + 1] what every committed step did to system.energy, by step
     unsigned long long ring_mask;
+    unsigned long long gen_mask;  // the ring of random parts holds gen_mask + 1 steps
     SqCtl *ctl;
     MovePool pool;
     int K;                        // window slots in use (<= SQ_KMAX, multiple of 64)
@@ -126,7 +127,7 @@ struct SqArgs {
 
 // ---- random parts ------------------------------------------------------------------------------------------------------
 // exactly the words and operations of k_ref_ops / orc_mc_steps_sequential for step g
-PMC_GLOBAL void k_sq_gen(SqGen *__restrict__ gen, unsigned long long g0, int n, uint32_t key0, uint32_t key1, MovePool pool)
+PMC_GLOBAL void k_sq_gen(SqGen *__restrict__ gen, unsigned long long gen_mask, unsigned long long g0, int n, uint32_t key0, uint32_t key1, MovePool pool)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -147,7 +148,7 @@ PMC_GLOBAL void k_sq_gen(SqGen *__restrict__ gen, unsigned long long g0, int n, 
         box_muller(Q[2], Q[3], &z[2], &z[3]);
         for (int q = 0; q < 3; q++) o.d[q] = pool.sigma[o.m] * z[q];
     }
-    gen[g % SQ_GEN] = o;
+    gen[g & gen_mask] = o;
 }
 
 // ---- helpers -------------------------------------------------------------------------------------------------------------
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__res
         const int q = r * SQ_FILL_THREADS + tid;
         gm[r] = 0; gr1[r] = 0; gq0[r] = 0;
         if (q < maxcand) {
-            const SqGen &ge = s.gen[(next + (unsigned long long)q) % SQ_GEN];
+            const SqGen &ge = s.gen[(next + (unsigned long long)q) & s.gen_mask];
             gm[r] = ge.m; gr1[r] = ge.r1; gq0[r] = ge.q0;
         }
     }
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void k_sq_prep(const SqArgs *__restrict__ tab)
     const int q = t - nold;
     if (q >= nadm) return;
     const unsigned long long g = ctl->f_next0 + (unsigned long long)q;
-    const SqGen &ge = s.gen[g % SQ_GEN];
+    const SqGen &ge = s.gen[g & s.gen_mask];
     const int i = s.cand[3 * q], j = s.cand[3 * q + 1];
     SqSlot sl;
     sl.g = g;

@@ -88,16 +88,27 @@ static int seq_ensure(pmc_system *h, int K)
         if (rc) return rc;
     }
     if (!h->d_sq_ctl) {
-        HIPCHK(h, hipMalloc(&h->d_sq_slots[0], (size_t)SQ_KMAX * sizeof(SqSlot)));
-        HIPCHK(h, hipMalloc(&h->d_sq_slots[1], (size_t)SQ_KMAX * sizeof(SqSlot)));
-        HIPCHK(h, hipMalloc(&h->d_sq_gen, (size_t)SQ_GEN * sizeof(SqGen)));
-        HIPCHK(h, hipMalloc(&h->d_sq_M, (size_t)SQ_KMAX * SQ_KW * sizeof(unsigned long long)));
         HIPCHK(h, hipMalloc(&h->d_sq_cp, (size_t)2 * SQ_KW * sizeof(unsigned long long)));
-        HIPCHK(h, hipMalloc(&h->d_sq_moveto, (size_t)SQ_KMAX * 4 * sizeof(int)));
-        HIPCHK(h, hipMalloc(&h->d_sq_cellnext, (size_t)SQ_KMAX * 2 * sizeof(int)));
         HIPCHK(h, hipMalloc(&h->d_sq_cellhead, (size_t)h->ncell_ref * sizeof(int)));
         HIPCHK(h, hipHostMalloc(&h->h_sq_ctl, sizeof(SqCtl)));
         HIPCHK(h, hipMalloc(&h->d_sq_ctl, sizeof(SqCtl)));
+    }
+    // what scales with the window: slot records, the conflict matrix's rows, the random parts (128 windows' worth)
+    if (K > h->sq_cap_K) {
+        void *old[] = {h->d_sq_slots[0], h->d_sq_slots[1], h->d_sq_gen, h->d_sq_M, h->d_sq_moveto, h->d_sq_cellnext};
+        for (void *q : old) if (q) (void)hipFree(q);
+        h->d_sq_slots[0] = h->d_sq_slots[1] = nullptr; h->d_sq_gen = nullptr; h->d_sq_M = nullptr; h->d_sq_moveto = nullptr; h->d_sq_cellnext = nullptr;
+        h->sq_cap_K = 0;
+        int gen = 8192;
+        while (gen < 128 * K && gen < SQ_GEN_MAX) gen *= 2;
+        HIPCHK(h, hipMalloc(&h->d_sq_slots[0], (size_t)K * sizeof(SqSlot)));
+        HIPCHK(h, hipMalloc(&h->d_sq_slots[1], (size_t)K * sizeof(SqSlot)));
+        HIPCHK(h, hipMalloc(&h->d_sq_gen, (size_t)gen * sizeof(SqGen)));
+        HIPCHK(h, hipMalloc(&h->d_sq_M, (size_t)K * SQ_KW * sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc(&h->d_sq_moveto, (size_t)K * 4 * sizeof(int)));
+        HIPCHK(h, hipMalloc(&h->d_sq_cellnext, (size_t)K * 2 * sizeof(int)));
+        h->sq_cap_K = K;
+        h->sq_gen = gen;
     }
     // the log ring: 64 windows' worth of steps between two folds (16 B per step, device + pinned host)
     int ring = 4096;
@@ -262,8 +273,9 @@ static int seq_run_begin(SeqRun &r, pmc_system *h, const pmc_move *pool, int npo
     s.cp = h->d_sq_cp;
     s.log = h->d_sq_log;
     s.ring_mask = r.ring - 1;
+    s.gen_mask = (unsigned long long)h->sq_gen - 1;
     s.moveto = h->d_sq_moveto;
-    s.cand = h->d_sq_moveto + SQ_KMAX;
+    s.cand = h->d_sq_moveto + h->sq_cap_K;
     s.ctl = h->d_sq_ctl;
     s.pool = make_pool(pool, npool);
     s.K = K;
@@ -352,13 +364,13 @@ static int seq_group_enqueue(SeqGroup &g)
     for (SeqRun &r : g.runs) {
         if (r.done || r.failed) continue;
         pmc_system *h = r.h;
-        // random parts ahead of the admission front (the ring holds SQ_GEN steps; admitted steps have been copied out)
-        const unsigned long long target = std::min<unsigned long long>(r.c0.gend, r.next_known + SQ_GEN);
+        // random parts ahead of the admission front (admitted steps have been copied out of the ring)
+        const unsigned long long target = std::min<unsigned long long>(r.c0.gend, r.next_known + (unsigned long long)h->sq_gen);
         if (r.gen_hi < target) {
             unsigned long long g0 = r.gen_hi;
             while (g0 < target) {
                 const int nn = (int)std::min<unsigned long long>(target - g0, 1u << 20);
-                hipLaunchKernelGGL(k_sq_gen, dim3(nblk(nn, 256)), dim3(256), 0, m->stream, h->d_sq_gen, g0, nn, h->key[0], h->key[1], r.s.pool);
+                hipLaunchKernelGGL(k_sq_gen, dim3(nblk(nn, 256)), dim3(256), 0, m->stream, h->d_sq_gen, r.s.gen_mask, g0, nn, h->key[0], h->key[1], r.s.pool);
                 g0 += (unsigned long long)nn;
             }
             r.gen_hi = target;
