@@ -937,9 +937,24 @@ extern "C" int pmc_build_cells(pmc_system *h)
     hipLaunchKernelGGL(k_ref_links, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, h->d_cell_of, N, h->d_start_ref,
                        h->d_ids_ref, h->ncell_ref, h->d_head, h->d_list, h->d_ccount);
     if (h->list_type >= 2) {
-        // CellList / VerletList: cells[c] vectors in ascending id (build_neighbour_list!, src/neighbours.jl:145-156, 431-435)
-        hipLaunchKernelGGL(k_ref_cellvec, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, N, h->d_cell_of, h->d_start_ref,
-                           h->d_ids_ref, h->ncell_ref, h->d_cl_items, h->cl_cap, h->d_ccount, h->d_ref_err);
+        // CellList / VerletList: cells[c] vectors in ascending id (build_neighbour_list!, src/neighbours.jl:145-156, 431-435).
+        // The reference's vectors grow as they must; the device rows are re-allocated with twice the capacity until the fullest
+        // cell fits (found by tests/test_gpu_seq_fuzz.py: with particles stored outside the box some cells hold 8 x the mean)
+        for (int attempt = 0; ; attempt++) {
+            hipLaunchKernelGGL(k_ref_cellvec, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, N, h->d_cell_of, h->d_start_ref,
+                               h->d_ids_ref, h->ncell_ref, h->d_cl_items, h->cl_cap, h->d_ccount, h->d_ref_err);
+            HIPCHK(h, hipGetLastError());
+            int e = 0;
+            HIPCHK(h, hipMemcpyAsync(&e, h->d_ref_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (!(e & 1)) break;
+            if (attempt >= 12 || (double)h->ncell_ref * 2.0 * h->cl_cap * sizeof(int) > 32e9) break;   // reported below
+            HIPCHK(h, hipMemsetAsync(h->d_ref_err, 0, sizeof(int), h->stream));
+            (void)hipFree(h->d_cl_items);
+            h->d_cl_items = nullptr;
+            h->cl_cap *= 2;
+            HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * h->cl_cap * sizeof(int)));
+        }
     } else if (h->list_type == 1 && h->rows_own) {
         // LinkedList rows of the fast sequential engine (pmc_seq.h): the chain of a cell read backwards = ids ascending
         rc = seq_build_rows(h);
@@ -1792,7 +1807,12 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
         // (a crowded cell can make the rows outgrow the LDS after all: nothing has run then, and the windows take over)
         if (rl != PMC_ERR_UNSUPPORTED || h->seq_engine == 3) return rl;
     }
-    if (nsweeps > 0 && h->seq_engine != 3 && seq_fast_applicable(h, pool, npool)) return sweep_sequential_fast(h, pool, npool, nsweeps, out);
+    if (nsweeps > 0 && h->seq_engine != 3 && seq_fast_applicable(h, pool, npool)) {
+        const int rf = sweep_sequential_fast(h, pool, npool, nsweeps, out);
+        // (neighbourhood rows beyond the LDS -- a cell of thousands of particles -- are refused before anything runs: the
+        // literal loop below has no such limit)
+        if (rf != PMC_ERR_UNSUPPORTED || h->seq_engine == 2) return rf;
+    }
     if (!h->cells_built) {
         int rc = pmc_build_cells(h);
         if (rc) return rc;
