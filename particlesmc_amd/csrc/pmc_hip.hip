@@ -1780,7 +1780,7 @@ extern "C" int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t 
     if (engine < 0 || engine > 3 || window < 0 || window > SQ_KMAX)
         return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront), 2 (speculative windows) or 3 (state in LDS); window 0..4096");
     if (engine == 3 && !seq_lds_fits(h, SQ_LDS_MAX))
-        return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 3 needs a LinkedList or CellList system whose state fits 160 KB of LDS");
+        return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 3 needs a LinkedList, CellList or EmptyList system whose state fits 160 KB of LDS");
     if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
     h->seq_engine = engine;
     h->seq_window = window;

@@ -118,3 +118,59 @@ def _run_case(gpu, case, monkeypatch):
                 assert np.array_equal(g.get_cell_members(c), o.cell_members(c)), (engine, c)
         for s_ in range(1, S + 1):
             assert np.array_equal(g.species_ids(s_), o.species_ids(s_)), (call, engine, s_)
+
+
+@pytest.mark.parametrize("case", range(FIRST, FIRST + max(12, NCASES // 4)))
+def test_random_sequential_chains_in_shared_launches(gpu, case, monkeypatch):
+    """pmc_sweep_many(PMC_SEQUENTIAL) on drawn systems: 2-12 chains of one system (own start configuration, temperature and
+    chain number each), engine and window drawn per call and set on every handle, every chain against the oracle's chain."""
+    from oracle import oracle as O
+    pmc = gpu
+    rng, d, S, pos, sp, rho, T, seed, chain, mm, mo, lt, olt = _draw(pmc, O, 500000 + case)
+    N = len(pos)
+    glt = {"linked": pmc.LinkedList, "cell": pmc.CellList, "empty": pmc.EmptyList}[lt]
+    monkeypatch.delenv("PMC_SEQ_WAVES", raising=False)
+    monkeypatch.delenv("PMC_SEQ_WINDOW", raising=False)
+    if rng.random() < 0.5:
+        monkeypatch.setenv("PMC_SEQ_WAVES", str(int(rng.choice([1, 4]))))
+    nch = int(rng.integers(2, 13)) if N <= 4000 else int(rng.integers(2, 5))
+    box = (N / rho) ** (1.0 / d)
+    starts, temps = [], []
+    for k in range(nch):
+        starts.append(pos + rng.uniform(-0.02, 0.02, size=pos.shape) * box / N ** (1.0 / d))
+        temps.append(float(T * rng.uniform(0.7, 1.4)))
+    chains = [pmc.System(starts[k], sp, rho, temps[k], mm, list_type=glt, seed=seed, chain=k) for k in range(nch)]
+    oracles = [O.System(starts[k], sp, rho, temps[k], mo, olt) for k in range(nch)]
+    pm, po = _pools(pmc, rng, S, chains[0])
+    pool_o = O.make_pool(po)
+    done = 0
+    for call in range(int(rng.integers(1, 3))):
+        engine = int(rng.choice([0, 2, 3]))
+        if engine == 2 and lt == "empty":
+            engine = 0
+        window = int(rng.choice([0, 0, 64, 256]))
+        nsw = int(rng.integers(1, 3))
+        try:
+            for g in chains:
+                g.set_sequential_engine(engine, window)
+            stats = pmc.mc_sweep_many(chains, pm, nsweeps=nsw, mode="sequential")
+        except pmc.PMCError as e:
+            assert engine == 3 and e.code == -4, (engine, e)
+            for g in chains:
+                g.set_sequential_engine(0, window)
+            stats = pmc.mc_sweep_many(chains, pm, nsweeps=nsw, mode="sequential")
+        for k in range(nch):
+            g, o = chains[k], oracles[k]
+            att, acc = o.mc_steps(pool_o, seed, k, done, nsw * N)
+            assert np.array_equal(stats[k].attempted[: len(pm)], att) and np.array_equal(stats[k].accepted[: len(pm)], acc), (call, engine, k)
+            assert np.array_equal(g.position, o.positions()) and np.array_equal(g.species, o.species()), (call, engine, k)
+            assert g.energy[0] == o.energy, (call, engine, k)
+            if lt != "empty":
+                assert np.array_equal(g.get_cells(), o.cells()), (call, engine, k)
+            if lt == "linked":
+                hg, lg = g.get_linked_list()
+                ho, lo = o.linked_list()
+                assert np.array_equal(hg, ho) and np.array_equal(lg, lo), (call, engine, k)
+            for s_ in range(1, S + 1):
+                assert np.array_equal(g.species_ids(s_), o.species_ids(s_)), (call, engine, k, s_)
+        done += nsw * N
