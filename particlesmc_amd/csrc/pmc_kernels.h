@@ -62,6 +62,9 @@
 #define PMC_T(var)
 #endif
 
+#ifndef PMC_ECACHE_MINROUNDS
+#define PMC_ECACHE_MINROUNDS 2   // rounds per visit (schedule parameter m) from which re-picked particles reuse a cached energy
+#endif
 #define PMC_FTRIPS 8         // filter trips whose float coordinates a wavefront keeps in registers: 512 candidates
 
 // ------------------------------------------------------------------------------
@@ -1534,7 +1537,9 @@ struct PairCount {
 // SWAP (DiscreteSwap of the particles in LDS slots pc and pj, species sa <-> sb; `si` carries sa): the two "positions" are the
 // two particles, which do not move; a lane adds the pair energy with the species its particle takes and subtracts the one with
 // the species it has (the terms of src/moves.jl:189-207 = swap_delta below, candidate by candidate).
-template <int D, int KIND, bool MULTI, bool NOWRAP, bool SWAP = false>
+// NEWONLY (a slot whose particle's energy at its present position is cached, PMC_ECACHE): the entries passed the filter at the
+// new position and every lane takes one of them there.
+template <int D, int KIND, bool MULTI, bool NOWRAP, bool SWAP = false, bool NEWONLY = false>
 __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h, const DevModel *tab, const unsigned short *queue,
                                               int qn, int pc, int si, double xo, double yo, double zo, double xn, double yn, double zn,
                                               PairCount &pcnt, int pj = 0, int sb = 0)
@@ -1550,14 +1555,14 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
     // neighbouring lanes: even lanes take the old position (and subtract), odd lanes the new one (and add).  Which of the
     // two a lane takes never changes, so the position is picked once per slot instead of once per trip, and the exact test
     // `r2 > rcut2` below drops the half of a pair that only rode along.
-    const bool isnew = (lane & 1) != 0;
+    const bool isnew = NEWONLY || (lane & 1) != 0;
     const double xi = isnew ? xn : xo, yi = isnew ? yn : yo, zi = isnew ? zn : zo;
-    const int qe = 2 * qn;
+    const int qe = NEWONLY ? qn : 2 * qn;
     if (pcnt.count_dense) pcnt.dense += (unsigned)qe;
     for (int e0 = 0; e0 < qe; e0 += PMC_WAVE) {
         // lanes behind the last entry re-read it (no branch around the loads) and are masked out of the range test
         const int e = min(e0 + lane, qe - 1);
-        const int k = (int)queue[e >> 1];
+        const int k = (int)queue[NEWONLY ? e : (e >> 1)];
         const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
         const double r2 = NOWRAP ? dist2_nowrap<D>(xi, yi, zi, xj, yj, zj) : dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
         if (SWAP && MULTI) {
@@ -1586,12 +1591,13 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
 // wavefront, result in every lane.  f = this wavefront's register copy; fo* / fn* = float images of the old and new
 // position (rel_float).  Requires h.filt.  `overflow` is set (and nothing returned) when the survivor queue cannot hold
 // the next trip: the caller then takes the direct loop for this slot (dense clusters only).
-template <int D, int KIND, bool MULTI, bool SWAP = false>
+// NEWONLY: the energy at the new position alone (returned); otherwise dE, and with `enew` also the new position's part of it.
+template <int D, int KIND, bool MULTI, bool SWAP = false, bool NEWONLY = false>
 __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
                                                         const FRegs &f, int pc, int si, double xo, double yo, double zo,
                                                         double xn, double yn, double zn, float fxo, float fyo, float fzo,
                                                         float fxn, float fyn, float fzn, PairCount &pcnt, bool &overflow,
-                                                        int pj = 0, int sb = 0)
+                                                        int pj = 0, int sb = 0, double *enew = nullptr)
 {
     const int lane = wave_lane();
     // wave-uniform values the compiler cannot prove uniform (they come from loads and cross-lane moves): pin them to
@@ -1642,24 +1648,45 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
         if (b1) (queue + q1)[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)k1;
         qn = q1 + (unsigned)__popcll(m1);
     };
+    // new position only: the two halves of a packed operation take two trips
+    auto trips2n = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        const f2 qx = {fxn, fxn}, qy = {fyn, fyn}, qz = {fzn, fzn};
+        const f2 cx = {f.x[J], f.x[J + 1]}, cy = {f.y[J], f.y[J + 1]};
+        const f2 dx = cx - qx, dy = cy - qy;
+        f2 r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
+        if (D == 3) {
+            const f2 cz = {f.z[J], f.z[J + 1]};
+            const f2 dz = cz - qz;
+            r2 = __builtin_elementwise_fma(dz, dz, r2);
+        }
+        const bool b0 = (r2.x <= thr), b1 = (r2.y <= thr);
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0), m1 = __builtin_amdgcn_ballot_w64(b1);
+        const unsigned k0 = (unsigned)lane + (unsigned)(J * PMC_WAVE), k1 = k0 + (unsigned)PMC_WAVE;
+        const unsigned q0 = qn, q1 = q0 + (unsigned)__popcll(m0);
+        if (b0) (queue + q0)[__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = (unsigned short)k0;
+        if (b1) (queue + q1)[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)k1;
+        qn = q1 + (unsigned)__popcll(m1);
+    };
+    auto trips = [&](auto jc) { if constexpr (NEWONLY) trips2n(jc); else trips2(jc); };
     static_assert(PMC_FTRIPS == 8 && PMC_QCAP >= 2 * 2 * PMC_WAVE, "the first two pairs of trips must fit the queue unchecked");
-    if (nrun > 0) trips2(std::integral_constant<int, 0>{});
-    if (nrun > 2 * PMC_WAVE) trips2(std::integral_constant<int, 2>{});
+    if (nrun > 0) trips(std::integral_constant<int, 0>{});
+    if (nrun > 2 * PMC_WAVE) trips(std::integral_constant<int, 2>{});
     if (nrun > 4 * PMC_WAVE) {
         // each further pair adds at most 128 entries
-        if (qn > (unsigned)(PMC_QCAP - 2 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 4>{});
+        if (qn > (unsigned)(PMC_QCAP - 2 * PMC_WAVE)) overflow = true; else trips(std::integral_constant<int, 4>{});
     }
     if (nrun > 6 * PMC_WAVE && !overflow) {
-        if (qn > (unsigned)(PMC_QCAP - 2 * PMC_WAVE)) overflow = true; else trips2(std::integral_constant<int, 6>{});
+        if (qn > (unsigned)(PMC_QCAP - 2 * PMC_WAVE)) overflow = true; else trips(std::integral_constant<int, 6>{});
     }
     if (overflow) return 0.0;
-    pcnt.tests += 2u * (unsigned)ncand;
+    pcnt.tests += (NEWONLY ? 1u : 2u) * (unsigned)ncand;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PMC_T(tf_1);
-    double acc = h.nowrap ? queue_flush<D, KIND, MULTI, true, SWAP>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb)
-                          : queue_flush<D, KIND, MULTI, false, SWAP>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb);
+    double acc = h.nowrap ? queue_flush<D, KIND, MULTI, true, SWAP, NEWONLY>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb)
+                          : queue_flush<D, KIND, MULTI, false, SWAP, NEWONLY>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1673,6 +1700,7 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
         pcnt.t_dense += tf_2 - tf_1;
     }
 #endif
+    if (!NEWONLY && !SWAP && enew) *enew = wave_sum_exact((lane & 1) ? acc : 0.0);      // the odd lanes took the new position
     return wave_sum_exact(acc);
 }
 
@@ -1685,7 +1713,8 @@ __device__ __forceinline__ double wave_delta_e_direct(const CbArgs &a, const Wav
 template <int D, int KIND, bool MULTI>
 __device__ __forceinline__ double wave_delta_e(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
                                                const FRegs &f, int pc, int si, double xo, double yo, double zo, double xn,
-                                               double yn, double zn, float &fxn, float &fyn, float &fzn, PairCount &pcnt)
+                                               double yn, double zn, float &fxn, float &fyn, float &fzn, PairCount &pcnt,
+                                               double *enew = nullptr, bool *got_enew = nullptr)
 {
     if (h.filt) {
         float fxo, fyo, fzo = 0.0f;
@@ -1717,10 +1746,31 @@ __device__ __forceinline__ double wave_delta_e(const CbArgs &a, const WaveNbh &h
         }
         bool overflow;
         const double de = wave_delta_e_filtered<D, KIND, MULTI>(a, h, tab, queue, f, pc, si, xo, yo, zo, xn, yn, zn,
-                                                                fxo, fyo, fzo, fxn, fyn, fzn, pcnt, overflow);
-        if (!overflow) return de;
+                                                                fxo, fyo, fzo, fxn, fyn, fzn, pcnt, overflow, 0, 0, enew);
+        if (!overflow) { if (got_enew) *got_enew = true; return de; }
     }
     return wave_delta_e_direct<D, KIND, MULTI>(a, h, tab, pc, si, xo, yo, zo, xn, yn, zn, pcnt);
+}
+
+// The energy of the particle in LDS slot pc at its trial position alone (PMC_ECACHE: its energy at the present position is
+// cached).  Requires h.filt; `overflow` as in wave_delta_e_filtered (the caller then takes the full evaluation).
+template <int D, int KIND, bool MULTI>
+__device__ __forceinline__ double wave_e_new(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
+                                             const FRegs &f, int pc, int si, double xn, double yn, double zn,
+                                             float &fxn, float &fyn, float &fzn, PairCount &pcnt, bool &overflow)
+{
+    fzn = 0.0f;
+    if (h.nowrap) {
+        fxn = rel_float<true>(xn, h.bc[0], a.L[0], a.invL[0]);
+        fyn = rel_float<true>(yn, h.bc[1], a.L[1], a.invL[1]);
+        if (D == 3) fzn = rel_float<true>(zn, h.bc[2], a.L[2], a.invL[2]);
+    } else {
+        fxn = rel_float<false>(xn, h.bc[0], a.L[0], a.invL[0]);
+        fyn = rel_float<false>(yn, h.bc[1], a.L[1], a.invL[1]);
+        if (D == 3) fzn = rel_float<false>(zn, h.bc[2], a.L[2], a.invL[2]);
+    }
+    return wave_delta_e_filtered<D, KIND, MULTI, false, true>(a, h, tab, queue, f, pc, si, xn, yn, zn, xn, yn, zn,
+                                                              fxn, fyn, fzn, fxn, fyn, fzn, pcnt, overflow);
 }
 
 // The same dE by the direct loop (every candidate tested in FP64): visits whose neighbourhood does not fit the LDS
@@ -2107,6 +2157,15 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
         }
     };
 
+    // -DPMC_EXP_ECACHE (one wavefront per cell, one species, one Displacement): energies of re-picked particles, see the slot loop
+#ifdef PMC_EXP_ECACHE      // experiment of round 4, measured and left off: see DESIGN.md 8b and profiles/r04_ecache_ab.json
+    constexpr bool ECACHE = (NW == 1) && !MULTI && ONE;
+#else
+    constexpr bool ECACHE = false;
+#endif
+    const bool use_cache = ECACHE && a.rounds >= PMC_ECACHE_MINROUNDS && h.filt && nc <= PMC_WAVE && !anyimg;
+    double ecache = 0.0;
+    unsigned long long cvalid = 0ull;
     const int nsl = nc * a.rounds;     // proposal slots of this visit
     for (int chunk = 0; chunk < nsl; chunk += PMC_WAVE) {
         // lanes generate the slots of this chunk in parallel
@@ -2454,7 +2513,26 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     tp_pro += ts_1 - ts_0;
                     tp_n += 1;
 #endif
-                    const double de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
+                    // -DPMC_EXP_ECACHE: a particle picked again in this visit has its energy at the present position cached (lane p
+                    // of `ecache`): only the trial position is evaluated, dE = e_new - cache -- the same bits, every term being
+                    // a multiple of 2^-32 and every sum exact (dev_quant)
+                    double de, e_new = 0.0;
+                    bool got_enew = false, cached = false;
+                    const int pu = __builtin_amdgcn_readfirstlane(p);
+                    if (ECACHE && use_cache) cached = ((cvalid >> pu) & 1ull) != 0ull;
+                    if (ECACHE && cached) {
+                        bool ovf;
+                        e_new = wave_e_new<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xn, yn, zn, fxn, fyn, fzn, pcnt, ovf);
+                        if (!ovf) {
+                            got_enew = true;
+                            de = e_new - readlane_double(ecache, pu);
+                        } else {
+                            de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
+                        }
+                    } else {
+                        de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt,
+                                                          (ECACHE && use_cache) ? &e_new : nullptr, &got_enew);
+                    }
                     PMC_T(ts_2);
                     ok = tlnu < -de;
                     if (ok) {
@@ -2468,6 +2546,32 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         if (h.filt) update_fregs<D>(fr, pc, fxn, fyn, fzn, h.compacted && nc <= PMC_WAVE);
                         efix += (long long)(de * PMC_FIX);
                         dirty = true;
+                    }
+                    if (ECACHE && use_cache) {
+                        const unsigned long long bit = 1ull << pu;
+                        if (ok) {
+                            // the cached energies of the other centre particles follow the move: the pair term with the mover,
+                            // computed as their own evaluation computes it (they are particle i, the mover is candidate j)
+                            const unsigned long long others = cvalid & ~bit;
+                            if (others) {
+                                if ((lane < nc) && ((others >> lane) & 1ull)) {
+                                    const int kc = h.ctr + lane;
+                                    const double xc = h.cx[kc], yc = h.cy[kc], zc = (D == 3) ? h.cz[kc] : 0.0;
+                                    const DevModel &mm = a.m0;
+                                    const double r2o = h.nowrap ? dist2_nowrap<D>(xc, yc, zc, xo, yo, zo) : dist2_fast<D>(a, xc, yc, zc, xo, yo, zo);
+                                    const double r2n = h.nowrap ? dist2_nowrap<D>(xc, yc, zc, xn, yn, zn) : dist2_fast<D>(a, xc, yc, zc, xn, yn, zn);
+                                    double du = 0.0;
+                                    if (!(r2n > mm.rcut2)) du += dev_quant(pot_kind<KIND>(r2n, mm));
+                                    if (!(r2o > mm.rcut2)) du -= dev_quant(pot_kind<KIND>(r2o, mm));
+                                    ecache += du;
+                                }
+                            }
+                            if (got_enew) { if (lane == pu) ecache = e_new; cvalid |= bit; }
+                            else cvalid &= ~bit;
+                        } else if (!cached && got_enew) {
+                            if (lane == pu) ecache = e_new - de;         // the energy at the position the particle keeps
+                            cvalid |= bit;
+                        }
                     }
 #ifdef PMC_DEBUG_TIME
                     { PMC_T(ts_3); tp_red += ts_3 - ts_2; }
