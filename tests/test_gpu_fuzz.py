@@ -12,7 +12,8 @@ from inputs import lj_lattice
 
 pytestmark = pytest.mark.gpu
 
-NCASES = 36
+NCASES = int(os.environ.get("PMC_FUZZ_CASES", "36"))      # PMC_FUZZ_CASES / PMC_FUZZ_FIRST: longer soaks (round 4: cases 0 .. 1499)
+FIRST = int(os.environ.get("PMC_FUZZ_FIRST", "0"))
 
 
 def _models(pmc, O, rng, S):
@@ -103,7 +104,7 @@ def _draw_configuration(pmc, O, case):
     raise AssertionError(f"case {case}: no acceptable geometry in 50 draws")
 
 
-@pytest.mark.parametrize("case", range(NCASES))
+@pytest.mark.parametrize("case", range(FIRST, FIRST + NCASES))
 def test_random_configuration_both_engines(gpu, case, monkeypatch):
     from oracle import oracle as O
     pmc = gpu
