@@ -393,3 +393,29 @@ def test_every_model_kind_on_the_fast_engines(gpu, engine):
     att, acc = o.mc_steps(opool, 2, 0, 0, 3 * len(pos))
     assert np.array_equal(st.accepted, acc), (st.accepted, acc)
     _same_state(g, o, species=True)
+
+
+def test_ss142d_hundred_chains_of_eight_particles_in_one_launch(gpu):
+    """test/ss142d.jl:8-21 as written, all of it: M = 100 chains of N = 8 (4 + 4) 2-D BHHP soft spheres, rho = 0.5, T = 1,
+    EmptyList, Displacement sigma = 0.065 -- one pmc_sweep_many(PMC_SEQUENTIAL) launch, every chain's state in LDS, every chain
+    against the oracle's chain of its (seed, chain)."""
+    from oracle import oracle as O
+    pmc = gpu
+    N, rho, T, M = 8, 0.5, 1.0, 100
+    box = (N / rho) ** 0.5
+    rng = np.random.default_rng(7)
+    starts, species = [], []
+    for k in range(M):
+        starts.append(rng.uniform(0.0, box, (N, 2)))
+        sp = np.array([1] * 4 + [2] * 4, dtype=np.int32)
+        rng.shuffle(sp)
+        species.append(sp)
+    chains = [pmc.System(starts[k], species[k], rho, T, pmc.BHHP(), list_type=pmc.EmptyList, seed=42, chain=k) for k in range(M)]
+    pool = [_disp(pmc, 0.065)]
+    opool = O.make_pool([{"kind": "Displacement", "sigma": 0.065}])
+    stats = pmc.mc_sweep_many(chains, pool, nsweeps=200, mode="sequential")
+    for k in range(M):
+        o = O.System(starts[k], species[k], rho, T, O.bhhp(), O.EMPTYLIST)
+        att, acc = o.mc_steps(opool, 42, k, 0, 200 * N)
+        assert stats[k].attempted[0] == att[0] == 1600 and stats[k].accepted[0] == acc[0], k
+        assert np.array_equal(chains[k].position, o.positions()) and chains[k].energy[0] == o.energy, k
