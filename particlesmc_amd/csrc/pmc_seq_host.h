@@ -132,8 +132,10 @@ static int seq_window(const pmc_system *h)
         long long nn = 1;
         for (int a = 0; a < h->D; a++) nn *= 3;
         K = (int)(2LL * h->ncell_ref / nn);
-        if (const char *e = getenv("PMC_SEQ_WINDOW")) K = atoi(e);
-        K = std::min(K, 2048);
+        // (measured, 3-D LJ liquid: N = 10^6 -- 4 400 by this rule -- runs 1.45 / 1.58 / 1.51e7 moves/s with windows of 1024 /
+        // 2048 / 4096; N = 4.1e6 (19 400) 1.73 / 2.49 / 2.65e7; N = 8e6 (35 000) 1.74 / 2.61 / 2.98e7)
+        K = (K >= 16384) ? SQ_KMAX : std::min(K, 2048);
+        if (const char *e = getenv("PMC_SEQ_WINDOW")) K = std::min(atoi(e), SQ_KMAX);
     }
     int P = 64;                                             // a power of two (the fill kernel's hash table has 4 K entries)
     while (P < K && P < SQ_KMAX) P *= 2;

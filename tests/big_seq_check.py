@@ -1,6 +1,6 @@
 """Not a pytest file (the oracle needs 2-3 minutes): one sweep of the reference-order chain at N = n^3 (default 200^3 = 8 * 10^6, the
 maximum-size case) on the speculative windows against the oracle -- accept count, positions, system.energy, cs, head / list.
-usage (MI355X box): python tests/big_seq_check.py [n]     round 4: N = 8 * 10^6 bit-equal, 0.31 s against 136 s"""
+usage (MI355X box): python tests/big_seq_check.py [n]     round 4: N = 8 * 10^6 bit-equal, 0.27 s against 140 s"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
