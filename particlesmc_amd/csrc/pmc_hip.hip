@@ -939,7 +939,8 @@ extern "C" int pmc_build_cells(pmc_system *h)
     if (h->list_type >= 2) {
         // CellList / VerletList: cells[c] vectors in ascending id (build_neighbour_list!, src/neighbours.jl:145-156, 431-435).
         // The reference's vectors grow as they must; the device rows are re-allocated with twice the capacity until the fullest
-        // cell fits (found by tests/test_gpu_seq_fuzz.py: with particles stored outside the box some cells hold 8 x the mean)
+        // cell fits (found by tests/test_gpu_seq_fuzz.py: CellList's floor(Int, box / cell) can come out one short of box / rcut's -- box /
+        // (box / 7) = 6.999... -- and the last slab of every dimension then folds onto the first: cells of 2, 4 and 8 x the mean)
         for (int attempt = 0; ; attempt++) {
             hipLaunchKernelGGL(k_ref_cellvec, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, N, h->d_cell_of, h->d_start_ref,
                                h->d_ids_ref, h->ncell_ref, h->d_cl_items, h->cl_cap, h->d_ccount, h->d_ref_err);

@@ -7,7 +7,7 @@ density from a dilute gas to a dense liquid, temperature from frozen to hot, 1-3
 with one or two displacement widths up to most of a cell and swaps, LinkedList / CellList / EmptyList, particles stored
 several boxes away from their folded image, the engine, its window, the team width of the LDS engine and the split of the
 sweeps into calls.  Every case is reproducible from its number; PMC_SEQ_FUZZ_CASES=<n> (and PMC_SEQ_FUZZ_FIRST=<k>)
-run a longer soak (the round's: cases 0 .. 7999; it found the fixed capacity of the CellList rows)."""
+run a longer soak (the round's: cases 0 .. 7999; it found that CellList cells can hold 8 x the mean)."""
 import os
 
 import numpy as np
@@ -61,8 +61,10 @@ def test_random_sequential_chain(gpu, case, monkeypatch):
 
 @pytest.mark.parametrize("case", [283, 1321])
 def test_cell_list_rows_grow_with_the_fullest_cell(gpu, case, monkeypatch):
-    """What the soak found: a CellList built from particles stored boxes away from their folded image puts up to 8 x the mean
-    into some cells (64 where the mean is 8, 216 where it is 32); the reference's vectors grow, and so do the device rows."""
+    """What the soak found: CellList's cell count, floor(Int, box / cell) with cell = box / floor(box / rcut)
+    (src/neighbours.jl:126-133), can come out one short -- box / (box / 7) = 6.999... gives 6 cells of width box / 7 -- and the
+    seventh slab of every dimension folds onto the first: cells of 2, 4 and 8 x the mean (64 where the mean is 8, 216 where it
+    is 32).  The reference's vectors grow, and so do the device rows."""
     _run_case(gpu, case, monkeypatch)
 
 
