@@ -90,7 +90,7 @@ static int seq_ensure(pmc_system *h, int K)
     if (!h->d_sq_ctl) {
         HIPCHK(h, hipMalloc(&h->d_sq_cp, (size_t)2 * SQ_KW * sizeof(unsigned long long)));
         HIPCHK(h, hipMalloc(&h->d_sq_cellhead, (size_t)h->ncell_ref * sizeof(int)));
-        HIPCHK(h, hipHostMalloc(&h->h_sq_ctl, sizeof(SqCtl)));
+        HIPCHK(h, hipHostMalloc(&h->h_sq_ctl, 2 * sizeof(SqCtl)));      // [0]: the device's block read back; [1]: words on their way to it
         HIPCHK(h, hipMalloc(&h->d_sq_ctl, sizeof(SqCtl)));
     }
     // what scales with the window: slot records, the conflict matrix's rows, the random parts (128 windows' worth)
@@ -111,7 +111,7 @@ static int seq_ensure(pmc_system *h, int K)
         h->sq_gen = gen;
     }
     // the log ring: 64 windows' worth of steps between two folds (16 B per step, device + pinned host)
-    int ring = 4096;
+    int ring = 16384;
     while (ring < 64 * K && ring < SQ_RING_MAX) ring *= 2;
     if (ring > h->sq_ring) {
         if (h->d_sq_log) (void)hipFree(h->d_sq_log);
@@ -189,7 +189,7 @@ struct SeqGroup {
     SqArgs *d_tab = nullptr;          // device table of the chains' arguments
     int n = 0, K = 0;
     size_t lds = 0, lds_fill = 0;
-    long long rounds_last = 0;
+    long long rounds_last = 0, rounds_folded = 0;     // rounds of the batch enqueued last / of the batch being folded
     hipGraphExec_t graph = nullptr;   // SQ_GRAPH_ROUNDS rounds, captured once per call (a group of one caches it on the handle)
     bool own_graph = false;
     ~SeqGroup()
@@ -356,10 +356,13 @@ static bool seq_group_done(const SeqGroup &g)
 }
 
 // one batch of rounds for every chain of the group onto the lead's stream; returns without waiting
-static int seq_group_enqueue(SeqGroup &g)
+static int seq_group_enqueue(SeqGroup &g, bool pipelined = false)
 {
     pmc_system *m = g.lead;
     const int K = g.K;
+    // (pipelined: the host is still folding the batch before this one while it runs, so the device's idea of the folded prefix
+    // lags by two batches: a quarter of the ring per batch keeps the admission front clear of it)
+    const unsigned long long ring_div = pipelined ? 4ull : 2ull;
     int rc = set_device(m);
     if (rc) return rc;
     long long rounds = 1;
@@ -378,14 +381,15 @@ static int seq_group_enqueue(SeqGroup &g)
             r.gen_hi = target;
             HIPCHK(h, hipMemcpyAsync(&h->d_sq_ctl->gen_hi, &r.gen_hi, sizeof r.gen_hi, hipMemcpyHostToDevice, m->stream));
         }
-        const double left = (double)(r.c0.gend - r.prefix);
+        // steps still to decide: from the fold's position, or (pipelined: the fold lags) from the admission front plus a window
+        const double left = pipelined ? (double)(r.c0.gend - r.next_known) + (double)K : (double)(r.c0.gend - r.prefix);
         long long want = (long long)(left / std::max(r.per_round, 1.0)) + 2;
         want = std::min<long long>(want, std::max<long long>(1, (long long)((r.gen_hi - r.next_known) / (unsigned long long)K)));
-        want = std::min<long long>(want, (long long)(r.ring / (2ull * K)));    // the log ring holds a batch and the window
+        want = std::min<long long>(want, (long long)(r.ring / (ring_div * K)));    // the log ring holds a batch and the window
         rounds = std::max(rounds, want);
     }
     for (SeqRun &r : g.runs)                                 // ... and no chain's ring may overflow in the batch
-        if (!r.done && !r.failed) rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)(r.ring / (2ull * K))));
+        if (!r.done && !r.failed) rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)(r.ring / (ring_div * K))));
     g.rounds_last = rounds;
     long long q = 0;
     if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH")) {
@@ -400,15 +404,17 @@ static int seq_group_enqueue(SeqGroup &g)
     return PMC_OK;
 }
 
-// waits for the batch, folds every chain's log into its system.energy and counters (seq_fold), tells the device how far
-static int seq_group_collect(SeqGroup &g)
+// waits for the batch, reads every chain's control block and enqueues the copies of its new log records; `all_admitted`: no
+// chain has steps left to admit (what remains is at most a window per chain)
+static int seq_group_wait(SeqGroup &g, bool &copies, bool &all_admitted)
 {
     pmc_system *m = g.lead;
     int rc = set_device(m);
     if (rc) return rc;
     HIPCHK(m, hipStreamSynchronize(m->stream));
     int first = PMC_OK;
-    bool copies = false;
+    copies = false;
+    all_admitted = true;
     for (SeqRun &r : g.runs) {
         if (r.done || r.failed) continue;
         pmc_system *h = r.h;
@@ -429,17 +435,29 @@ static int seq_group_collect(SeqGroup &g)
             if (nrec > n1) HIPCHK(h, hipMemcpyAsync(h->h_sq_log, h->d_sq_log, (size_t)(nrec - n1) * sizeof(SqLog), hipMemcpyDeviceToHost, m->stream));
             copies = true;
         }
+        r.next_known = r.c.next;
+        if (r.c.next < r.c0.gend) all_admitted = false;
     }
-    if (copies) HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (copies) HIPCHK(m, hipEventRecord(m->ev[2], m->stream));
+    return first;
+}
+
+// folds every chain's copied log into its system.energy and counters (seq_fold) and tells the device how far
+static int seq_group_fold(SeqGroup &g, bool copies)
+{
+    pmc_system *m = g.lead;
+    int first = PMC_OK;
+    if (copies) HIPCHK(m, hipEventSynchronize(m->ev[2]));
     for (SeqRun &r : g.runs) {
         if (r.done || r.failed) continue;
         pmc_system *h = r.h;
         const unsigned long long before = r.prefix;
         r.prefix = seq_fold(h->h_sq_log, r.s.ring_mask, r.prefix, r.c.next, &r.energy, r.att, r.acc);
-        HIPCHK(h, hipMemcpyAsync(&h->d_sq_ctl->prefix, &r.prefix, sizeof r.prefix, hipMemcpyHostToDevice, m->stream));
+        // (from pinned memory: with the next batch already on the stream this copy must not make the host wait for it)
+        h->h_sq_ctl[1].prefix = r.prefix;
+        HIPCHK(h, hipMemcpyAsync(&h->d_sq_ctl->prefix, &h->h_sq_ctl[1].prefix, sizeof r.prefix, hipMemcpyHostToDevice, m->stream));
         const double done = (double)(r.prefix - before);
-        if (done > 0) r.per_round = std::max(1.0, done / (double)g.rounds_last);
-        r.next_known = r.c.next;
+        if (done > 0) r.per_round = std::max(1.0, done / (double)g.rounds_folded);
         if (done == 0 && ++r.guard > 8) {
             r.failed = true;
             const int e = fail(h, PMC_ERR_STATE, "sequential engine: no progress");
@@ -492,11 +510,34 @@ static int sweep_sequential_fast_many(pmc_system **hs, int n, const pmc_move *po
     int rc = seq_group_begin(g, hs, n, pool, npool, nsweeps);
     if (rc) return rc;
     int first = PMC_OK;
-    while (!seq_group_done(g)) {
-        rc = seq_group_enqueue(g);
-        if (rc) return rc;
-        rc = seq_group_collect(g);
+    // Batches of rounds; while steps are left to admit, the next batch is enqueued BEFORE the host copies and folds the log of the
+    // one that has just finished (the copies are ordered ahead of it on the stream), so the device does not wait for the fold
+    // (large windows only: N = 10^6 gains 3 %; with windows of 64 .. 512 a batch is a few hundred microseconds of copies and folds
+    // per several milliseconds of rounds, and the shorter batches the lagging prefix asks for cost more than that -- 32 chains of
+    // N = 4096 lost 12 %)
+    const bool pipe = g.K >= 1024 && !getenv("PMC_SEQ_NOPIPE");
+    rc = seq_group_enqueue(g);
+    if (rc) return rc;
+    g.rounds_folded = g.rounds_last;
+    while (true) {
+        bool copies = false, all_admitted = true;
+        rc = seq_group_wait(g, copies, all_admitted);
         if (rc && !first) first = rc;
+        bool enqueued = false;
+        const long long rounds_done = g.rounds_last;
+        if (pipe && !all_admitted && !first) {
+            rc = seq_group_enqueue(g, true);
+            if (rc) return rc;
+            enqueued = true;
+        }
+        g.rounds_folded = rounds_done;
+        rc = seq_group_fold(g, copies);
+        if (rc && !first) first = rc;
+        if (seq_group_done(g)) break;              // (never with a batch in flight: a chain with steps to admit is not done)
+        if (!enqueued) {
+            rc = seq_group_enqueue(g);
+            if (rc) return rc;
+        }
     }
     rc = seq_group_end(g, out);
     return first ? first : rc;
