@@ -515,7 +515,7 @@ static int sweep_sequential_fast_many(pmc_system **hs, int n, const pmc_move *po
     // (large windows only: N = 10^6 gains 3 %; with windows of 64 .. 512 a batch is a few hundred microseconds of copies and folds
     // per several milliseconds of rounds, and the shorter batches the lagging prefix asks for cost more than that -- 32 chains of
     // N = 4096 lost 12 %)
-    const bool pipe = g.K >= 1024 && !getenv("PMC_SEQ_NOPIPE");
+    const bool pipe = (g.K >= 1024 || getenv("PMC_SEQ_PIPE")) && !getenv("PMC_SEQ_NOPIPE");
     rc = seq_group_enqueue(g);
     if (rc) return rc;
     g.rounds_folded = g.rounds_last;
