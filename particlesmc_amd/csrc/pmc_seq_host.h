@@ -99,8 +99,10 @@ static int seq_ensure(pmc_system *h, int K)
         for (void *q : old) if (q) (void)hipFree(q);
         h->d_sq_slots[0] = h->d_sq_slots[1] = nullptr; h->d_sq_gen = nullptr; h->d_sq_M = nullptr; h->d_sq_moveto = nullptr; h->d_sq_cellnext = nullptr;
         h->sq_cap_K = 0;
+        // (512 windows' worth for small windows: a batch between two visits of the host is then ~20 ms of rounds, and the
+        // copies, folds and launches per chain and batch -- a third of the time for 128 chains -- shrink with it)
         int gen = 8192;
-        while (gen < 128 * K && gen < SQ_GEN_MAX) gen *= 2;
+        while (gen < 512 * K && gen < SQ_GEN_MAX) gen *= 2;
         HIPCHK(h, hipMalloc(&h->d_sq_slots[0], (size_t)K * sizeof(SqSlot)));
         HIPCHK(h, hipMalloc(&h->d_sq_slots[1], (size_t)K * sizeof(SqSlot)));
         HIPCHK(h, hipMalloc(&h->d_sq_gen, (size_t)gen * sizeof(SqGen)));
@@ -110,9 +112,9 @@ static int seq_ensure(pmc_system *h, int K)
         h->sq_cap_K = K;
         h->sq_gen = gen;
     }
-    // the log ring: 64 windows' worth of steps between two folds (16 B per step, device + pinned host)
+    // the log ring: up to 1024 windows' worth of steps (two batches) between two folds (16 B per step, device + pinned host)
     int ring = 16384;
-    while (ring < 64 * K && ring < SQ_RING_MAX) ring *= 2;
+    while (ring < 1024 * K && ring < SQ_RING_MAX) ring *= 2;
     if (ring > h->sq_ring) {
         if (h->d_sq_log) (void)hipFree(h->d_sq_log);
         if (h->h_sq_log) (void)hipHostFree(h->h_sq_log);
