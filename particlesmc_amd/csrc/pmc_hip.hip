@@ -941,6 +941,7 @@ extern "C" int pmc_build_cells(pmc_system *h)
         // The reference's vectors grow as they must; the device rows are re-allocated with twice the capacity until the fullest
         // cell fits (found by tests/test_gpu_seq_fuzz.py: CellList's floor(Int, box / cell) can come out one short of box / rcut's -- box /
         // (box / 7) = 6.999... -- and the last slab of every dimension then folds onto the first: cells of 2, 4 and 8 x the mean)
+        bool headroom = false;
         for (int attempt = 0; ; attempt++) {
             hipLaunchKernelGGL(k_ref_cellvec, dim3(nblk(tot, 256)), dim3(256), 0, h->stream, N, h->d_cell_of, h->d_start_ref,
                                h->d_ids_ref, h->ncell_ref, h->d_cl_items, h->cl_cap, h->d_ccount, h->d_ref_err);
@@ -948,7 +949,10 @@ extern "C" int pmc_build_cells(pmc_system *h)
             int e = 0;
             HIPCHK(h, hipMemcpyAsync(&e, h->d_ref_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (!(e & 1)) break;
+            // (rows that had to grow get one doubling more than the fullest cell needs: the chain that follows moves particles
+            // into that cell too, and a row that overflows mid-chain ends the call with PMC_ERR_STATE)
+            if (!(e & 1) && (attempt == 0 || headroom)) break;
+            if (!(e & 1)) headroom = true;
             if (attempt >= 12 || (double)h->ncell_ref * 2.0 * h->cl_cap * sizeof(int) > 32e9) break;   // reported below
             HIPCHK(h, hipMemsetAsync(h->d_ref_err, 0, sizeof(int), h->stream));
             (void)hipFree(h->d_cl_items);
