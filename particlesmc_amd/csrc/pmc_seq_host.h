@@ -112,9 +112,11 @@ static int seq_ensure(pmc_system *h, int K)
         h->sq_cap_K = K;
         h->sq_gen = gen;
     }
-    // the log ring: up to 1024 windows' worth of steps (two batches) between two folds (16 B per step, device + pinned host)
+    // the log ring: up to 2048 windows' worth of steps (four batches) between two folds (16 B per step, device + pinned host)
     int ring = 16384;
-    while (ring < 1024 * K && ring < SQ_RING_MAX) ring *= 2;
+    long long ringx = 2048;                                              // (four batches of 512 rounds: see the pipelined order below)
+    if (const char *e = getenv("PMC_SEQ_RINGX")) ringx = atoll(e);       // (A/B of the batch length)
+    while (ring < ringx * K && ring < SQ_RING_MAX) ring *= 2;
     if (ring > h->sq_ring) {
         if (h->d_sq_log) (void)hipFree(h->d_sq_log);
         if (h->h_sq_log) (void)hipHostFree(h->h_sq_log);
@@ -517,7 +519,8 @@ static int sweep_sequential_fast_many(pmc_system **hs, int n, const pmc_move *po
     // (large windows only: N = 10^6 gains 3 %; with windows of 64 .. 512 a batch is a few hundred microseconds of copies and folds
     // per several milliseconds of rounds, and the shorter batches the lagging prefix asks for cost more than that -- 32 chains of
     // N = 4096 lost 12 %)
-    const bool pipe = (g.K >= 1024 || getenv("PMC_SEQ_PIPE")) && !getenv("PMC_SEQ_NOPIPE");
+    // (groups of chains as well, now that their ring holds four batches: 32 chains of N = 32768 +7 %, 128 of N = 4096 +3 %)
+    const bool pipe = (g.K >= 1024 || g.n > 1 || getenv("PMC_SEQ_PIPE")) && !getenv("PMC_SEQ_NOPIPE");
     rc = seq_group_enqueue(g);
     if (rc) return rc;
     g.rounds_folded = g.rounds_last;
