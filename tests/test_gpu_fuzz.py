@@ -149,7 +149,7 @@ def test_random_configuration_both_engines(gpu, case, monkeypatch):
             assert np.array_equal(g.species_ids(s_), o2.species_ids(s_))
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(FIRST, FIRST + max(12, NCASES // 3)))
 def test_random_operation_sequences(gpu, case):
     """Random interleavings of throughput sweeps, reference-order sweeps, per-move verbs, temperature changes and
     position/species round trips on ONE handle; after every operation the device state equals the oracle's."""
