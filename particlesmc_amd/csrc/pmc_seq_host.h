@@ -658,13 +658,15 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
     // wavefronts per chain: four split the pair loop and the two ordered sums of a step while the chains alone would leave SIMDs
     // idle; from a thousand chains on, one wavefront per chain fills the chip and wastes nothing on barriers (PMC_SEQ_WAVES: A/B)
-    int nw = (n <= 512) ? 4 : 1;
-    if (const char *e = getenv("PMC_SEQ_WAVES")) nw = (atoi(e) == 4) ? 4 : 1;
-    if (nw == 4 && seq_lds_layout(m, cap, nullptr, 4) > SQ_LDS_MAX) nw = 1;
+    // (measured, N = 216 LJ, 10^7 moves/s for 256 / 512 / 1000 / 2000 chains: four wavefronts 4.8 / 4.9 / 4.8 / 4.8, two
+    // 4.3 / 7.3 / 7.2 / 7.3, one 3.2 / 6.1 / 11.6 / 11.9 -- a team's ceiling falls with its width)
+    int nw = (n <= 320) ? 4 : (n <= 608 ? 2 : 1);
+    if (const char *e = getenv("PMC_SEQ_WAVES")) { nw = atoi(e); if (nw != 4 && nw != 2) nw = 1; }
+    if (nw > 1 && seq_lds_layout(m, cap, nullptr, nw) > SQ_LDS_MAX) nw = 1;
     const size_t lds = seq_lds_layout(m, cap, &s, nw);
     if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: the chain's state does not fit the LDS");
-    const void *kfn = (m->D == 3) ? (nw == 4 ? (const void *)k_sq_lds<3, 4> : (const void *)k_sq_lds<3, 1>)
-                                  : (nw == 4 ? (const void *)k_sq_lds<2, 4> : (const void *)k_sq_lds<2, 1>);
+    const void *kfn = (m->D == 3) ? (nw == 4 ? (const void *)k_sq_lds<3, 4> : nw == 2 ? (const void *)k_sq_lds<3, 2> : (const void *)k_sq_lds<3, 1>)
+                                  : (nw == 4 ? (const void *)k_sq_lds<2, 4> : nw == 2 ? (const void *)k_sq_lds<2, 2> : (const void *)k_sq_lds<2, 1>);
     HIPCHK(m, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<SqChain> tab((size_t)n);
     for (int r = 0; r < n; r++) {
@@ -690,12 +692,9 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     long long launches = 0;
     for (long long done = 0; done < total; done += chunk) {
         s.nsteps = std::min(chunk, total - done);
-        if (m->D == 3) {
-            if (nw == 4) hipLaunchKernelGGL((k_sq_lds<3, 4>), dim3(n), dim3(256), lds, m->stream, s);
-            else hipLaunchKernelGGL((k_sq_lds<3, 1>), dim3(n), dim3(64), lds, m->stream, s);
-        } else {
-            if (nw == 4) hipLaunchKernelGGL((k_sq_lds<2, 4>), dim3(n), dim3(256), lds, m->stream, s);
-            else hipLaunchKernelGGL((k_sq_lds<2, 1>), dim3(n), dim3(64), lds, m->stream, s);
+        {
+            void *kargs[1] = {(void *)&s};
+            HIPCHK(m, hipLaunchKernel(kfn, dim3(n), dim3(nw * 64), kargs, lds, m->stream));
         }
         HIPCHK(m, hipGetLastError());
         launches++;
