@@ -1056,7 +1056,9 @@ __device__ __forceinline__ double sql_dist2(const SqLdsArgs &s, const double *xi
 // compute_energy_particle at xa (and xb when BOTH) over the neighbourhood of cell c; species spa at xa, spb at xb; `other`
 // (a swap partner, or -1) is seen with species sp_other at xb (src/moves.jl:159-167).  The trips of 64 candidates are dealt to
 // the NW wavefronts; the two sums are then taken in iterator order by wavefront 0 (ea) and wavefront 1 (eb).
-template <int D, bool BOTH, int NW>
+// KIND: the kind every pair model of the system has (the potential is then compiled in: the kernel of a Lennard-Jones or an
+// integer-power soft-sphere system carries no other potential), or 4: read from the model, pair by pair.
+template <int D, bool BOTH, int NW, int KIND = 4>
 __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v, int c, int i, int spa, int spb, int other, int sp_other,
                                          const double *xa, const double *xb, double &ea, double &eb)
 {
@@ -1082,11 +1084,11 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
                 const int sj = (S > 1) ? (int)v.species[j] : 0;
                 const DevModel &ma = s.a.models[spa * S + sj];
                 const double r2a = sql_dist2<D>(s, xa, xj);
-                if (!(r2a > ma.rcut2)) ua = dev_potential_dyn(r2a, ma);
+                if (!(r2a > ma.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2a, ma) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, ma));
                 if (BOTH) {
                     const DevModel &mb = s.a.models[spb * S + (j == other ? sp_other : sj)];
                     const double r2b = sql_dist2<D>(s, xb, xj);
-                    if (!(r2b > mb.rcut2)) ub = dev_potential_dyn(r2b, mb);
+                    if (!(r2b > mb.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2b, mb) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2b, mb));
                 }
             }
         }
@@ -1166,7 +1168,7 @@ __device__ __forceinline__ void sql_row_move(const SqLdsArgs &s, const SqLdsView
     __syncthreads();
 }
 
-template <int D, int NW>
+template <int D, int NW, int KIND = 4>
 __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sql_smem[];
@@ -1259,10 +1261,10 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                 const int spi = (S > 1) ? (int)v.species[i] : 0;
                 double e1, e2, dummy;
                 if (c1 == c0) {
-                    sql_pass<D, true, NW>(s, v, c0, i, spi, spi, -1, 0, x, xn, e1, e2);
+                    sql_pass<D, true, NW, KIND>(s, v, c0, i, spi, spi, -1, 0, x, xn, e1, e2);
                 } else {
-                    sql_pass<D, false, NW>(s, v, c0, i, spi, spi, -1, 0, x, x, e1, dummy);
-                    sql_pass<D, false, NW>(s, v, c1, i, spi, spi, -1, 0, xn, xn, e2, dummy);
+                    sql_pass<D, false, NW, KIND>(s, v, c0, i, spi, spi, -1, 0, x, x, e1, dummy);
+                    sql_pass<D, false, NW, KIND>(s, v, c1, i, spi, spi, -1, 0, xn, xn, e2, dummy);
                 }
                 double de = 0.0;
                 if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }           // src/moves.jl:13-18
@@ -1292,8 +1294,8 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                     for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
                     const int spi = v.species[i], spj = v.species[j];
                     double e1i, e2i, e1j, e2j;
-                    sql_pass<D, true, NW>(s, v, s.empty ? 0 : (int)v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
-                    sql_pass<D, true, NW>(s, v, s.empty ? 0 : (int)v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
+                    sql_pass<D, true, NW, KIND>(s, v, s.empty ? 0 : (int)v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
+                    sql_pass<D, true, NW, KIND>(s, v, s.empty ? 0 : (int)v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
                     const double e1 = e1i + e1j, e2 = e2i + e2j;
                     double de = 0.0;
                     if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }

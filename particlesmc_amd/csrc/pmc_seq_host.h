@@ -665,8 +665,16 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     if (nw > 1 && seq_lds_layout(m, cap, nullptr, nw) > SQ_LDS_MAX) nw = 1;
     const size_t lds = seq_lds_layout(m, cap, &s, nw);
     if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: the chain's state does not fit the LDS");
-    const void *kfn = (m->D == 3) ? (nw == 4 ? (const void *)k_sq_lds<3, 4> : nw == 2 ? (const void *)k_sq_lds<3, 2> : (const void *)k_sq_lds<3, 1>)
-                                  : (nw == 4 ? (const void *)k_sq_lds<2, 4> : nw == 2 ? (const void *)k_sq_lds<2, 2> : (const void *)k_sq_lds<2, 1>);
+    // the kernel of a system whose pair models are all Lennard-Jones, or all soft spheres of an even exponent, has that potential
+    // compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
+    int ukind = m->models.empty() ? 4 : (int)m->models[0].kind;
+    for (const pmc_pair_model &pm : m->models) if ((int)pm.kind != ukind) ukind = 4;
+    if (ukind > 1 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
+    const void *kfn = nullptr;
+#define SQ_LDS_PICK(DD, WW) (ukind == 0 ? (const void *)k_sq_lds<DD, WW, 0> : ukind == 1 ? (const void *)k_sq_lds<DD, WW, 1> : (const void *)k_sq_lds<DD, WW, 4>)
+    if (m->D == 3) kfn = (nw == 4) ? SQ_LDS_PICK(3, 4) : (nw == 2) ? SQ_LDS_PICK(3, 2) : SQ_LDS_PICK(3, 1);
+    else kfn = (nw == 4) ? SQ_LDS_PICK(2, 4) : (nw == 2) ? SQ_LDS_PICK(2, 2) : SQ_LDS_PICK(2, 1);
+#undef SQ_LDS_PICK
     HIPCHK(m, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<SqChain> tab((size_t)n);
     for (int r = 0; r < n; r++) {
