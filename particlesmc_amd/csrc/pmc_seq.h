@@ -382,7 +382,8 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
 
 // compute_energy_particle (src/atoms.jl:81-88) of particle i, species spi, at xa (and, when BOTH, at xb over the same
 // neighbour sequence) for a particle whose iterator runs over the neighbourhood of cell c
-template <int D, bool BOTH>
+// (KIND: the one kind of every pair model of the system, compiled in, or 4: read per pair -- as for k_sq_lds below)
+template <int D, bool BOTH, int KIND = 4>
 __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, const double *xa, const double *xb, int *lds_ids,
                                         double &ea, double &eb, int w)
 {
@@ -414,10 +415,10 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
             if (j[u] >= 0 && j[u] != i) {                                        // src/atoms.jl:68
                 const DevModel &m = a.models[spi * a.S + sj[u]];
                 const double r2a = sq_dist2<D>(s, xa, xj[u]);
-                if (!(r2a > m.rcut2)) ua = dev_potential_dyn(r2a, m);          // src/atoms.jl:72-73
+                if (!(r2a > m.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2a, m) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, m));          // src/atoms.jl:72-73
                 if (BOTH) {
                     const double r2b = sq_dist2<D>(s, xb, xj[u]);
-                    if (!(r2b > m.rcut2)) ub = dev_potential_dyn(r2b, m);
+                    if (!(r2b > m.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2b, m) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2b, m));
                 }
             }
             if (na > SQ_TERMS || nb > SQ_TERMS) {                // the next 64 terms might not fit: sum down, in order
@@ -435,7 +436,7 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
 
 // the two energies of one particle of a DiscreteSwap (src/moves.jl:159-167): before (species sp1) and after the exchange
 // (species sp2, and the partner `other`, if it is a neighbour, with the species sp1 it then has)
-template <int D>
+template <int D, int KIND = 4>
 __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int sp1, int sp2, int other, const double *xi,
                                              int *lds_ids, double &e_before, double &e_after, int w)
 {
@@ -467,9 +468,9 @@ __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int 
             if (j[u] >= 0 && j[u] != i) {
                 const double r2 = sq_dist2<D>(s, xi, xj[u]);
                 const DevModel &m1 = a.models[sp1 * a.S + sj[u]];
-                if (!(r2 > m1.rcut2)) ua = dev_potential_dyn(r2, m1);
+                if (!(r2 > m1.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2, m1) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m1));
                 const DevModel &m2 = a.models[sp2 * a.S + (j[u] == other ? sp1 : sj[u])];
-                if (!(r2 > m2.rcut2)) ub = dev_potential_dyn(r2, m2);
+                if (!(r2 > m2.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2, m2) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m2));
             }
             if (na > SQ_TERMS || nb > SQ_TERMS) {
                 sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
@@ -490,7 +491,7 @@ __device__ __forceinline__ bool sq_bits_differ(double p, double q)
 }
 
 // ---- one step, evaluated against the current state (nothing is written but the slot) --------------------------------------
-template <int D>
+template <int D, int KIND = 4>
 __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 {
     const RefArgs &a = s.a;
@@ -512,11 +513,11 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
         const int c2 = sq_cell_of<D>(a, xr);
         const int spi = a.S > 1 ? a.species[i] : 0;
         if (c1 == c0) {
-            sq_pass<D, true>(s, c0, i, spi, x, xn, lds_ids, e1, e2, w);
+            sq_pass<D, true, KIND>(s, c0, i, spi, x, xn, lds_ids, e1, e2, w);
         } else {
             double dummy;
-            sq_pass<D, false>(s, c0, i, spi, x, x, lds_ids, e1, dummy, w);
-            sq_pass<D, false>(s, c1, i, spi, xn, xn, lds_ids, e2, dummy, w);
+            sq_pass<D, false, KIND>(s, c0, i, spi, x, x, lds_ids, e1, dummy, w);
+            sq_pass<D, false, KIND>(s, c1, i, spi, xn, xn, lds_ids, e2, dummy, w);
             flags |= SQF_CROSSED;
         }
         const bool ok = sl.lnu < -(e2 - e1) / a.temperature;    // src/utils.jl:8-10 (forward / backward log q cancel)
@@ -538,8 +539,8 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
         for (int q = 0; q < D; q++) { xi[q] = sl.x[q]; xj[q] = sl.xn[q]; }
         const int spi = a.species[i], spj = a.species[j];
         double e1i, e2i, e1j, e2j;
-        sq_pass_swap<D>(s, sl.c0, i, spi, spj, j, xi, lds_ids, e1i, e2i, w);
-        sq_pass_swap<D>(s, sl.c1, j, spj, spi, i, xj, lds_ids, e1j, e2j, w);
+        sq_pass_swap<D, KIND>(s, sl.c0, i, spi, spj, j, xi, lds_ids, e1i, e2i, w);
+        sq_pass_swap<D, KIND>(s, sl.c1, j, spj, spi, i, xj, lds_ids, e1j, e2j, w);
         e1 = e1i + e1j;                                 // src/moves.jl:166
         e2 = e2i + e2j;
         const bool ok = sl.lnu < -(e2 - e1) / a.temperature;
@@ -563,14 +564,14 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 }
 
 // ---- round, third launch: every pending step finds the earlier steps it could interact with and is evaluated --------------------------------------
-template <int D>
+template <int D, int KIND = 4>
 __global__ __launch_bounds__(64) void k_sq_round_a(const SqArgs *__restrict__ tab)
 {
     const SqArgs &s = tab[blockIdx.y];
     extern __shared__ int sq_lds[];
     const int b = blockIdx.x;
     if (b < s.ctl->nslots) {
-        if (!(s.dbg & 4)) sq_eval<D>(s, b, sq_lds);
+        if (!(s.dbg & 4)) sq_eval<D, KIND>(s, b, sq_lds);
     }
 }
 

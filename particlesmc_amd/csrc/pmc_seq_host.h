@@ -193,6 +193,7 @@ struct SeqGroup {
     SqArgs *d_tab = nullptr;          // device table of the chains' arguments
     int n = 0, K = 0;
     size_t lds = 0, lds_fill = 0;
+    const void *k_eval = nullptr;     // k_sq_round_a for the group's dimension and model kind
     long long rounds_last = 0, rounds_folded = 0;     // rounds of the batch enqueued last / of the batch being folded
     hipGraphExec_t graph = nullptr;   // SQ_GRAPH_ROUNDS rounds, captured once per call (a group of one caches it on the handle)
     bool own_graph = false;
@@ -209,15 +210,17 @@ static void seq_launch_round(const SeqGroup &g)
 {
     pmc_system *h = g.lead;
     const int K = g.K, n = g.n;
+    const SqArgs *tab = g.d_tab;
+    void *kargs[1] = {(void *)&tab};
     if (h->D == 3) {
         hipLaunchKernelGGL(k_sq_fill<3>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
         hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
-        hipLaunchKernelGGL(k_sq_round_a<3>, dim3(K, n), dim3(64), g.lds, h->stream, g.d_tab);
+        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64), kargs, g.lds, h->stream);
         hipLaunchKernelGGL(k_sq_commit<3>, dim3(K, n), dim3(64), 0, h->stream, g.d_tab);
     } else {
         hipLaunchKernelGGL(k_sq_fill<2>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
         hipLaunchKernelGGL(k_sq_prep<2>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
-        hipLaunchKernelGGL(k_sq_round_a<2>, dim3(K, n), dim3(64), g.lds, h->stream, g.d_tab);
+        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64), kargs, g.lds, h->stream);
         hipLaunchKernelGGL(k_sq_commit<2>, dim3(K, n), dim3(64), 0, h->stream, g.d_tab);
     }
 }
@@ -330,9 +333,21 @@ static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *
     for (int k = 0; k < n; k++) g.runs[k].s.ids_cap = ids_cap;     // one LDS layout for the launch
     g.lds = (size_t)((ids_cap + 3) & ~3) * sizeof(int) + 2 * (size_t)SQ_TERMS_BUF * sizeof(double);   // ids + the two term buffers
     if (g.lds > 160 * 1024 - 256) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
+    {
+        // the evaluation kernel of a group whose chains all have pair models of ONE kind -- Lennard-Jones, or soft spheres of an even
+        // exponent -- has that potential compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
+        int ukind = -1;
+        for (int k = 0; k < n; k++)
+            for (const pmc_pair_model &pm : hs[k]->models) {
+                if (ukind == -1) ukind = (int)pm.kind;
+                else if ((int)pm.kind != ukind) ukind = 4;
+            }
+        if (ukind < 0 || ukind > 1 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
+        if (m->D == 3) g.k_eval = (ukind == 0) ? (const void *)k_sq_round_a<3, 0> : (ukind == 1) ? (const void *)k_sq_round_a<3, 1> : (const void *)k_sq_round_a<3, 4>;
+        else g.k_eval = (ukind == 0) ? (const void *)k_sq_round_a<2, 0> : (ukind == 1) ? (const void *)k_sq_round_a<2, 1> : (const void *)k_sq_round_a<2, 4>;
+    }
     if (g.lds > 48 * 1024) {
-        if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_round_a<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
-        else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_round_a<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        HIPCHK(m, hipFuncSetAttribute(g.k_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
     }
     g.lds_fill = (size_t)8 * g.K * sizeof(int);            // keys[4 K] + vals[4 K]
     if (g.lds_fill > 48 * 1024) {
