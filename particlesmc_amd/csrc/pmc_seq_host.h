@@ -334,17 +334,18 @@ static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *
     g.lds = (size_t)((ids_cap + 3) & ~3) * sizeof(int) + 2 * (size_t)SQ_TERMS_BUF * sizeof(double);   // ids + the two term buffers
     if (g.lds > 160 * 1024 - 256) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
     {
-        // the evaluation kernel of a group whose chains all have pair models of ONE kind -- Lennard-Jones, or soft spheres of an even
-        // exponent -- has that potential compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
+        // the evaluation kernel of a group whose chains all have pair models of ONE kind has that potential compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
         int ukind = -1;
         for (int k = 0; k < n; k++)
             for (const pmc_pair_model &pm : hs[k]->models) {
                 if (ukind == -1) ukind = (int)pm.kind;
                 else if ((int)pm.kind != ukind) ukind = 4;
             }
-        if (ukind < 0 || ukind > 1 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
-        if (m->D == 3) g.k_eval = (ukind == 0) ? (const void *)k_sq_round_a<3, 0> : (ukind == 1) ? (const void *)k_sq_round_a<3, 1> : (const void *)k_sq_round_a<3, 4>;
-        else g.k_eval = (ukind == 0) ? (const void *)k_sq_round_a<2, 0> : (ukind == 1) ? (const void *)k_sq_round_a<2, 1> : (const void *)k_sq_round_a<2, 4>;
+        if (ukind < 0 || ukind > 3 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
+#define SQ_EVAL_PICK(DD) (ukind == 0 ? (const void *)k_sq_round_a<DD, 0> : ukind == 1 ? (const void *)k_sq_round_a<DD, 1> : \
+                          ukind == 2 ? (const void *)k_sq_round_a<DD, 2> : ukind == 3 ? (const void *)k_sq_round_a<DD, 3> : (const void *)k_sq_round_a<DD, 4>)
+        g.k_eval = (m->D == 3) ? SQ_EVAL_PICK(3) : SQ_EVAL_PICK(2);
+#undef SQ_EVAL_PICK
     }
     if (g.lds > 48 * 1024) {
         HIPCHK(m, hipFuncSetAttribute(g.k_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
@@ -680,13 +681,13 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     if (nw > 1 && seq_lds_layout(m, cap, nullptr, nw) > SQ_LDS_MAX) nw = 1;
     const size_t lds = seq_lds_layout(m, cap, &s, nw);
     if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: the chain's state does not fit the LDS");
-    // the kernel of a system whose pair models are all Lennard-Jones, or all soft spheres of an even exponent, has that potential
-    // compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
+    // the kernel of a system whose pair models are all of one kind has that potential compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
     int ukind = m->models.empty() ? 4 : (int)m->models[0].kind;
     for (const pmc_pair_model &pm : m->models) if ((int)pm.kind != ukind) ukind = 4;
-    if (ukind > 1 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
+    if (ukind > 3 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
     const void *kfn = nullptr;
-#define SQ_LDS_PICK(DD, WW) (ukind == 0 ? (const void *)k_sq_lds<DD, WW, 0> : ukind == 1 ? (const void *)k_sq_lds<DD, WW, 1> : (const void *)k_sq_lds<DD, WW, 4>)
+#define SQ_LDS_PICK(DD, WW) (ukind == 0 ? (const void *)k_sq_lds<DD, WW, 0> : ukind == 1 ? (const void *)k_sq_lds<DD, WW, 1> : \
+                             ukind == 2 ? (const void *)k_sq_lds<DD, WW, 2> : ukind == 3 ? (const void *)k_sq_lds<DD, WW, 3> : (const void *)k_sq_lds<DD, WW, 4>)
     if (m->D == 3) kfn = (nw == 4) ? SQ_LDS_PICK(3, 4) : (nw == 2) ? SQ_LDS_PICK(3, 2) : SQ_LDS_PICK(3, 1);
     else kfn = (nw == 4) ? SQ_LDS_PICK(2, 4) : (nw == 2) ? SQ_LDS_PICK(2, 2) : SQ_LDS_PICK(2, 1);
 #undef SQ_LDS_PICK
