@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import platform
 import socket
 import subprocess
 import sys
@@ -94,13 +95,40 @@ def _cpu_worker(args):
     return nsteps, time.perf_counter() - t0
 
 
-def cpu_baseline_multicore(pos, rho, single_rate, max_cores=32):
-    """one independent chain per host core (reference `parallel=true`) from the same state,
-    bounded to `max_cores` processes of ~10 s each; aggregate attempted moves/s."""
+def host_cpu_model():
+    """`lscpu`'s model string of the host the CPU legs run on ("print nproc / lscpu model and core count")."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline_multicore(pos, rho, single_rate, max_cores=None):
+    """BASELINE.md section 4 (b), SURVEY 8(d): one independent chain per host core (the reference's `parallel = true`,
+    src/ParticlesMC.jl:164,246) from the same state, on ALL host cores the process may use (os.sched_getaffinity) unless
+    `max_cores` / --cpu-cores caps it (the line then says so); ~5 s of steps per chain; aggregate attempted moves/s over the
+    slowest chain's time."""
     import multiprocessing as mp
     import tempfile
-    cores = max(1, min(max_cores, os.cpu_count() or 1))
-    nsteps = int(max(20000, single_rate * 2.5))    # chains slow each other down ~4x (shared caches, DRAM)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    # every chain holds its own copy of the state and lists (~0.2 GB at N = 10^6): never more chains than memory allows
+    try:
+        mem_gb = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+    except (ValueError, OSError):
+        mem_gb = 64.0
+    mem_cap = max(1, int(0.5 * mem_gb / (0.25 * max(1.0, len(pos) / 1e6))))
+    cores = max(1, min(avail, mem_cap, max_cores or avail))
+    cap_reason = None
+    if cores < avail:
+        cap_reason = "--cpu-cores" if (max_cores and cores == max_cores) else "host memory"
+    # chains slow each other down (shared caches, DRAM, SMT siblings): ~4x at 32 chains, more on every hardware thread
+    nsteps = int(max(20000, single_rate * (2.5 if cores <= 32 else 1.0)))
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "state.npy")
@@ -111,8 +139,9 @@ def cpu_baseline_multicore(pos, rho, single_rate, max_cores=32):
         wall = time.perf_counter() - t0
     tmax = max(r[1] for r in res)
     return {"value": sum(r[0] for r in res) / tmax, "unit": "attempted moves/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} independent chains (one process per core), {nsteps} sequential steps each from the "
-                      f"same state; slowest chain {tmax:.1f} s, {wall:.1f} s including the builds"}
+            "host_cores_available": avail, "cores_capped_by": cap_reason, "cpu_model": host_cpu_model(),
+            "sample": f"{cores} independent chains (one process per hardware thread the host offers: {avail}), {nsteps} sequential "
+                      f"steps each from the same state; slowest chain {tmax:.1f} s, {wall:.1f} s including the builds"}
 
 
 # ---- launcher: `bench.py --gpus N` started plainly ------------------------------------------
@@ -166,6 +195,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lattice", type=int, default=100, help="lattice sites per side (N = lattice^3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (baseline and move efficiency)")
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="cap of the multi-core CPU leg (0: every hardware thread the host offers, SURVEY 8d)")
     ap.add_argument("--equilibrate", type=int, default=1000,
                     help="untimed sweeps that melt the jittered lattice into the rho = 1, T = 1 liquid before the warm-up "
                          "(0: time the first sweeps from the lattice instead, as rounds 1-2 did; with > 0 that figure is still "
@@ -768,6 +799,22 @@ def run_rank(args):
             "by_rounds": {str(m): legs[m] for m in sorted(legs)},
             "roofline": roofline_objects(N, timed_steps, st, avg_launch_s, moves_per_launch, ncell_ref),
         }
+        # SURVEY 8(d)'s two HBM figures as first-class siblings of `roofline` (they also stay inside it): the contract figure
+        # B_alg x moves / time -- not a bound of this kernel: a staged neighbourhood serves every slot of a visit from LDS -- and
+        # the bytes rocprofv3 measured for the same launch
+        rf = out["roofline"]
+        out["roofline_hbm_contract"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                        "achieved": rf["contract_hbm_equiv"]["GBps_equivalent"],
+                                        "frac": rf["contract_hbm_equiv"]["over_hbm_peak"],
+                                        "algorithmic_bytes_per_move": rf["contract_hbm_equiv"]["algorithmic_bytes_per_move"],
+                                        "note": rf["contract_hbm_equiv"]["note"]}
+        if rf.get("traffic") is not None:
+            out["hbm_measured"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "bytes_per_launch": rf["traffic"],
+                                   "achieved": rf["traffic"] / avg_launch_s / 1e9, "frac": rf["hbm_measured_frac"]["value"],
+                                   "source": rf.get("traffic_source")}
+        # the like-for-like schedule (m = 1: one grid shift per sweep, the library's default) next to the headline's
+        if 1 in legs:
+            out["value_m1"] = legs[1]["value"]
         if by_call is not None:
             out["by_call_size"] = {"unit": "attempted moves/s over 64 sweeps issued as calls of 1 / 4 / 64 sweeps (rank 0's clock)",
                                    "by_rounds": by_call}
@@ -796,10 +843,11 @@ def run_rank(args):
         if ngpus == 1 and not args.no_cpu and not stub:
             out["cpu_baseline"] = cpu_baseline(head_state, sp, rho, 3_000_000)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"]["cpu_model"] = host_cpu_model()
             if isinstance(out.get("reference_order_chain"), dict) and "value" in out["reference_order_chain"]:
                 out["reference_order_chain"]["over_cpu_baseline"] = out["reference_order_chain"]["value"] / out["cpu_baseline"]["value"]
             try:
-                out["cpu_baseline_multicore"] = cpu_baseline_multicore(head_state, rho, out["cpu_baseline"]["value"])
+                out["cpu_baseline_multicore"] = cpu_baseline_multicore(head_state, rho, out["cpu_baseline"]["value"], args.cpu_cores or None)
             except Exception as exc:      # the single-core figure is the contract; this one is a courtesy
                 out["cpu_baseline_multicore"] = {"error": repr(exc)}
             try:

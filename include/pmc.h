@@ -231,13 +231,21 @@ int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
  * system (positions, species, cell rows, SpeciesList: up to 160 KB) lives in LDS and one wavefront walks the chain with no
  * global-memory traffic; pmc_sweep_many runs any number of such chains of one shape in one launch (the reference's own
  * workloads: benchmark/particles_benchmarks.jl:10-28, N = 216; test/ss142d.jl:8-21, 100 chains of N = 8).  engine 0 (default):
- * 3 for LinkedList / CellList systems of at most 7 cells per side whose state fits 64 KB, else 2; 1 for EmptyList / VerletList
- * and for swap moves between a species and itself.  window: pending steps per round of engine 2 (0: chosen from the cell
+ * 3 for LinkedList / CellList / EmptyList systems of at most 7 cells per side (EmptyList: any) whose state fits 64 KB of LDS,
+ * else 2 for LinkedList / CellList; 1 for VerletList, for EmptyList systems too large for the LDS and for swap moves between a
+ * species and itself.  window: pending steps per round of engine 2 (0: chosen from the cell
  * count; at most 4096). */
 int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window);
 /* diagnostics of the last PMC_SEQUENTIAL call that ran engine 2: out[0] rounds, out[1] step evaluations, out[2] window,
- * out[3] steps folded into system.energy */
+ * out[3] steps of that call folded into system.energy (= nsweeps * N when it ended well) */
 int pmc_sequential_info(pmc_system *h, int64_t *out);
+
+/* Fault injection for the library's own tests (no reference counterpart; never needed by a host).  what =
+ * PMC_INJECT_STARVED_LAUNCH: the next fused checkerboard launch of this handle is reported as starved although it ran to the
+ * end -- the path a lost completion flag takes: PMC_ERR_STATE, the chain invalid, the handle switched to the single
+ * dispatch-order-independent ticket counter.  One shot; a handle property, so nothing in the environment can trigger it. */
+#define PMC_INJECT_STARVED_LAUNCH 1
+int pmc_debug_inject(pmc_system *h, int32_t what);
 
 /* The same sweep split in two so that several handles (chains with parallel=true,
  * src/ParticlesMC.jl:164,246; replicas of a tempering ladder) run concurrently on one GPU: begin

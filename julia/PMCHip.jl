@@ -144,8 +144,11 @@ struct HIPMetropolis <: Arianna.Algorithm
     pool::Vector{CMove}; mode::Int32            # 0 = sequential (reference chain), 1 = checkerboard (throughput)
     sweeps_per_step::Int64                      # sweeps per scheduler tick: one library call (one sync, one counter fold) per tick,
 end                                             # so coarse schedulers should tick in blocks (INTEGRATION.md section 4)
-# default: four passes per tick, whatever the handle's schedule parameter m (a pass never spans calls: include/pmc.h)
-HIPMetropolis(pool, mode; rounds=1) = HIPMetropolis(pool, mode, 4 * rounds)
+# default: ONE sweep of N attempted moves per scheduler tick, as the reference's Metropolis entry (sweepstep = length(chains[1]),
+# src/ParticlesMC.jl:246) -- callbacks and schedulers fire at the reference's cadence.  Coarser ticks are an explicit opt-in:
+# HIPMetropolis(pool, 1; sweeps_per_step = 4m) lets a pass of m sweeps per grid shift (pmc_set_rounds) stay inside one call
+# (a pass never spans calls: include/pmc.h), at the price of a tick that is 4m sweeps long.
+HIPMetropolis(pool, mode; sweeps_per_step=1) = HIPMetropolis(pool, mode, sweeps_per_step)
 
 # how mode = 0 runs: 0 the library's choice, 1 one wavefront, 2 speculative windows, 3 the chain's state in LDS (include/pmc.h)
 set_sequential_engine!(system, engine, window=0) =
@@ -163,7 +166,7 @@ set_images!(system, img::Vector{Int32}) =
 cmove(m::Arianna.Move{<:ParticlesMC.Displacement}) = CMove(0, (0, 0), m.weight, m.parameters.σ)
 cmove(m::Arianna.Move{<:ParticlesMC.DiscreteSwap}) = CMove(1, Int32.(m.action.species), m.weight, 0.0)
 
-function Arianna.make_step!(sim::Arianna.Simulation, alg::HIPMetropolis)          # one scheduler tick = one sweep
+function Arianna.make_step!(sim::Arianna.Simulation, alg::HIPMetropolis)          # one scheduler tick = alg.sweeps_per_step sweeps (default 1)
     for system in sim.chains                                                      # parallel=true: Threads.@threads, one handle per chain
         st = Ref{Stats}()
         handover!(system)

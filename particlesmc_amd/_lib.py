@@ -104,6 +104,7 @@ SYMBOLS = {
     "pmc_energy_particles_exact": (C.c_int, [_h, _dp]),
     "pmc_delta_e": (C.c_int, [_h, C.c_int64, _lp, _dp, _dp, _dp]),
     "pmc_grid": (C.c_int, [_h, _lp, _dp]),
+    "pmc_debug_inject": (C.c_int, [_h, C.c_int32]),
     "pmc_set_rounds": (C.c_int, [_h, C.c_int32]),
     "pmc_get_rounds": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pmc_set_sequential_engine": (C.c_int, [_h, C.c_int32, C.c_int32]),

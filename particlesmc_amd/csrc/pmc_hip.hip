@@ -139,7 +139,7 @@ struct pmc_system {
     // fast reference-order engine (pmc_seq.h): speculative windows over the sequential chain
     int seq_engine = 0;          // 0 auto, 1 the one-wavefront loop (k_ref_ops), 2 speculative windows
     int seq_window = 0;          // window slots (0: from the cell count)
-    bool rows_own = false;       // d_cl_items was allocated for a LinkedList (the rows the fast engine reads)
+    int rows_min_cap = 0;        // row capacity a LinkedList's rows must at least have (doubled when a row overflowed mid-chain)
     SqSlot *d_sq_slots[2] = {nullptr, nullptr};
     SqGen *d_sq_gen = nullptr;
     unsigned long long *d_sq_M = nullptr, *d_sq_cp = nullptr;
@@ -149,6 +149,8 @@ struct pmc_system {
     int sq_cap_K = 0, sq_gen = 0;   // window the per-slot buffers are allocated for; steps the ring of random parts holds
     SqCtl *d_sq_ctl = nullptr, *h_sq_ctl = nullptr;
     SqCtl sq_last{};             // control block of the last fast sequential call (diagnostics: rounds, evaluations)
+    long long sq_last_steps = 0; // ... and the steps of that call the host folded into system.energy (all of them when it ended well)
+    bool inject_starve = false;  // pmc_debug_inject(PMC_INJECT_STARVED_LAUNCH): the next fused launch is declared starved (one shot)
     hipGraphExec_t sq_graph = nullptr;   // SQ_GRAPH_ROUNDS rounds of the windows, captured for sq_graph_args / sq_graph_K
     SqArgs sq_graph_args;
     int sq_graph_K = 0;
@@ -833,6 +835,17 @@ static int ref_list_errors(pmc_system *h)
     HIPCHK(h, hipMemcpy(&e, h->d_ref_err, sizeof(int), hipMemcpyDeviceToHost));
     if (e) {
         (void)hipMemset(h->d_ref_err, 0, sizeof(int));
+        if ((e & 4) && h->list_type == 1) {
+            // a LinkedList's row (the copy of its chains the fast sequential engines read: ref_relink) was full when the literal
+            // loop moved a particle into its cell.  head / list / cs -- the list itself -- are right and the move stands; the
+            // rows are not, so they are dropped: the next fast sequential call re-creates them FROM THE CHAINS (never from the
+            // positions: moves have shaped the chains' order, seq_alloc_rows) with twice the capacity.  Not an error of the call.
+            if (h->d_cl_items) (void)hipFree(h->d_cl_items);
+            h->d_cl_items = nullptr;
+            h->rows_min_cap = std::max(h->rows_min_cap, 2 * h->cl_cap);
+            h->cl_cap = 0;
+            if (e == 4) return PMC_OK;
+        }
         h->cells_built = false;
         return fail(h, PMC_ERR_UNSUPPORTED, (e & 2) ? "VerletList: a neighbour vector exceeded its device capacity"
                                                    : "CellList: a cell vector exceeded its device capacity");
@@ -960,8 +973,10 @@ extern "C" int pmc_build_cells(pmc_system *h)
             h->cl_cap *= 2;
             HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * h->cl_cap * sizeof(int)));
         }
-    } else if (h->list_type == 1 && h->rows_own) {
-        // LinkedList rows of the fast sequential engine (pmc_seq.h): the chain of a cell read backwards = ids ascending
+    } else if (h->list_type == 1 && h->d_cl_items) {
+        // LinkedList rows of the fast sequential engine (pmc_seq.h): the chain of a cell read backwards = ids ascending.  Whenever
+        // rows exist they are rebuilt here -- also rows a CellList / VerletList allocated before the handle was switched back to
+        // LinkedList (pmc_set_list_type): ref_relink edits them and the fast engines read them, so they are never left stale
         rc = seq_build_rows(h);
         if (rc) return rc;
     }
@@ -1223,7 +1238,7 @@ static int ref_op_launch(pmc_system *h, RefOp &o)
     h->mc_binned = false;
     h->e_fix_valid = false;
     h->img_valid = false;
-    return h->list_type >= 2 ? ref_list_errors(h) : PMC_OK;
+    return (h->list_type >= 2 || h->d_cl_items) ? ref_list_errors(h) : PMC_OK;
 }
 
 extern "C" int pmc_displacement_perform(pmc_system *h, int64_t i, const double *delta, double *e1, double *e2,
@@ -1646,8 +1661,10 @@ static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
         return fail(h, PMC_ERR_UNSUPPORTED, "a cell holds more particles than the LDS staging capacity (that cell's slots were "
                                             "skipped; moves accepted in other cells are kept and the energy is recomputed on the next call)");
     bool starved = (st[17] & 2ull) != 0;
-    if (!starved && h->ticket_lanes != 1)
-        if (const char *e = getenv("PMC_TEST_STARVE")) starved = (e[0] == '1');   // test hook: take the fallback after a good launch
+    if (h->inject_starve) {          // fault injection (pmc_debug_inject): take the fallback after a good launch
+        h->inject_starve = false;
+        if (h->ticket_lanes != 1) starved = true;
+    }
     if (starved)
     {
         // the eight-counter ticket scheme assumes in-order round-robin dispatch to the XCDs for its progress argument (DESIGN.md
@@ -1660,6 +1677,14 @@ static int check_kernel_flags(pmc_system *h, const unsigned long long *st)
                                       "sweep: the chain is invalid; upload the configuration again -- the handle now draws its "
                                       "workgroup tickets from the single, dispatch-order-independent counter)");
     }
+    return PMC_OK;
+}
+
+extern "C" int pmc_debug_inject(pmc_system *h, int32_t what)
+{
+    if (!h) return fail(h, PMC_ERR_BADARG, "pmc_debug_inject: null handle");
+    if (what != PMC_INJECT_STARVED_LAUNCH) return fail(h, PMC_ERR_BADARG, "pmc_debug_inject: unknown fault");
+    h->inject_starve = true;
     return PMC_OK;
 }
 
@@ -1798,7 +1823,7 @@ extern "C" int pmc_sequential_info(pmc_system *h, int64_t *out)
     out[0] = (int64_t)h->sq_last.rounds;
     out[1] = (int64_t)h->sq_last.evals;
     out[2] = (int64_t)seq_window(h);
-    out[3] = (int64_t)(h->sq_last.gend - h->sq_last.next == 0 ? h->sq_last.prefix : 0);
+    out[3] = (int64_t)h->sq_last_steps;
     return PMC_OK;
 }
 

@@ -632,11 +632,9 @@ __device__ __forceinline__ void sq_row_append(const SqArgs &s, int c, int i)
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void k_sq_commit(const SqArgs *__restrict__ tab)
+__device__ __forceinline__ void sq_commit_wave(const SqArgs &s, const int w)
 {
-    const SqArgs &s = tab[blockIdx.y];
     const RefArgs &a = s.a;
-    const int w = blockIdx.x;
     const int lane = wave_lane();
     SqCtl *ctl = s.ctl;
     if (w >= ctl->nslots) return;
@@ -697,13 +695,20 @@ __global__ __launch_bounds__(64) void k_sq_commit(const SqArgs *__restrict__ tab
     }
 }
 
+template <int D>
+__global__ __launch_bounds__(64) void k_sq_commit(const SqArgs *__restrict__ tab)
+{
+    sq_commit_wave<D>(tab[blockIdx.y], (int)blockIdx.x);
+}
+
 // ---- round, first launch: drop the committed steps, admit new ones in step order ------------------------------------------------
 // One workgroup; writes slots[cur ^ 1] from slots[cur].  No two pending steps may share a particle: the particles of the
 // steps that stay and of the candidates go into a hash table in LDS (value = the smallest claimant, -1 for a pending step);
 // admission stops at the first candidate that does not hold all its particles.
+template <int NT>
 __device__ __forceinline__ int sq_block_scan_excl(int v, int *lds, int *total)
 {
-    // exclusive scan over the workgroup (SQ_FILL_THREADS threads), wave scan + scan of the 16 wave totals
+    // exclusive scan over the workgroup (NT threads), wave scan + scan of the wave totals
     const int lane = wave_lane(), wv = threadIdx.x >> 6;
     int incl = v;
 #pragma unroll
@@ -715,7 +720,7 @@ __device__ __forceinline__ int sq_block_scan_excl(int v, int *lds, int *total)
     if (lane == 63) lds[wv] = incl;
     __syncthreads();
     int base = 0, tot = 0;
-    for (int q = 0; q < SQ_FILL_THREADS / 64; q++) {
+    for (int q = 0; q < NT / 64; q++) {
         const int t = lds[q];
         if (q < wv) base += t;
         tot += t;
@@ -743,12 +748,10 @@ __device__ __forceinline__ int sq_table_owner(const int *keys, const int *vals, 
     return vals[hh];
 }
 
-template <int D>
-__global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__restrict__ tab)
+// NT threads admit for windows of up to 4 NT slots (k_sq_fill: 1024 threads)
+template <int D, int NT>
+__device__ __forceinline__ void sq_fill_block(const SqArgs &s, int *sq_table, int *lds)
 {
-    const SqArgs &s = tab[blockIdx.y];
-    extern __shared__ int sq_table[];            // keys[4 K], vals[4 K]
-    __shared__ int lds[SQ_FILL_THREADS / 64 + 2];
     const RefArgs &a = s.a;
     SqCtl *ctl = s.ctl;
     const int cur = ctl->cur;
@@ -762,14 +765,14 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__res
     if (ctl->gen_hi < lim) lim = ctl->gen_hi;
     if (ctl->prefix + s.ring_mask + 1 < lim) lim = ctl->prefix + s.ring_mask + 1;
     const int maxcand = (lim <= next) ? 0 : (int)min((unsigned long long)s.K, lim - next);
-    for (int k = tid; k < 4 * s.K; k += SQ_FILL_THREADS) { keys[k] = -1; vals[k] = INT_MAX; }
-    constexpr int PER = SQ_KMAX / SQ_FILL_THREADS;
+    for (int k = tid; k < 4 * s.K; k += NT) { keys[k] = -1; vals[k] = INT_MAX; }
+    constexpr int PER = 4;                       // slots per thread: the window is at most 4 NT
     // -- the particle words of every step that could be admitted: loads that do not wait for anything below
     int gm[PER];
     uint32_t gr1[PER], gq0[PER];
 #pragma unroll
     for (int r = 0; r < PER; r++) {
-        const int q = r * SQ_FILL_THREADS + tid;
+        const int q = r * NT + tid;
         gm[r] = 0; gr1[r] = 0; gq0[r] = 0;
         if (q < maxcand) {
             const SqGen &ge = s.gen[(next + (unsigned long long)q) & s.gen_mask];
@@ -779,26 +782,26 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__res
     // -- keep the held-back steps, in order
     int nkeep = 0;
     for (int r = 0; r < PER; r++) {
-        const int w = r * SQ_FILL_THREADS + tid;
+        const int w = r * NT + tid;
         int fl = SQF_COMMITTED, pi = -1, pj = -1;
         if (w < nold) { fl = src[w].flags; pi = src[w].i; pj = src[w].j; }
         const bool keep = !(fl & SQF_COMMITTED);
         int tot;
-        const int at = nkeep + sq_block_scan_excl(keep ? 1 : 0, lds, &tot);   // (its barriers also cover the table's initialisation)
+        const int at = nkeep + sq_block_scan_excl<NT>(keep ? 1 : 0, lds, &tot);   // (its barriers also cover the table's initialisation)
         if (w < nold) s.moveto[w] = keep ? at : -1;
         if (keep) {
             if (pi >= 0) sq_table_claim(keys, vals, tmask, pi, -1);
             if (pj >= 0) sq_table_claim(keys, vals, tmask, pj, -1);
         }
         nkeep += tot;
-        if (r * SQ_FILL_THREADS + SQ_FILL_THREADS >= nold) break;
+        if (r * NT + NT >= nold) break;
     }
     // -- candidates in step order
     const int avail = min(s.K - nkeep, maxcand);
     int ci[PER], cj[PER], cf[PER];
 #pragma unroll
     for (int r = 0; r < PER; r++) {
-        const int q = r * SQ_FILL_THREADS + tid;
+        const int q = r * NT + tid;
         ci[r] = -1; cj[r] = -1; cf[r] = 0;
         if (q < avail) {
             const int m = gm[r];
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__res
     __syncthreads();                                   // the pending steps' claims are in the table
 #pragma unroll
     for (int r = 0; r < PER; r++) {
-        const int q = r * SQ_FILL_THREADS + tid;
+        const int q = r * NT + tid;
         if (q < avail) {
             if (ci[r] >= 0) sq_table_claim(keys, vals, tmask, ci[r], q);
             if (cj[r] >= 0) sq_table_claim(keys, vals, tmask, cj[r], q);
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__res
     int mycut = INT_MAX;
 #pragma unroll
     for (int r = 0; r < PER; r++) {
-        const int q = r * SQ_FILL_THREADS + tid;
+        const int q = r * NT + tid;
         if (q < avail) {
             bool lose = false;
             if (ci[r] >= 0 && sq_table_owner(keys, vals, tmask, ci[r]) != q) lose = true;
@@ -844,11 +847,11 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__res
     if (wave_lane() == 0) lds[threadIdx.x >> 6] = mycut;
     __syncthreads();
     int cut = INT_MAX;
-    for (int q = 0; q < SQ_FILL_THREADS / 64; q++) cut = min(cut, lds[q]);
+    for (int q = 0; q < NT / 64; q++) cut = min(cut, lds[q]);
     const int nadm = min(cut, avail);
 #pragma unroll
     for (int r = 0; r < PER; r++) {
-        const int q = r * SQ_FILL_THREADS + tid;
+        const int q = r * NT + tid;
         if (q < nadm) { s.cand[3 * q] = ci[r]; s.cand[3 * q + 1] = cj[r]; s.cand[3 * q + 2] = cf[r]; }
     }
     if (tid < SQ_KW) s.cp[tid] = 0;
@@ -867,15 +870,22 @@ __global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__res
     }
 }
 
+template <int D>
+__global__ __launch_bounds__(SQ_FILL_THREADS) void k_sq_fill(const SqArgs *__restrict__ tab)
+{
+    extern __shared__ int sq_table[];            // keys[4 K], vals[4 K]
+    __shared__ int lds[SQ_FILL_THREADS / 64 + 2];
+    static_assert(SQ_KMAX == 4 * SQ_FILL_THREADS, "sq_fill_block admits for windows of up to four slots per thread");
+    sq_fill_block<D, SQ_FILL_THREADS>(tab[blockIdx.y], sq_table, lds);
+}
+
 // ---- round, second launch: the new window -- held-back steps moved up, admitted steps built (position, trial position, cells) ------
 // one thread per old slot and per admitted step; writes slots[cur] from slots[cur ^ 1] (the host has flipped cur)
 template <int D>
-__global__ __launch_bounds__(256) void k_sq_prep(const SqArgs *__restrict__ tab)
+__device__ __forceinline__ void sq_prep_thread(const SqArgs &s, const int t)
 {
-    const SqArgs &s = tab[blockIdx.y];
     const RefArgs &a = s.a;
     const SqCtl *ctl = s.ctl;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nold = ctl->f_nold, nkeep = ctl->f_nkeep;
     const int nadm = ctl->nslots - nkeep;
     const int cur = ctl->cur;
@@ -926,6 +936,12 @@ __global__ __launch_bounds__(256) void k_sq_prep(const SqArgs *__restrict__ tab)
         if (sl.c1 != sl.c0) s.cellnext[2 * to + 1] = atomicExch(&s.cellhead[sl.c1], 2 * to + 1);
     }
     dst[nkeep + q] = sl;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_sq_prep(const SqArgs *__restrict__ tab)
+{
+    sq_prep_thread<D>(tab[blockIdx.y], (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 // The rows of a LinkedList whose chains already exist (moves have shaped their order: src/neighbours.jl:276-302): the row of

@@ -4,7 +4,18 @@
 static int seq_rows_cap(const pmc_system *h)
 {
     const double mean = (double)h->N / (double)h->ncell_ref;
-    return std::max(32, (int)(3.0 * mean) + 32);
+    return std::max(h->rows_min_cap, std::max(32, (int)(3.0 * mean) + 32));   // (rows_min_cap: a row overflowed mid-chain before)
+}
+
+// A cell row overflowed in the middle of a chain (err bit 0): the reference's vectors simply grow, the device rows are fixed for
+// the length of a call, so the call fails -- but the next one gets rows of twice the capacity (seq_rows_cap honours
+// rows_min_cap; CellList / VerletList rows are re-allocated by pmc_build_cells, which doubles until the fullest cell fits and
+// then once more).
+static void seq_rows_overflowed(pmc_system *h, int err)
+{
+    if (!(err & 1)) return;
+    h->rows_min_cap = std::max(h->rows_min_cap, 2 * std::max(h->cl_cap, 16));
+    if (h->list_type == 1 && h->d_cl_items) { (void)hipFree(h->d_cl_items); h->d_cl_items = nullptr; h->cl_cap = 0; }
 }
 
 // the cell rows of a LinkedList: allocated on the first fast sequential call, rebuilt by every pmc_build_cells
@@ -45,7 +56,6 @@ static int seq_alloc_rows(pmc_system *h, int cap)
         h->d_cl_items = nullptr;
         h->cl_cap = cap;
         HIPCHK(h, hipMalloc(&h->d_cl_items, (size_t)h->ncell_ref * cap * sizeof(int)));
-        h->rows_own = true;
         if (!h->cells_built) return PMC_OK;            // the next pmc_build_cells fills the rows
         HIPCHK(h, hipMemsetAsync(h->d_ref_err, 0, sizeof(int), h->stream));
         hipLaunchKernelGGL(k_sq_rows_from_chains, dim3(nblk(h->ncell_ref, 128)), dim3(128), 0, h->stream, h->ncell_ref, h->d_head,
@@ -442,6 +452,8 @@ static int seq_group_wait(SeqGroup &g, bool &copies, bool &all_admitted)
         if (r.c.err) {
             h->cells_built = false;
             h->energy_stale = true;
+            h->state_invalid = true;        // positions are partly advanced: no caller-side energy belongs to them (pmc_set_energy)
+            seq_rows_overflowed(h, r.c.err);
             r.failed = true;
             const int e = fail(h, PMC_ERR_STATE, (r.c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
             if (!first) first = e;
@@ -508,6 +520,7 @@ static int seq_group_end(SeqGroup &g, pmc_stats *out)
         if (r.failed) continue;
         r.c.prefix = r.prefix;
         h->sq_last = r.c;
+        h->sq_last_steps = (r.c.gend == r.c.next) ? (long long)r.nsteps - (long long)(r.c.gend - r.prefix) : 0;   // steps of THIS call folded
         h->energy = r.energy;
         h->step_ctr += (uint64_t)r.nsteps;
         h->sweep_ctr += (uint64_t)r.nsweeps;
@@ -738,7 +751,8 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
         if (c.err) {
             h->cells_built = false;
             h->energy_stale = true;
-            if ((c.err & 1) && h->list_type == 1) { (void)hipFree(h->d_cl_items); h->d_cl_items = nullptr; h->cl_cap = 0; h->rows_own = false; }   // larger next time
+            h->state_invalid = true;        // positions are partly advanced: no caller-side energy belongs to them (pmc_set_energy)
+            seq_rows_overflowed(h, c.err);
             if (!first) first = fail(h, PMC_ERR_STATE, (c.err & 1) ? "sequential engine: a cell row overflowed" : "sequential engine: a particle was not in its cell row");
             continue;
         }

@@ -273,11 +273,17 @@ class Atoms(Particles):
 
     # --- how PMC_SEQUENTIAL sweeps run (same chain bit for bit; include/pmc.h) --------------------
     def set_sequential_engine(self, engine=0, window=0):
-        """engine 0 auto, 1 the one-wavefront literal loop, 2 speculative windows; window: pending steps per round (0 auto)."""
+        """engine 0 auto, 1 the one-wavefront literal loop, 2 speculative windows, 3 the chain's state in LDS (small systems;
+        any number of chains per launch through mc_sweep_many); window: pending steps per round of engine 2 (0 auto)."""
         _lib.check(_lib.lib().pmc_set_sequential_engine(self._h, int(engine), int(window)), self._h)
 
+    def debug_inject(self, what=1):
+        """Fault injection for the tests (include/pmc.h: pmc_debug_inject); 1 = the next fused launch is declared starved."""
+        _lib.check(_lib.lib().pmc_debug_inject(self._h, int(what)), self._h)
+
     def sequential_info(self):
-        """(rounds, step evaluations, window, steps folded) of the last PMC_SEQUENTIAL call that ran engine 2."""
+        """(rounds, step evaluations, window, steps of that call folded into system.energy) of the last PMC_SEQUENTIAL call that
+        ran engine 2."""
         out = (C.c_int64 * 4)()
         _lib.check(_lib.lib().pmc_sequential_info(self._h, out), self._h)
         return tuple(int(v) for v in out)

@@ -541,8 +541,9 @@ def test_engines_interleave_without_manual_rebuilds(gpu):
 
 def test_ticket_fallback_after_a_starved_launch(gpu, monkeypatch):
     """when a fused launch is declared starved the handle falls back from the eight per-XCD ticket counters to the
-    single monotonic one -- which must restart in step with the host's count, not at the aborted sweep's.  The hook
-    PMC_TEST_STARVE=1 declares a good launch starved; afterwards the chain (re-uploaded, as the error text asks) must follow the
+    single monotonic one -- which must restart in step with the host's count, not at the aborted sweep's.  The fault injection
+    pmc_debug_inject(PMC_INJECT_STARVED_LAUNCH) declares the handle's next good launch starved (one shot; ADVICE r04: it used to
+    be an environment variable read on every call); afterwards the chain (re-uploaded, as the error text asks) must follow the
     oracle's schedule again, alone and in a shared launch."""
     from oracle import oracle as O
     pmc = gpu
@@ -551,10 +552,9 @@ def test_ticket_fallback_after_a_starved_launch(gpu, monkeypatch):
     pool_o = O.make_pool([{"kind": "Displacement", "sigma": 0.05}])
     g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=9)
     pmc.mc_sweep(g, pool, nsweeps=2)
-    monkeypatch.setenv("PMC_TEST_STARVE", "1")
+    g.debug_inject(1)
     with pytest.raises(pmc.PMCError):
         pmc.mc_sweep(g, pool, nsweeps=1)
-    monkeypatch.delenv("PMC_TEST_STARVE")
     g.upload(pos, sp)
     g.set_counters(0, 0)
     cb = O.Checkerboard(pos, sp, g.box, 1.0, O.single(O.lennard_jones(1.0, 1.0)), seed=9)
@@ -564,10 +564,9 @@ def test_ticket_fallback_after_a_starved_launch(gpu, monkeypatch):
     # ... and every chain of a shared launch
     chains = [pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=9, chain=k) for k in range(3)]
     pmc.mc_sweep_many(chains, pool, nsweeps=1)
-    monkeypatch.setenv("PMC_TEST_STARVE", "1")
+    chains[0].debug_inject(1)
     with pytest.raises(pmc.PMCError):
         pmc.mc_sweep_many(chains, pool, nsweeps=1)
-    monkeypatch.delenv("PMC_TEST_STARVE")
     for k, c in enumerate(chains):
         c.upload(pos, sp)
         c.set_counters(0, 0)

@@ -260,3 +260,13 @@ def test_glue_call_sequences_replayed_in_c_match_the_oracle(gpu, harness, tmp_pa
         assert [int(v) for v in row[5:9]] == O.philox((step & 0xffffffff, step >> 32, 0, 2), (77, 3))
     assert len(out["words"]) == 3
     del pmc
+
+
+def test_default_tick_is_one_sweep_as_in_the_reference():
+    """The reference's Metropolis entry runs one mc_sweep! of N steps per scheduler tick (sweepstep = length(chains[1]),
+    src/ParticlesMC.jl:246): the glue's default HIPMetropolis must do the same -- callbacks and schedulers then fire at the
+    reference's cadence in both modes -- and longer ticks must be an explicit keyword."""
+    txt = open(JL).read()
+    m = re.search(r"^HIPMetropolis\(pool, mode; sweeps_per_step=(\d+)\) = HIPMetropolis\(pool, mode, sweeps_per_step\)", txt, re.M)
+    assert m and int(m.group(1)) == 1, "the default tick must be one sweep"
+    assert "4 * rounds" not in txt
