@@ -153,7 +153,7 @@ def _free_port():
     return p
 
 
-def launch_ranks(ngpus, argv):
+def launch_ranks(ngpus, argv, timeout=None):
     """Start `ngpus` ranks of this script (one process per GPU) as CHILD processes and return their
     exit status.  Nothing in this (parent) process has touched the GPU: no torch import, no HIP call."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
@@ -161,7 +161,35 @@ def launch_ranks(ngpus, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    if not timeout or timeout <= 0:
+        return subprocess.call(cmd, env=env)
+    # --launch-timeout: a rank that hangs (a rendezvous that never completes, a collective that never returns) must end the job
+    # with a non-zero status, never with a re-exec: the ranks run in a process group of their own, which is killed as a whole
+    import signal
+    p = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return p.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        # exactly the processes this call started: the launcher, its process group, and the ranks it spawned (the elastic agent
+        # gives its workers sessions of their own, so the group alone would leave them -- and the caller's pipes -- alive)
+        kids = []
+        try:
+            import psutil
+            kids = psutil.Process(p.pid).children(recursive=True)
+        except Exception:
+            pass
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        for k in kids:
+            try:
+                k.kill()
+            except Exception:
+                pass
+        p.wait()
+        print(f"bench.py: the {ngpus} ranks did not finish within {timeout:.0f} s: killed", file=sys.stderr)
+        return 5
 
 
 # ---- test hook: the launcher / reduction logic without a GPU ----------------------------------
@@ -180,10 +208,13 @@ class _StubEngine:
         pairs_in_range = 0
         null_moves = 0
 
-    def __init__(self, N):
+    def __init__(self, N, rank=0):
         self.N = N
+        self.hang = os.environ.get("PMC_BENCH_STUB_HANG") == str(rank)     # (the launcher's timeout test: this rank never returns)
 
     def sweep(self, nsweeps):
+        if self.hang:
+            time.sleep(3600)
         time.sleep(0.002 * nsweeps)
         return self._Stats()
 
@@ -210,6 +241,10 @@ def parse_args(argv=None):
                          "steps / rounds launches of the sweep kernel are the timed region (profiles/collect.sh)")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the bounded block of the other BASELINE configurations and of the reference-order chain (\"other_configs\", \"reference_order_chain\")")
+    ap.add_argument("--launch-timeout", type=float, default=0.0,
+                    help="seconds after which the self-launched ranks are killed as a group and the exit status is 5 (0: wait)")
+    ap.add_argument("--strict-rccl", action="store_true",
+                    help="exit with status 4 unless the replica-exchange self-check ran on every rank and agreed with pmc_pt_decide")
     ap.add_argument("--share-devices", action="store_true",
                     help="functional testing only: allow more ranks than visible GPUs (ranks share devices, gloo reductions)")
     return ap.parse_args(argv)
@@ -490,6 +525,92 @@ def other_configs(pmc, budget_cpu_s=1.2):
     row["reference_order_chain"]["roofline_frac"] = _seq_flop_frac(s.N, 3, s.neighbour_list.ncells, row["reference_order_chain"]["moves_per_s"], 75.0)
     row["cpu_oracle_moves_per_s"] = _oracle_rate(lambda: O.System(state, sstate, rho, TEMPERATURE, O.kob_andersen(), O.LINKEDLIST), pool_o, 42, budget_cpu_s)
     rows.append(row)
+    # -- the reference's own validation example at a liquid density (examples/lj-mixture/run-validation.py:26-34,98-115): binary LJ,
+    #    rcut = 4 sigma unshifted, 90 % Displacement + 10 % DiscreteSwap; N = 8000 so that a checkerboard grid exists (4 x 4 x 4 cells of
+    #    125 particles: 3375 candidates per neighbourhood -- the big-neighbourhood instances of k_cb_pass, round 5)
+    nmx = 20
+    Nmx, rho_mx, T_mx = nmx ** 3, 0.8, 1.5
+    Lmx = (Nmx / rho_mx) ** (1.0 / 3.0)
+    gmx = np.stack(np.meshgrid(*[np.arange(nmx)] * 3, indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
+    pos = (gmx + 0.5) * (Lmx / nmx)
+    sp = np.ones(Nmx, dtype=np.int32)
+    sp[np.random.default_rng(3).permutation(Nmx)[: Nmx // 2]] = 2
+    EPS_MX, SIG_MX = ((1.0, 1.1523), (1.1523, 1.3702)), ((1.0, 1.0339), (1.0339, 1.0640))
+    mm = [[pmc.LennardJones(EPS_MX[i][j], SIG_MX[i][j], rcut=4.0, shift_potential=False) for j in range(2)] for i in range(2)]
+    s = pmc.System(pos, sp, Nmx / Lmx ** 3, T_mx, mm, seed=42)
+    pool = [disp(p=0.9), pmc.Move(pmc.DiscreteSwap([1, 2], s), pmc.DoubleUniform(), [], 0.1)]
+    s.total_energy()
+    pmc.mc_sweep(s, pool, nsweeps=200)
+    row = {"config": "published mixture (examples/lj-mixture): binary LJ rcut=4 unshifted, N=8000 rho=0.8 T=1.5 x=0.5, 90% Displacement + 10% DiscreteSwap "
+                     "(4x4x4 cells of 125 particles; 200 untimed sweeps from the lattice)",
+           "checkerboard_m1": cb_leg(s, pool, 100, 10, 1), "checkerboard_m4": cb_leg(s, pool, 100, 12, 4)}
+    s.rounds = 1
+    state, sstate = s.position.copy(), s.species.copy()
+    mo_mx = O.model_matrix(O.lennard_jones, EPS_MX, SIG_MX, rcut=4.0, shift_potential=False)
+    row["cpu_oracle_moves_per_s"] = _oracle_rate(lambda: O.System(state, sstate, Nmx / Lmx ** 3, T_mx, mo_mx, O.LINKEDLIST),
+                                                 O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE, "probability": 0.9},
+                                                              {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}]), 42, budget_cpu_s)
+    rows.append(row)
+    # -- the same example AS PUBLISHED (N = 1000: 2.7 cutoffs per side -- a single-cell box, round 5): one chain on one CU, 256 chains
+    try:
+        nm1 = 10
+        Lm1 = (1000 / rho_mx) ** (1.0 / 3.0)
+        g1 = np.stack(np.meshgrid(*[np.arange(nm1)] * 3, indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
+        pos1 = (g1 + 0.5) * (Lm1 / nm1)
+        sp1 = np.ones(1000, dtype=np.int32)
+        sp1[np.random.default_rng(3).permutation(1000)[:500]] = 2
+        s1 = pmc.System(pos1, sp1, 1000 / Lm1 ** 3, T_mx, mm, seed=42)
+        pool1 = [disp(p=0.9), pmc.Move(pmc.DiscreteSwap([1, 2], s1), pmc.DoubleUniform(), [], 0.1)]
+        s1.total_energy()
+        pmc.mc_sweep(s1, pool1, nsweeps=200)
+        leg1 = cb_leg(s1, pool1, 200, 10, 1)
+        chains = [pmc.System(pos1, sp1, 1000 / Lm1 ** 3, T_mx, mm, seed=42, chain=k) for k in range(256)]
+        pmc.mc_sweep_many(chains, pool1, nsweeps=10)
+        t0 = time.perf_counter()
+        pmc.mc_sweep_many(chains, pool1, nsweeps=40)
+        dtn = time.perf_counter() - t0
+        st1, ss1 = s1.position.copy(), s1.species.copy()
+        rows.append({"config": "published mixture AS PUBLISHED (examples/lj-mixture/run-validation.py:26-34,155-166): N=1000 rho=0.8 T=1.5 x=0.5 rcut=4, 90% Displacement + "
+                               "10% DiscreteSwap; box of 2.7 cutoffs per side = ONE cell, the plain Metropolis chain with global DoubleUniform picks",
+                     "checkerboard_m1": leg1, "checkerboard_m1_256_chains": {"moves_per_s": 256 * 1000 * 40 / dtn},
+                     "cpu_oracle_moves_per_s": _oracle_rate(lambda: O.System(st1, ss1, 1000 / Lm1 ** 3, T_mx, mo_mx, O.LINKEDLIST),
+                                                            O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE, "probability": 0.9},
+                                                                         {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}]), 42, budget_cpu_s)})
+        del chains
+    except Exception as exc:
+        rows.append({"config": "published mixture as published (N=1000)", "error": repr(exc)})
+    # -- the reference's CI system (test/runtests.jl:22-91: config_0, N = 1290 2-D ternary JBB, T = 0.231) with a VerletList dr = 0.2 on
+    #    the reference's own chain: the literal loop (engine 1), one chain and 256 chains of a parallel = true run in one launch
+    try:
+        from particlesmc_amd.io import load_configuration
+        cfg = load_configuration(os.path.join(ROOT, "tests", "golden", "config_0.xyz"))
+        cpos, csp, cbox = np.asarray(cfg["position"], dtype=np.float64), np.asarray(cfg["species"], dtype=np.int32), np.asarray(cfg["box"], dtype=np.float64)
+        cpos = cpos - np.floor(cpos / cbox) * cbox
+        crho = len(cpos) / float(np.prod(cbox))
+        vpool = [disp()]
+
+        def verlet_chain(k):
+            return pmc.System(cpos, csp, crho, 0.231, pmc.JBB(), list_type=pmc.VerletList, list_parameters={"dr": 0.2}, seed=10, chain=k)
+        one = verlet_chain(0)
+        pmc.mc_sweep(one, vpool, nsweeps=1, mode="sequential")
+        t0 = time.perf_counter()
+        st1 = pmc.mc_sweep(one, vpool, nsweeps=4, mode="sequential")
+        dt1 = time.perf_counter() - t0
+        chains = [verlet_chain(k) for k in range(256)]
+        pmc.mc_sweep_many(chains, vpool, nsweeps=1, mode="sequential")
+        t0 = time.perf_counter()
+        pmc.mc_sweep_many(chains, vpool, nsweeps=2, mode="sequential")
+        dtn = time.perf_counter() - t0
+        rows.append({"config": "the reference's CI system (test/runtests.jl:22-91): config_0, N=1290 2-D ternary JBB, T=0.231, VerletList dr=0.2, Displacement sigma=0.05; "
+                               "the reference's sequential chain on the literal loop (engine 1)",
+                     "reference_order_chain": {"moves_per_s_one_chain": 4 * one.N / dt1, "us_per_step_one_chain": 1e6 * dt1 / (4 * one.N),
+                                               "moves_per_s_256_chains_one_launch": 256 * 2 * one.N / dtn,
+                                               "acceptance": [float(st1.accepted[0]) / max(1, st1.attempted[0])]},
+                     "cpu_oracle_moves_per_s": _oracle_rate(lambda: O.System(cpos, csp, crho, 0.231, O.jbb(), O.VERLETLIST, 0.2),
+                                                            O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}]), 10, budget_cpu_s)})
+        del chains
+    except Exception as exc:
+        rows.append({"config": "the reference's CI system with a VerletList", "error": repr(exc)})
     # -- config 5: 8 tempering replicas of 2-D r^-14 soft spheres on this GPU, exchange every 10 sweeps
     n, side = 8, 256
     Nss = side * side
@@ -627,7 +748,7 @@ def run_rank(args):
     pmc = None
     system = None
     if stub:
-        engine = _StubEngine(N)
+        engine = _StubEngine(N, rank)
         sweep = engine.sweep
         ncell_ref, grid = [1, 1, 1], [0, 0, 0]
         e0 = 0.0
@@ -757,12 +878,17 @@ def run_rank(args):
         energy_ok = bool(ok.item() == 1.0)
 
     # the path's one collective, on the ranks of this job (N > 1 over RCCL only), in child processes
+    # (--share-devices with PMC_RCCL_LIB naming another library with RCCL's entry points -- tests/c/rccl_stub.c -- runs the same
+    # leg with every rank on one device: the whole rank path of an N-GPU run, minus RCCL's own transport, on a one-GPU box)
     rccl = None
-    if dist is not None and backend == "nccl" and not stub:
+    rccl_lib = os.environ.get("PMC_RCCL_LIB")
+    if dist is not None and not stub and (backend == "nccl" or (args.share_devices and rccl_lib)):
         try:
             rccl = rccl_exchange_check(rank, world, dev_index, dist)
         except Exception as exc:
             rccl = {"n_ranks_rccl": 0, "error": repr(exc)}
+        if isinstance(rccl, dict):
+            rccl["transport"] = os.path.basename(rccl_lib) if rccl_lib else "librccl.so"
 
     if rank == 0:
         value = legs[args.rounds]["value"]
@@ -859,9 +985,15 @@ def run_rank(args):
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    status = 0
+    if args.strict_rccl and dist is not None:
+        good = [1.0 if (rank != 0 or (isinstance(rccl, dict) and rccl.get("n_ranks_rccl") == world and rccl.get("decisions_equal_pt_decide"))) else 0.0]
+        t = torch.tensor(good, dtype=torch.float64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        status = 0 if float(t.item()) == 1.0 else 4
     if dist is not None:
         dist.destroy_process_group()
-    return 0
+    return status
 
 
 def main(argv=None):
@@ -871,7 +1003,7 @@ def main(argv=None):
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return launch_ranks(args.gpus, argv)        # parent: no torch, no HIP; the ranks are child processes
+        return launch_ranks(args.gpus, argv, args.launch_timeout)        # parent: no torch, no HIP; the ranks are child processes
     return run_rank(args)
 
 

@@ -85,7 +85,10 @@ typedef struct {
 
 typedef enum {
     PMC_SEQUENTIAL = 0,    /* the reference's one-particle-per-step chain (src/moves.jl:57-81) */
-    PMC_CHECKERBOARD = 1   /* many independent proposals per sweep (DESIGN.md "schedule") */
+    PMC_CHECKERBOARD = 1   /* many independent proposals per sweep (DESIGN.md "schedule"): an even grid of >= 4 cells of width >= rcut per
+                              side, 2^d colour passes; or -- a box of 2 ... 4 cutoffs per side in every dimension with N <= 1024 -- ONE cell
+                              spanning the periodic box: the plain Metropolis chain, its N proposal slots evaluated eight at a time.
+                              Other boxes: PMC_ERR_UNSUPPORTED (PMC_SEQUENTIAL runs them) */
 } pmc_mode;
 
 typedef struct {
@@ -102,7 +105,8 @@ typedef struct {
     int64_t pairs_in_range;   /* pair energies evaluated (r2 <= rcut2, src/atoms.jl:72) */
     int64_t null_moves;       /* attempted slots that evaluated no dE: Displacements that would leave their cell, swaps in a cell lacking a species */
     int64_t dense_evals;      /* FP64 distance evaluations: (survivor of the FP32 pre-filter, old | new position); counted by the
-                                 single-species kernels with one wavefront per cell (the large-system path), 0 otherwise */
+                                 single-species kernels with one wavefront per cell (the large-system path) and by the
+                                 big-neighbourhood team kernels (boxes of 4-5 cutoffs per side), 0 otherwise */
     int64_t staged_candidates;/* candidates the cell visits loaded from global memory (all 3^d cells of every visit) */
     int64_t written_back;     /* particles the cell visits wrote back (every particle of a cell with an accepted move) */
 } pmc_stats;

@@ -361,7 +361,7 @@ class Checkerboard:
         self.h = lib().orc_cb_create(self.N, self.d, _dp(p), _ip(sp), _dp(b), temperature, S, marr,
                                      seed, chain, C.byref(err))
         if not self.h:
-            raise ValueError("checkerboard grid needs >= 4 cells per side")
+            raise ValueError("checkerboard grid needs >= 4 cells per side (or a single-cell box: 2 ... 4 cutoffs per side in every dimension, N <= 1024)")
         self.models = models
 
     def __del__(self):

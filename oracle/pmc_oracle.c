@@ -1086,6 +1086,7 @@ void orc_mc_steps_sequential(orc_system *s, const orc_move *pool, int32_t npool,
 #define CB_UMAX 1024.0
 #define CB_CQ 1572864.0           /* 1.5 * 2^20: rounds to multiples of 2^-32 */
 #define CB_FIX 4294967296.0       /* 2^32 */
+#define ORC_CB_SINGLE_MAX 1024    /* particles a single-cell box may hold (the staging capacity of one cell visit) */
 
 struct orc_cb {
     int64_t N;
@@ -1175,15 +1176,18 @@ static int64_t cb_gather(const orc_cb *c, int64_t lin, int64_t *out)
     int nn = (d == 3) ? 27 : (d == 2 ? 9 : 3);
     int64_t n = 0;
     for (int o = 0; o < nn; o++) {
-        int rr = o;
+        int rr = o, dup = 0;
         int64_t l2 = 0;
         for (int a = 0; a < d; a++) {
-            int64_t q = cc[a] + (rr % 3) - 1;
+            int off = (rr % 3) - 1;
+            int64_t q = cc[a] + off;
             rr /= 3;
+            if (c->n_mc[a] == 1 && off != 0) dup = 1;      /* single-cell box: the cell is its own neighbour once, not 3^d times */
             if (q < 0) q += c->n_mc[a];
             if (q >= c->n_mc[a]) q -= c->n_mc[a];
             l2 = l2 * c->n_mc[a] + q;
         }
+        if (dup) continue;
         for (int64_t k = c->cell_start[l2]; k < c->cell_start[l2 + 1]; k++)
             out[n++] = c->cell_ids[k];
     }
@@ -1223,15 +1227,28 @@ orc_cb *orc_cb_create(int64_t N, int32_t d, const double *pos, const int32_t *sp
     /* widest even grid whose cells are wider than rcut by a safety margin */
     double need = maxcut * (1.0 + 1.0 / 1048576.0);
     c->ncell = 1;
+    int nsmall = 0;
     for (int a = 0; a < d; a++) {
         c->box[a] = box[a];
         int64_t n = (int64_t)floor(box[a] / need);
         n -= (n & 1);
         while (n >= 4 && box[a] / (double)n < need) n -= 2;
-        if (n < 4) { *err = 2; orc_cb_destroy(c); return NULL; }
+        if (n < 4) { nsmall++; n = 1; }
         c->n_mc[a] = n;
         c->w[a] = box[a] / (double)n;
         c->ncell *= n;
+    }
+    /* SINGLE-CELL BOXES (round 5).  A box of fewer than 4 cutoffs per side cannot be two-coloured periodically; if it is small
+     * in EVERY dimension, still at least 2 (1 + 2^-10) cutoffs wide (the two roundings of the minimum image -- and the device's FP32
+     * pre-filter -- then only differ for pairs beyond the cutoff) and holds at most ORC_CB_SINGLE_MAX particles, the whole periodic box is ONE cell: one colour, one visit per
+     * pass, its N proposal slots in order against all N particles, no move ever "leaves the cell" -- i.e. the plain Metropolis
+     * chain of src/moves.jl:57-81 with a uniformly picked particle (and the reference's global DoubleUniform for swaps), keyed
+     * (cell 0, slot t, sweep g).  The reference's own validation example is such a box (N = 1000, rcut = 4 sigma,
+     * examples/lj-mixture/run-validation.py:26-34,155-166).  Mixed boxes (small in some dimensions only) stay refused. */
+    if (nsmall > 0) {
+        int ok = (nsmall == d) && N <= ORC_CB_SINGLE_MAX;
+        for (int a = 0; a < d; a++) if (box[a] < 2.0 * maxcut * (1.0 + 1.0 / 1024.0)) ok = 0;
+        if (!ok) { *err = 2; orc_cb_destroy(c); return NULL; }
     }
     c->cell_start = (int64_t *)calloc((size_t)c->ncell + 1, sizeof(int64_t));
     c->cell_ids = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
@@ -1361,8 +1378,8 @@ void orc_cb_sweeps_rounds(orc_cb *c, const orc_move *pool, int32_t npool, uint64
                         int inside = 1;
                         for (int a = 0; a < d; a++) {
                             xn[a] = cb_settle(xo[a] + pool[m].sigma * z[a], ki[a], c->box[a]);
-                            if (floor((xn[a] - shift[a]) / c->w[a]) != floor((xo[a] - shift[a]) / c->w[a]))
-                                inside = 0;
+                            if (c->n_mc[a] > 1 && floor((xn[a] - shift[a]) / c->w[a]) != floor((xo[a] - shift[a]) / c->w[a]))
+                                inside = 0;                             /* (a single-cell box has no cell to leave) */
                         }
                         if (!inside) continue;
                         double e1 = cb_energy_excl(c, xo, c->species[i], cand, ncand, i, -1);

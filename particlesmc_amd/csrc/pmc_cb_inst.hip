@@ -13,4 +13,7 @@ PMC_CB_VARIANTS_IMG(PMC_INSTANTIATE_IMG)
 #define PMC_INSTANTIATE(M, NW, ONE, MW) \
     template __global__ void k_cb_pass<PMC_INST_D, PMC_INST_KIND, M, NW, ONE, MW>(const CbArgs *__restrict__ args, int nrep);
 PMC_CB_VARIANTS(PMC_INSTANTIATE)
+#define PMC_INSTANTIATE_BIG(M, ONE) \
+    template __global__ void k_cb_pass<PMC_INST_D, PMC_INST_KIND, M, 8, ONE, PMC_TEAM_MINWAVES, false, true>(const CbArgs *__restrict__ args, int nrep);
+PMC_CB_VARIANTS_BIG(PMC_INSTANTIATE_BIG)
 #endif

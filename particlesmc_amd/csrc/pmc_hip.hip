@@ -33,6 +33,20 @@ PMC_CB_VARIANTS(PMC_DECL_2_0) PMC_CB_VARIANTS(PMC_DECL_2_1) PMC_CB_VARIANTS(PMC_
 #define PMC_DECLI_2_4(M_, NW_, ONE_) PMC_DECLI(2, 4, M_, NW_, ONE_)
 PMC_CB_VARIANTS_IMG(PMC_DECLI_3_0) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_1) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_2) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_3) PMC_CB_VARIANTS_IMG(PMC_DECLI_3_4)
 PMC_CB_VARIANTS_IMG(PMC_DECLI_2_0) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_1) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_2) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_3) PMC_CB_VARIANTS_IMG(PMC_DECLI_2_4)
+// ... and the big-neighbourhood instances (teams of eight, no images)
+#define PMC_DECLB(DD_, KK_, M_, ONE_) extern template __global__ void k_cb_pass<DD_, KK_, M_, 8, ONE_, PMC_TEAM_MINWAVES, false, true>(const CbArgs *__restrict__, int);
+#define PMC_DECLB_3_0(M_, ONE_) PMC_DECLB(3, 0, M_, ONE_)
+#define PMC_DECLB_3_1(M_, ONE_) PMC_DECLB(3, 1, M_, ONE_)
+#define PMC_DECLB_3_2(M_, ONE_) PMC_DECLB(3, 2, M_, ONE_)
+#define PMC_DECLB_3_3(M_, ONE_) PMC_DECLB(3, 3, M_, ONE_)
+#define PMC_DECLB_3_4(M_, ONE_) PMC_DECLB(3, 4, M_, ONE_)
+#define PMC_DECLB_2_0(M_, ONE_) PMC_DECLB(2, 0, M_, ONE_)
+#define PMC_DECLB_2_1(M_, ONE_) PMC_DECLB(2, 1, M_, ONE_)
+#define PMC_DECLB_2_2(M_, ONE_) PMC_DECLB(2, 2, M_, ONE_)
+#define PMC_DECLB_2_3(M_, ONE_) PMC_DECLB(2, 3, M_, ONE_)
+#define PMC_DECLB_2_4(M_, ONE_) PMC_DECLB(2, 4, M_, ONE_)
+PMC_CB_VARIANTS_BIG(PMC_DECLB_3_0) PMC_CB_VARIANTS_BIG(PMC_DECLB_3_1) PMC_CB_VARIANTS_BIG(PMC_DECLB_3_2) PMC_CB_VARIANTS_BIG(PMC_DECLB_3_3) PMC_CB_VARIANTS_BIG(PMC_DECLB_3_4)
+PMC_CB_VARIANTS_BIG(PMC_DECLB_2_0) PMC_CB_VARIANTS_BIG(PMC_DECLB_2_1) PMC_CB_VARIANTS_BIG(PMC_DECLB_2_2) PMC_CB_VARIANTS_BIG(PMC_DECLB_2_3) PMC_CB_VARIANTS_BIG(PMC_DECLB_2_4)
 #endif
 
 #include <rccl/rccl.h>     // types only: the library itself is opened with dlopen on first use
@@ -150,6 +164,8 @@ struct pmc_system {
     SqCtl *d_sq_ctl = nullptr, *h_sq_ctl = nullptr;
     SqCtl sq_last{};             // control block of the last fast sequential call (diagnostics: rounds, evaluations)
     long long sq_last_steps = 0; // ... and the steps of that call the host folded into system.energy (all of them when it ended well)
+    bool single_cell = false;    // the throughput grid is one cell spanning the periodic box (boxes of 2 ... 4 cutoffs per side, N <= PMC_CAP_MAX)
+    bool no_big = false;         // a shared launch with a replica that carries images: no big-neighbourhood instances for any of its chains (cb_big)
     bool inject_starve = false;  // pmc_debug_inject(PMC_INJECT_STARVED_LAUNCH): the next fused launch is declared starved (one shot)
     hipGraphExec_t sq_graph = nullptr;   // SQ_GRAPH_ROUNDS rounds of the windows, captured for sq_graph_args / sq_graph_K
     SqArgs sq_graph_args;
@@ -456,16 +472,33 @@ extern "C" int pmc_create(const pmc_params *p, pmc_system **out)
     h->mc_ok = true;
     long long nmc = 1;
     const double need = maxcut * (1.0 + 1.0 / 1048576.0);
+    int nsmall = 0;
     for (int a = 0; a < h->D; a++) {
         long long n = (long long)floor(p->box[a] / need);
         n -= (n & 1);
         while (n >= 4 && p->box[a] / (double)n < need) n -= 2;
-        if (n < 4) { h->mc_ok = false; n = 0; }
+        if (n < 4) { nsmall++; n = 1; }
         h->grid.n[a] = (int)n;
-        h->grid.w[a] = n ? p->box[a] / (double)n : 0.0;
+        h->grid.w[a] = p->box[a] / (double)n;
         h->grid.shift[a] = 0.0;
         h->grid.L[a] = p->box[a];
         nmc *= n;
+    }
+    if (nsmall > 0) {
+        // SINGLE-CELL BOXES (round 5; restated in oracle/pmc_oracle.c:orc_cb_create).  Fewer than 4 cutoffs per side cannot be
+        // two-coloured periodically.  A box that is small in EVERY dimension, still >= 2 cutoffs wide (the two roundings of the
+        // minimum image then only differ beyond the cutoff) and holds <= PMC_CAP_MAX particles is ONE cell: one colour, one visit
+        // per pass -- its N proposal slots in order against all N particles, evaluated eight at a time by a team with the exact
+        // pair corrections of any batch; no move "leaves the cell", DoubleUniform picks are the reference's global ones.  The
+        // reference's own validation example is such a box (N = 1000, rcut = 4 sigma: examples/lj-mixture/run-validation.py:26-34).
+        bool ok = (nsmall == h->D) && h->N <= PMC_CAP_MAX;
+        for (int a = 0; a < h->D; a++) if (p->box[a] < 2.0 * maxcut * (1.0 + 1.0 / 1024.0)) ok = false;
+        h->single_cell = ok;
+        if (!ok) {
+            h->mc_ok = false;
+            nmc = 0;
+            for (int a = 0; a < h->D; a++) { h->grid.n[a] = 0; h->grid.w[a] = 0.0; }
+        }
     }
     if (h->D == 2) { h->grid.n[2] = 1; h->grid.w[2] = 1.0; h->grid.shift[2] = 0.0; h->grid.L[2] = 1.0; }
     h->ncell_mc = h->mc_ok ? (int)nmc : 0;
@@ -1452,9 +1485,7 @@ static int cb_cap(const pmc_system *h);
 static bool cb_fuse_teams(const pmc_system *h)
 {
     if (const char *e = getenv("PMC_FUSE_TEAMS")) return e[0] == '1';      // experiments
-#ifndef PMC_EXP_FUSE_ALL
     if (h->S < 2) return false;      // (compiled into the multi-species kernels only)
-#endif
     if (!h->mc_ok || !h->use_filter || h->D != 3) return false;
     return 3.0 * (double)h->N / (double)h->ncell_mc > 62.0;
 }
@@ -1465,7 +1496,7 @@ static CbArgs cb_args(pmc_system *h)
     memset(&a, 0, sizeof a);
     for (int q = 0; q < 3; q++) {
         a.n[q] = q < h->D ? h->grid.n[q] : 1;
-        a.half[q] = a.n[q] / 2;
+        a.half[q] = std::max(1, a.n[q] / 2);
         a.w[q] = q < h->D ? h->grid.w[q] : 1.0;
         a.shift[q] = h->grid.shift[q];
         a.L[q] = q < h->D ? h->p.box[q] : 1.0;
@@ -1484,6 +1515,8 @@ static CbArgs cb_args(pmc_system *h)
     a.models = h->d_models;
     a.stats = h->d_stats;
     a.cap = h->mc_ok ? cb_cap(h) : 128;
+    a.fcap = 0;
+    a.qcap = PMC_QCAP;
     a.rc2pad = h->maxcut * h->maxcut * (1.0 + 1e-9);
     // threshold of the FP32 pre-filter: rcut_max^2 (1 + 2^-12), rounded UP to float (pmc_kernels.h: error bound 2^-19)
     a.rc2f = std::nextafter((float)(h->maxcut * h->maxcut * (1.0 + 1.0 / 4096.0)), INFINITY);
@@ -1497,9 +1530,44 @@ static CbArgs cb_args(pmc_system *h)
 // of 64 (candidates beyond it are read from HBM/L2 by the kernels' overflow loops)
 static int cb_cap(const pmc_system *h)
 {
+    if (h->single_cell) return std::min(std::max((h->N + 63) / 64 * 64, 128), PMC_CAP_MAX);   // the one cell IS the neighbourhood: N candidates, exactly
     double mean = (double)h->N / (double)h->ncell_mc * (h->D == 3 ? 27.0 : 9.0);
     int cap = (int)((mean * 1.04 + 63.0) / 64.0) * 64;
     return std::min(std::max(cap, 128), PMC_CAP_MAX);
+}
+
+// Big neighbourhoods (round 5).  A box of 4-5 cutoffs per side at liquid density -- the published mixture's rcut = 4 sigma at
+// N = 8000, examples/lj-mixture/run-validation.py:26-34 -- has 3^d-cell neighbourhoods of thousands of candidates: beyond the
+// 1024 the staging holds by default and the 512 whose float copy a wavefront keeps in registers, so every slot took the
+// direct FP64 loop over candidates read from L2.  Such systems have few cells per colour, i.e. they run teams with a CU to
+// themselves: the team then stages the WHOLE neighbourhood (up to PMC_CAP_BIG candidates), keeps one float copy of it in LDS
+// and every wavefront's pre-filter streams that copy (pmc_kernels.h: prepare_filter, wave_delta_e_filtered<STREAM>).
+// Returns false -- the default capacities stay -- when the neighbourhood is small, the launch has no teams, or the LDS
+// (160 KB per workgroup) cannot hold it.
+struct CbBig { int cap, fcap, qcap; };
+static bool cb_big(const pmc_system *h, int team, CbBig *out)
+{
+    if (!h->mc_ok || !h->use_filter || team != 8 || h->any_img || h->no_big || getenv("PMC_NO_BIG")) return false;   // (the instances that exist: k_cb_pass<..., BIG>)
+    const double per_cell = (double)h->N / (double)h->ncell_mc;
+    const double mean = h->single_cell ? (double)h->N : per_cell * (h->D == 3 ? 27.0 : 9.0);
+    // (a single-cell box: exactly N candidates, and always these instances: theirs is the pre-filter that takes the minimum image of a
+    // difference of two float coordinates, which the whole periodic box as ONE neighbourhood needs)
+    if (!h->single_cell && mean * 1.04 <= (double)PMC_CAP_MAX) return false;
+    // the whole 3^d-cell population with room for fluctuations (8 % + 64); the queue: the candidates within the largest cutoff of
+    // either position -- a sphere's worth at the mean density, + 50 % + 128
+    int cap = h->single_cell ? cb_cap(h) : (int)((mean * 1.08 + 64.0 + 63.0) / 64.0) * 64;
+    if (cap > PMC_CAP_BIG) return false;
+    double vol = 1.0;
+    for (int q = 0; q < h->D; q++) vol *= h->p.box[q];
+    const double r = h->maxcut, pi = 3.14159265358979323846;
+    const double sphere = (h->D == 3) ? 4.0 / 3.0 * pi * r * r * r : pi * r * r;
+    int qcap = (int)(((double)h->N / vol * sphere * 1.5 + 128.0 + 63.0) / 64.0) * 64;
+    qcap = std::min(std::max(qcap, PMC_QCAP), 2048);
+    size_t b = (pmc_lds_wave_bytes(cap, h->S > 1, team, cap, qcap) + 15) & ~(size_t)15;
+    if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
+    if (b > (size_t)160 * 1024 - 512) return false;
+    if (out) { out->cap = cap; out->fcap = cap; out->qcap = qcap; }
+    return true;
 }
 
 // ... of k_cb_pass, which applies the box filter while staging (stage_compacted) and only keeps the survivors in LDS --
@@ -1510,6 +1578,7 @@ static int cb_cap(const pmc_system *h)
 static int cb_cap_sweep(const pmc_system *h)
 {
     if (const char *e = getenv("PMC_CAP")) return std::min(std::max(atoi(e) / 64 * 64, 128), PMC_CAP_MAX);   // experiments
+    if (h->team > 1) { CbBig big; if (cb_big(h, h->team, &big)) return big.cap; }
     if (!h->use_filter || !PMC_FUSED_STAGE || h->team > 1) return cb_cap(h);   // (teams stage the old way)
     int cap = h->cap_hint;
     if (cap <= 0) {
@@ -1553,9 +1622,18 @@ static void cb_cap_learn(pmc_system *h, const unsigned long long *cum)
     }
 }
 
+// the float-copy and queue capacities that go with a big-neighbourhood staging capacity (cb_big)
+static void cb_apply_big(const pmc_system *h, int cap_sweep, CbArgs &a)
+{
+    CbBig big;
+    if (h->team > 1 && !getenv("PMC_CAP") && cb_big(h, h->team, &big) && cap_sweep == big.cap) { a.fcap = big.fcap; a.qcap = big.qcap; }
+}
+
 static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0, int cap = 0)
 {
-    size_t b = (pmc_lds_wave_bytes(cap > 0 ? cap : cb_cap(h), h->S > 1, batch_nw) + 15) & ~(size_t)15;
+    CbBig big;
+    const bool isbig = batch_nw >= 2 && !getenv("PMC_CAP") && cb_big(h, batch_nw, &big) && cap == big.cap;
+    size_t b = (pmc_lds_wave_bytes(cap > 0 ? cap : cb_cap(h), h->S > 1, batch_nw, isbig ? big.fcap : 0, isbig ? big.qcap : PMC_QCAP) + 15) & ~(size_t)15;
     if (h->S > 1) b += (size_t)h->S * h->S * sizeof(DevModel);
     if (const char *e = getenv("PMC_LDS_PAD")) b += (size_t)atoi(e);   // occupancy experiments
     return b;
@@ -1582,7 +1660,23 @@ static size_t cb_lds_bytes(const pmc_system *h, int batch_nw = 0, int cap = 0)
     }
 // one wavefront per cell comes in two register budgets: 4 wavefronts per SIMD (128 VGPRs) pays when the LDS footprint lets
 // more than 12 workgroups share a CU, 3 (168 VGPRs) is ~5 % faster when it does not (cb_minwaves)
+// big neighbourhoods (cb_big; big_ of the caller's scope): the instance with the float copy in LDS; its dynamic LDS is beyond 64 KB,
+// which needs the attribute on the instance that is launched
+#define DISPATCH_CB_BIG(DD, KK, h, grid, lds, args)                                                             \
+    if (!done_ && big_ && !img_ && (h)->D == DD && (h)->kind == KK && (h)->team == 8) {                          \
+        const void *f_ = ((h)->S > 1 && one_) ? (const void *)k_cb_pass<DD, KK, true, 8, true, PMC_TEAM_MINWAVES, false, true>   \
+                       : ((h)->S > 1)       ? (const void *)k_cb_pass<DD, KK, true, 8, false, PMC_TEAM_MINWAVES, false, true>  \
+                       : one_               ? (const void *)k_cb_pass<DD, KK, false, 8, true, PMC_TEAM_MINWAVES, false, true>  \
+                                            : (const void *)k_cb_pass<DD, KK, false, 8, false, PMC_TEAM_MINWAVES, false, true>; \
+        if ((lds) > 64 * 1024) (void)hipFuncSetAttribute(f_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
+        const CbArgs *a_ = (args);                                                                              \
+        int n_ = nrep_;                                                                                         \
+        void *ka_[2] = {(void *)&a_, (void *)&n_};                                                              \
+        (void)hipLaunchKernel(f_, dim3(grid), dim3(64 * 8), ka_, lds, (h)->stream);                             \
+        done_ = true;                                                                                           \
+    }
 #define DISPATCH_CB_KIND(DD, KK, h, grid, lds, args)                                                            \
+    DISPATCH_CB_BIG(DD, KK, h, grid, lds, args)                                                                 \
     DISPATCH_CB_ONE(DD, KK, 1, 3, h, grid, lds, args)                                                           \
     DISPATCH_CB_ONE(DD, KK, 1, 4, h, grid, lds, args)                                                           \
     DISPATCH_CB_ONE(DD, KK, 2, PMC_TEAM_MINWAVES, h, grid, lds, args)                                           \
@@ -1879,6 +1973,76 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
     return PMC_OK;
 }
 
+// The chains of a `parallel = true` run on the literal loop (engine 1: VerletList, EmptyList systems beyond the LDS, swap pools
+// between a species and itself, or chains forced onto it), ALL IN ONE LAUNCH: workgroup b of k_ref_steps_many runs chain b from
+// its own entry of two device tables (any shape, any list type; one dimension per launch).  Every chain ends exactly as
+// pmc_sweep(PMC_SEQUENTIAL) on it alone (the same ref_steps).  Until round 5 these chains ran one after the other.
+static int sweep_sequential_ref_many(pmc_system **hs, int n, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    pmc_system *m = hs[0];
+    int rc = set_device(m);
+    if (rc) return rc;
+    std::vector<RefArgs> args((size_t)n);
+    std::vector<RefOp> ops((size_t)n);
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
+        if (int rs = refresh_stale_energy(h)) return rs;
+        HIPCHK(h, hipStreamSynchronize(h->stream));                    // earlier work on the chain's own stream
+        HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), m->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_energy, &h->energy, sizeof(double), hipMemcpyHostToDevice, m->stream));
+        args[(size_t)r] = ref_args(h);
+        RefOp &o = ops[(size_t)r];
+        memset(&o, 0, sizeof o);
+        o.op = OP_STEPS;
+        o.step0 = h->step_ctr;
+        o.nsteps = nsweeps * (int64_t)h->N;                             // sweepstep = N, src/ParticlesMC.jl:246
+        o.key0 = h->key[0];
+        o.key1 = h->key[1];
+        o.pool = make_pool(pool, npool);
+        o.stats = h->d_stats;
+    }
+    DevTmp d_args, d_ops;
+    HIPCHK(m, d_args.alloc((size_t)n * sizeof(RefArgs)));
+    HIPCHK(m, d_ops.alloc((size_t)n * sizeof(RefOp)));
+    HIPCHK(m, hipMemcpyAsync(d_args.p, args.data(), (size_t)n * sizeof(RefArgs), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(m, hipMemcpyAsync(d_ops.p, ops.data(), (size_t)n * sizeof(RefOp), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
+    if (m->D == 3) hipLaunchKernelGGL(k_ref_steps_many<3>, dim3(n), dim3(64), 0, m->stream, d_args.as<RefArgs>(), d_ops.as<RefOp>());
+    else hipLaunchKernelGGL(k_ref_steps_many<2>, dim3(n), dim3(64), 0, m->stream, d_args.as<RefArgs>(), d_ops.as<RefOp>());
+    HIPCHK(m, hipGetLastError());
+    HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
+    std::vector<unsigned long long> st((size_t)n * PMC_NSTATS);
+    for (int r = 0; r < n; r++) {
+        HIPCHK(hs[r], hipMemcpyAsync(&hs[r]->energy, hs[r]->d_energy, sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hs[r], hipMemcpyAsync(st.data() + (size_t)r * PMC_NSTATS, hs[r]->d_stats, PMC_NSTATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+    }
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, m->ev[0], m->ev[1]);
+    int first = PMC_OK;
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        h->mc_binned = false;
+        h->e_fix_valid = false;
+        h->img_valid = false;
+        h->step_ctr += (uint64_t)ops[(size_t)r].nsteps;
+        h->sweep_ctr += (uint64_t)nsweeps;
+        if (h->list_type >= 2 || h->d_cl_items) { const int re = ref_list_errors(h); if (re && !first) first = re; }
+        if (out) {
+            pmc_stats &o = out[r];
+            const unsigned long long *s_ = st.data() + (size_t)r * PMC_NSTATS;
+            for (int q = 0; q < PMC_MAX_MOVES; q++) { o.attempted[q] = (int64_t)s_[q]; o.accepted[q] = (int64_t)s_[8 + q]; }
+            o.kernel_ms = ms;
+            o.sweep_kernel_ms = ms;
+            o.sweep_kernel_launches = 1;
+            o.energy = h->energy;
+            o.energy_fix = 0;
+        }
+    }
+    return first;
+}
+
 // after a failed or partial throughput sweep: positions may have changed, so the running energy, the
 // cell-sorted copy, the reference lists and the SpeciesList are all recomputed by their next consumer
 static void cb_invalidate(pmc_system *h)
@@ -1942,9 +2106,9 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     if (h->S > 1 && nsweeps > 0) h->species_list_stale = true;
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, PMC_NSTATS * sizeof(unsigned long long), h->stream));
     const MovePool mp = make_pool(pool, npool);
-    const int ncol = 1 << h->D;
+    const int ncol = h->single_cell ? 1 : (1 << h->D);     // (a single-cell box has one colour)
     int nactive = 1;
-    for (int q = 0; q < h->D; q++) nactive *= h->grid.n[q] / 2;
+    for (int q = 0; q < h->D; q++) nactive *= std::max(1, h->grid.n[q] / 2);
     int cap_sweep = cb_cap_sweep(h);
     size_t lds = cb_lds_bytes(h, h->team >= 2 ? h->team : 0, cap_sweep);   // teams keep slot records and one survivor queue per wavefront in LDS
     int64_t launches = 0, timed_sweeps = 0;
@@ -1952,13 +2116,14 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
     // workgroup waits for were ticketed long before it (a pipeline with one tail per sweep); separate
     // colour launches sort each colour longest-first to shorten their eight tails
     const bool fused = h->use_fused;
-    const bool lpt = h->use_order && (!fused || h->fused_lpt == 1);
+    const bool lpt = h->use_order && (!fused || h->fused_lpt == 1) && !h->single_cell;
     const bool fuse_slots = h->N < 500000;   // small systems: slots generated inside pass C of the binning (one launch fewer)
     const int per_sweep = fused ? 1 : ncol;  // launches, and CbArgs entries, per sweep
     const MovePool &pool_ = mp;
     const int nrep_ = 1;
     const bool img_ = h->any_img;          // some particle carries a periodic image: the kernel instances with the image path
     int mw_ = cb_minwaves(h, lds);
+    const bool big_ = [&] { CbBig b; return !img_ && !getenv("PMC_CAP") && cb_big(h, h->team, &b) && cap_sweep == b.cap; }();   // (teams never re-learn their capacity)
     // long calls: the staging capacity is fitted again (cb_cap_learn) to what the last chunk of sweeps saw -- a first call on
     // a handle after 16 sweeps already
     const bool learn = cb_cap_sweep_adapts(h) && !async;
@@ -2008,6 +2173,7 @@ static int cb_enqueue_sweeps(pmc_system *h, const pmc_move *pool, int npool, int
             for (int q = 0; q < 3; q++) h->grid.shift[q] = shifts[(size_t)k][(size_t)q];
             CbArgs a = cb_args(h);
             a.cap = cap_sweep;
+            cb_apply_big(h, cap_sweep, a);
             a.order = lpt ? h->d_order : nullptr;
             a.slot_tlnu = slots.tlnu; a.slot_dx = slots.dx; a.slot_dy = slots.dy; a.slot_dz = slots.dz;
             a.slot_w1 = slots.w1; a.slot_w2 = slots.w2; a.slot_m = slots.m;
@@ -2288,6 +2454,20 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         }
         if (fast) return sweep_sequential_fast_many(hs, n, pool, npool, nsweeps, out);
     }
+    if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0) {
+        // chains only the literal loop serves (VerletList, EmptyList beyond the LDS, swaps within a species, engine 1 chosen): one
+        // launch, one workgroup per chain
+        bool lit = true;
+        for (int r = 0; r < n; r++) {
+            pmc_system *h = hs[r];
+            const bool fast_ok = h->seq_engine != 1 && (seq_fast_applicable(h, pool, npool) ||
+                                                        (seq_pool_ok(pool, npool) && h->seq_engine != 2 && seq_lds_fits(h, h->seq_engine == 3 ? SQ_LDS_MAX : SQ_LDS_AUTO)));
+            if (fast_ok) lit = false;
+            if (h->p.device != hs[0]->p.device || h->D != hs[0]->D) lit = false;
+            for (int q = 0; q < r; q++) if (hs[q] == h) lit = false;
+        }
+        if (lit) return sweep_sequential_ref_many(hs, n, pool, npool, nsweeps, out);
+    }
     if (mode != PMC_CHECKERBOARD || n == 1 || nsweeps == 0 || !many_compatible(hs, n)) {
         // different shapes, large systems (they fill the chip on their own) or the reference-order engine: one stream per handle
         int first = PMC_OK, begun = 0;
@@ -2336,9 +2516,16 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         h->count_is_zero = true;
     }
     const MovePool mp = make_pool(pool, npool);
-    const int ncol = 1 << m->D, N = m->N;
+    const int ncol = m->single_cell ? 1 : (1 << m->D), N = m->N;
     int nactive = 1;
-    for (int q = 0; q < m->D; q++) nactive *= m->grid.n[q] / 2;
+    for (int q = 0; q < m->D; q++) nactive *= std::max(1, m->grid.n[q] / 2);
+    // (one kernel instance serves the whole launch: a replica with periodic images takes the image instances, which have no
+    // big-neighbourhood form -- then no chain of the launch stages big)
+    struct NoBig {
+        pmc_system **hs; int n;
+        NoBig(pmc_system **hs_, int n_) : hs(hs_), n(n_) { bool any = false; for (int r = 0; r < n; r++) any = any || hs[r]->any_img; for (int r = 0; r < n; r++) hs[r]->no_big = any; }
+        ~NoBig() { for (int r = 0; r < n; r++) hs[r]->no_big = false; }
+    } nobig_guard(hs, n);
     int cap_sweep = 0;                                       // one LDS layout for all the replicas
     for (int r = 0; r < n; r++) cap_sweep = std::max(cap_sweep, cb_cap_sweep(hs[r]));
     const size_t lds = cb_lds_bytes(m, m->team >= 2 ? m->team : 0, cap_sweep);
@@ -2377,6 +2564,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
     bool img_ = false;                     // (the image instances serve replicas without images too: their pointers are null)
     for (int r = 0; r < n; r++) img_ = img_ || hs[r]->any_img;
     const int mw_ = cb_minwaves(m, lds);
+    const bool big_ = [&] { CbBig b; return !img_ && !getenv("PMC_CAP") && cb_big(m, m->team, &b) && cap_sweep == b.cap; }();
     const int grid = ncol * n * nactive;
     if (getenv("PMC_DEBUG_CAP")) fprintf(stderr, "[pmc many] chains %d team %d cap %d lds %zu minwaves %d\n", n, m->team, cap_sweep, lds, mw_);
     HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
@@ -2400,6 +2588,7 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
                 for (int q = 0; q < 3; q++) h->grid.shift[q] = st.shift[q];
                 CbArgs a = cb_args(h);
                 a.cap = cap_sweep;
+                cb_apply_big(h, cap_sweep, a);
                 const size_t Ns = (size_t)h->N * (size_t)h->slot_rounds;
                 a.order = nullptr;
                 a.slot_tlnu = h->d_slot_f; a.slot_dx = h->d_slot_f + Ns; a.slot_dy = h->d_slot_f + 2 * Ns; a.slot_dz = h->d_slot_f + 3 * Ns;

@@ -12,6 +12,8 @@
 #include <type_traits>
 
 #define PMC_CAP_MAX 1024     // upper bound of the per-wavefront LDS staging capacity (CbArgs::cap)
+#define PMC_CAP_BIG 4096     // ... of a TEAM's staging when its neighbourhoods outgrow the register copy of the pre-filter (CbArgs::fcap)
+#define PMC_SEGTAB_TEAM 64   // entries of a team's segment tables: compact_candidates counts up to 64 chunks of 64 candidates
 #define PMC_CFL 8            // centre-cell particles whose cell coordinates are cached (the staging of the teams; stays_in_cell)
 #ifndef PMC_FUSED_STAGE
 #define PMC_FUSED_STAGE true  // k_cb_pass applies the box filter while staging (stage_compacted)
@@ -40,6 +42,8 @@
 #define PMC_CB_VARIANTS(X)                                                                                   \
     PMC_CB_VARIANTS_NW(X, 1, 3) PMC_CB_VARIANTS_NW(X, 1, 4) PMC_CB_VARIANTS_NW(X, 2, PMC_TEAM_MINWAVES)       \
     PMC_CB_VARIANTS_NW(X, 4, PMC_TEAM_MINWAVES) PMC_CB_VARIANTS_NW(X, 8, PMC_TEAM_MINWAVES)
+// ... the big-neighbourhood instances (k_cb_pass<..., BIG = true>: teams of eight, no images): X(MULTI, ONE)
+#define PMC_CB_VARIANTS_BIG(X) X(false, false) X(false, true) X(true, false) X(true, true)
 // ... and the instances for systems in which some particle carries a periodic image (IMG = true; one register budget per team
 // width: PMC_IMG_MW): X(MULTI, NW, ONE).  Systems without images -- every run that starts folded -- run the kernels above, whose slot
 // loop does not contain a single instruction of the image path (compiled in, it cost them 1 % through register allocation alone).
@@ -58,13 +62,12 @@
                              // adds at most 128, a typical slot ends with ~70, and a slot that would overflow takes the direct loop
 #ifdef PMC_DEBUG_TIME   // profiling builds only: shader-clock stamps of wavefront 0, summed per phase into stats[32..]
 #define PMC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PMC_TIME(...) __VA_ARGS__     // code (or a struct member) that only the stamped build contains
 #else
 #define PMC_T(var)
+#define PMC_TIME(...)
 #endif
 
-#ifndef PMC_ECACHE_MINROUNDS
-#define PMC_ECACHE_MINROUNDS 2   // rounds per visit (schedule parameter m) from which re-picked particles reuse a cached energy
-#endif
 #define PMC_FTRIPS 8         // filter trips whose float coordinates a wavefront keeps in registers: 512 candidates
 
 // ------------------------------------------------------------------------------
@@ -628,6 +631,8 @@ struct CbArgs {
     DevModel m0;
     const DevModel *models;
     int cap;                   // candidates staged in LDS per wavefront (multiple of 64)
+    int fcap;                  // teams, big neighbourhoods: candidates whose FLOAT copy lives in LDS (0: none; the register copy holds 512)
+    int qcap;                  // entries of a wavefront's survivor queue (PMC_QCAP unless fcap > 0)
     double rc2pad;             // (largest cutoff)^2 * (1 + 1e-9): box-distance filter of the staging
     float rc2f;                // (largest cutoff)^2 * (1 + 2^-12), rounded up: threshold of the FP32 pre-filter (conservative)
     int filter;                // 1: drop candidates that are out of range of the whole centre cell
@@ -656,12 +661,6 @@ struct CbArgs {
 // Agent-scope accesses of the data that workgroups of one fused launch hand to each other (the
 // cell-sorted coordinates and species): sc1 loads bypass the CU's L1, sc1 stores write through
 // (cdna_hip_programming.md Guideline 16, R1).  Outside a fused launch they are merely uncached in L1.
-#ifdef PMC_EXP_PLAIN   // experiment only (valid with PMC_NO_FUSED=1): plain accesses instead of sc1
-__device__ __forceinline__ double ld_agent(const double *p) { return *p; }
-__device__ __forceinline__ unsigned char ld_agent(const unsigned char *p) { return *p; }
-__device__ __forceinline__ void st_agent(double *p, double v) { *p = v; }
-__device__ __forceinline__ void st_agent(unsigned char *p, unsigned char v) { *p = v; }
-#else
 __device__ __forceinline__ double ld_agent(const double *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -678,7 +677,6 @@ __device__ __forceinline__ void st_agent(unsigned char *p, unsigned char v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#endif
 
 // bijective remap so that blocks sharing an XCD (b % 8) work on one contiguous slab of cells
 // (used by k_total_energy and when the longest-first order is switched off)
@@ -711,13 +709,15 @@ struct WaveNbh {
     unsigned short *queue;   // [max(NW,1)][PMC_QCAP] survivor queues, one per wavefront
     double bc[3];            // centre of the centre cell (frame of its first particle)
     bool filt;               // the pre-filter is usable for this visit (everything staged, at most 64 PMC_FTRIPS candidates)
+    bool fstream;            // ... from the float copy in LDS (fx, fy, fz): a team's neighbourhood beyond the register copy
+    float *fx, *fy, *fz;     // [fcap] float images (rel_float) of the staged candidates, kept current by the team's resolution
+    int fcap, qcap;
     bool compacted;          // the box filter was applied while staging (stage_compacted)
     int kept;                // candidates that passed the box filter (stage_compacted; a huge value if it could not count them)
     int loaded;              // population of the 3^d cells the staging read from global memory
     int myimg;               // packed image of centre-cell particle `lane` (PMC_IMG_ZERO behind the last one)
-#ifdef PMC_DEBUG_TIME
-    unsigned long long ts[10];  // stamps inside stage_neighbourhood: entry, table ready, flags seen, coordinates arrived, done; [5..8] inside stage_compacted
-#endif
+    // (stamped builds: stamps inside stage_neighbourhood -- entry, table ready, flags seen, coordinates arrived, done; [5..8] inside stage_compacted)
+    PMC_TIME(unsigned long long ts[10];)
     // proposal-slot values of the first chunk, fetched together with the coordinates (latency-bound teams only)
     double p_tlnu, p_dx, p_dy, p_dz;
     uint32_t p_w1, p_w2;
@@ -791,9 +791,7 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
                 if (MULTI) ts[r] = ld_agent(a.ssp + s0 + lane);
             }
         }
-#ifdef PMC_DEBUG_TIME
-        if (b == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); h.ts[3] = __builtin_amdgcn_s_memtime(); }
-#endif
+    PMC_TIME(if (b == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); h.ts[3] = __builtin_amdgcn_s_memtime(); })
         if (!have_box) {
             const double ref[3] = {xr, yr, zr};
 #pragma unroll
@@ -804,9 +802,7 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
             }
             have_box = true;
         }
-#ifdef PMC_DEBUG_TIME
-        if (b == 0) h.ts[5] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(if (b == 0) h.ts[5] = __builtin_amdgcn_s_memtime();)
         // which candidates are in another periodic image than the reference particle (see the no-wrap test of
         // stage_neighbourhood); one that is not lies in the unfolded 3-cell span, where the minimum image below is the identity
         bool wr[NR];
@@ -823,9 +819,7 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
         }
         const bool fold = __builtin_amdgcn_ballot_w64(wrapped) != 0ull;
         wrapped_any = wrapped_any || fold;
-#ifdef PMC_DEBUG_TIME
-        if (b == 0) h.ts[6] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(if (b == 0) h.ts[6] = __builtin_amdgcn_s_memtime();)
         int cnt[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -852,9 +846,7 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
             keepm[r] = __builtin_amdgcn_ballot_w64(keep);
             cnt[r] = __popcll(keepm[r]);
         }
-#ifdef PMC_DEBUG_TIME
-        if (b == 0) h.ts[7] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(if (b == 0) h.ts[7] = __builtin_amdgcn_s_memtime();)
         if (NW > 1) {
             // every run belongs to one wavefront of the team: exchange the kept counts
 #pragma unroll
@@ -885,14 +877,12 @@ __device__ __forceinline__ bool stage_compacted(const CbArgs &a, WaveNbh &h, int
             base += cnt[r];
         }
     }
-#ifdef PMC_DEBUG_TIME
-    h.ts[8] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(h.ts[8] = __builtin_amdgcn_s_memtime();)
     if (NW > 1 && wrapped_any && lane == 0) atomicOr(&h.flag[0], 1);
     __syncthreads();
     h.kept = base;
     if (base > h.cap) return false;
-    h.nowrap = (NW > 1) ? (h.flag[0] == 0) : !wrapped_any;
+    h.nowrap = ((NW > 1) ? (h.flag[0] == 0) : !wrapped_any) && a.n[0] != 1;     // (single-cell box: pairs are up to L apart, see below)
     h.ctr = 0;
     h.ncand = base;
     h.nseg = 1;
@@ -914,9 +904,7 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
 {
     h.compacted = false;
     h.kept = 1 << 20;
-#ifdef PMC_DEBUG_TIME
-    h.ts[0] = h.ts[1] = h.ts[2] = h.ts[3] = h.ts[4] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(h.ts[0] = h.ts[1] = h.ts[2] = h.ts[3] = h.ts[4] = __builtin_amdgcn_s_memtime();)
     constexpr int NN = (D == 3) ? 27 : 9;
     constexpr int NR = (D == 3) ? 9 : 3;
     bool poll_need = false;
@@ -996,16 +984,19 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
             // lane 0 <-> centre (offset index (NN-1)/2), that lane takes offset 0
             int o = (lane == 0) ? (NN - 1) / 2 : ((lane == (NN - 1) / 2) ? 0 : lane);
             int lin2 = 0, r = o;
+            bool dup = false;          // single-cell boxes (n = 1): the cell is its own neighbour once, not 3^d times
 #pragma unroll
             for (int q = 0; q < D; q++) {
-                int cq = cell[q] + (r % 3) - 1;
+                const int off = (r % 3) - 1;
+                int cq = cell[q] + off;
                 r /= 3;
+                dup = dup || (a.n[q] == 1 && off != 0);
                 if (cq < 0) cq += a.n[q];
                 if (cq >= a.n[q]) cq -= a.n[q];
                 lin2 = lin2 * a.n[q] + cq;
             }
             seg_start = a.start[lin2];
-            seg_cnt = a.start[lin2 + 1] - seg_start;
+            seg_cnt = dup ? 0 : a.start[lin2 + 1] - seg_start;
         }
     }
     int incl = seg_cnt;
@@ -1028,9 +1019,7 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         if (lane == 0) h.segoff[h.nseg] = h.ncand;
     }
     const int lim = min(h.ncand, h.cap);
-#ifdef PMC_DEBUG_TIME
-    h.ts[1] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(h.ts[1] = __builtin_amdgcn_s_memtime();)
     if (wait_colour > 0) {
         // a workgroup only ever waits for workgroups that already hold a ticket (see k_cb_pass): no deadlock; a bounded
         // spin turns a lost flag into an error code (stats[17] bit 1) instead of a hang
@@ -1048,9 +1037,7 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         }
         __syncthreads();
     }
-#ifdef PMC_DEBUG_TIME
-    h.ts[2] = h.ts[3] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(h.ts[2] = h.ts[3] = __builtin_amdgcn_s_memtime();)
     if (NW >= 4) {
         // (defined on every path: cb_visit reads them whenever NW >= 4)
         h.p_tlnu = h.p_dx = h.p_dy = h.p_dz = 0.0;
@@ -1077,9 +1064,7 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
         if (ok) {
             h.have_cfl = false;        // (h.fc is set; the rare exact 'stays in its cell' test divides for itself)
             __syncthreads();           // the segment table of the compacted layout is visible
-#ifdef PMC_DEBUG_TIME
-            h.ts[4] = __builtin_amdgcn_s_memtime();
-#endif
+    PMC_TIME(h.ts[4] = __builtin_amdgcn_s_memtime();)
             return;
         }
         // (rare) a segment longer than a wavefront, or more survivors than the capacity: the old way, overflow loops and all
@@ -1165,6 +1150,9 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
             __syncthreads();
             h.nowrap = (h.flag[0] == 0);
         }
+        // (a single-cell box: the candidates are the whole periodic box, two of them can be a box length apart however close
+        // each is to the reference particle: the minimum image stays in every pair distance)
+        if (a.n[0] == 1) h.nowrap = false;
     }
     if (tid < min(h.nc, PMC_CFL) && h.ctr + tid < h.cap) {
         h.cfl[0 * PMC_CFL + tid] = mc_coord<D>(h.cx[h.ctr + tid], a.shift[0], a.w[0]);
@@ -1183,13 +1171,14 @@ __device__ __forceinline__ void stage_neighbourhood(const CbArgs &a, const int c
 // staged candidates in place (LDS -> registers -> LDS), keeping the centre cell contiguous.
 // Preconditions: everything is staged (ncand <= cap) and the centre particles' cell coordinates
 // are cached (cfl).  About 30 % of a 27-cell neighbourhood goes away at w ~ rcut.
-template <int D, bool MULTI, int NW>
+template <int D, bool MULTI, int NW, bool BIG = false>
 __device__ __forceinline__ void compact_candidates(const CbArgs &a, WaveNbh &h)
 {
     constexpr int MAXC = 8;                       // chunks of 64 candidates per wavefront held in registers
     const int lane = wave_lane(), wv = team_wave<NW>();
     const int nchunk = (h.ncand + PMC_WAVE - 1) / PMC_WAVE;
-    if (h.compacted || !a.filter || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW || nchunk > 32) return;   // segoff holds 32 chunk counts
+    constexpr int SEGN = BIG ? PMC_SEGTAB_TEAM : 32;                   // chunk counts segoff holds
+    if (h.compacted || !a.filter || h.nc == 0 || h.ncand > h.cap || nchunk > MAXC * NW || nchunk > SEGN) return;
     // box centre (in the frame of the first centre particle) and padded half width; candidates in
     // another periodic image are brought to the box by the minimum image (|t| <= 2 w <= L/2)
     double bc[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
@@ -1231,7 +1220,7 @@ __device__ __forceinline__ void compact_candidates(const CbArgs &a, WaveNbh &h)
             keep = (k >= h.ctr && k < h.ctr + h.nc) || !(d2 > a.rc2pad);
         }
         keepm[c] = __ballot(keep);
-        if (lane == 0 && chunk < 32) h.segoff[chunk] = __popcll(keepm[c]);   // kept count of this chunk
+        if (lane == 0 && chunk < SEGN) h.segoff[chunk] = __popcll(keepm[c]);   // kept count of this chunk
     }
     __syncthreads();                              // all reads of the old layout are done; counts published
     int base_of[MAXC];
@@ -1326,23 +1315,9 @@ __device__ __forceinline__ double dpp_add(double v)
 
 // Sum over the 64 lanes of values that add EXACTLY (multiples of 2^-32, see dev_quant), so
 // the association below is free to differ from any other and still give the same bits.
-// With -DPMC_MFMA_REDUCE the sum is taken by the matrix core: v_mfma_f64_16x16x4 with a matrix of ones adds the four lanes
-// {i, i+16, i+32, i+48} (every product is v * 1.0, every partial sum exact), three adds fold the four result registers, and a
-// second MFMA adds the four 16-lane groups -- the total arrives in every lane.  2 MFMA + 3 VALU instructions instead of 18 + 2.
-#ifdef PMC_MFMA_REDUCE
-typedef double pmc_v4d __attribute__((ext_vector_type(4)));
+// (The same sum on the matrix core -- v_mfma_f64_16x16x4 with a matrix of ones -- is exact too and was measured 7 % slower:
+// its latency sits on the slot's critical path.  LAB.md, round 3.)
 __device__ __forceinline__ double wave_sum_exact(double v)
-{
-    const pmc_v4d z = {0.0, 0.0, 0.0, 0.0};
-    const pmc_v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, z, 0, 0, 0);
-    const double t = (d.x + d.y) + (d.z + d.w);
-    const pmc_v4d e = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, z, 0, 0, 0);
-    return e.x;
-}
-__device__ __forceinline__ double wave_sum_exact_dpp(double v)
-#else
-__device__ __forceinline__ double wave_sum_exact(double v)
-#endif
 {
     v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
@@ -1444,12 +1419,34 @@ __device__ __forceinline__ void load_fregs(const CbArgs &a, const WaveNbh &h, FR
 
 // after the box filter has compacted the staged candidates: decide whether the pre-filter applies to this visit and
 // load every wavefront's register copy
-template <int D>
+template <int D, int NW = 1, bool BIG = false>
 __device__ __forceinline__ void prepare_filter(const CbArgs &a, WaveNbh &h, FRegs &f)
 {
 #pragma unroll
     for (int q = 0; q < 3; q++) h.bc[q] = (q < D) ? a.shift[q] + (h.fc[q] + 0.5) * a.w[q] : 0.0;
-    h.filt = (h.nc > 0) && (h.ncand <= h.cap) && (h.ncand <= PMC_FTRIPS * PMC_WAVE);
+    // (single-cell boxes: differences of two folded float coordinates need the minimum image themselves, which only the streamed
+    // filter of the big-neighbourhood instances applies; the other instances take the direct FP64 loop there)
+    h.filt = (h.nc > 0) && (h.ncand <= h.cap) && (h.ncand <= PMC_FTRIPS * PMC_WAVE) && a.n[0] != 1;
+    if (BIG && !h.filt && h.fcap > 0 && h.nc > 0 && h.ncand <= h.cap && h.ncand <= h.fcap) {
+        // A neighbourhood beyond the 512 candidates of the register copy (boxes of 4-5 cutoffs per side at liquid density: 3^d cells
+        // of a hundred particles each) that still fits the LDS: the team shares ONE float copy in LDS and every slot's filter
+        // streams it, two trips at a time, into the same survivor queue.  Until round 5 such a slot took the direct FP64 loop over
+        // every candidate at both positions.
+        for (int k = team_tid<NW>(); k < h.ncand; k += NW * PMC_WAVE) {
+            if (h.nowrap) {
+                h.fx[k] = rel_float<true>(h.cx[k], h.bc[0], a.L[0], a.invL[0]);
+                h.fy[k] = rel_float<true>(h.cy[k], h.bc[1], a.L[1], a.invL[1]);
+                h.fz[k] = (D == 3) ? rel_float<true>(h.cz[k], h.bc[2], a.L[2], a.invL[2]) : 0.0f;
+            } else {
+                h.fx[k] = rel_float<false>(h.cx[k], h.bc[0], a.L[0], a.invL[0]);
+                h.fy[k] = rel_float<false>(h.cy[k], h.bc[1], a.L[1], a.invL[1]);
+                h.fz[k] = (D == 3) ? rel_float<false>(h.cz[k], h.bc[2], a.L[2], a.invL[2]) : 0.0f;
+            }
+        }
+        h.fstream = true;
+        __syncthreads();
+        return;
+    }
     if (!h.filt) return;
     if (h.nowrap) load_fregs<D, true>(a, h, f); else load_fregs<D, false>(a, h, f);
 }
@@ -1528,18 +1525,14 @@ struct PairCount {
     unsigned dense;               // FP64 distance evaluations: (queue entry, old | new position) of the filtered path, every (candidate, position) of the direct one
     bool count_dense;             // ... counted only by the kernels that have a register for it: one wavefront per cell, one species (the
                                   // benchmark's instance carries it for free; in the others it cost 8-24 B of scratch per lane)
-#ifdef PMC_DEBUG_TIME
-    unsigned long long t_filter, t_dense;
-#endif
+    PMC_TIME(unsigned long long t_filter, t_dense;)
 };
 
 // the FP64 evaluation of the queued survivors [0, qn) of one slot; returns this lane's partial sum
 // SWAP (DiscreteSwap of the particles in LDS slots pc and pj, species sa <-> sb; `si` carries sa): the two "positions" are the
 // two particles, which do not move; a lane adds the pair energy with the species its particle takes and subtracts the one with
 // the species it has (the terms of src/moves.jl:189-207 = swap_delta below, candidate by candidate).
-// NEWONLY (a slot whose particle's energy at its present position is cached, PMC_ECACHE): the entries passed the filter at the
-// new position and every lane takes one of them there.
-template <int D, int KIND, bool MULTI, bool NOWRAP, bool SWAP = false, bool NEWONLY = false>
+template <int D, int KIND, bool MULTI, bool NOWRAP, bool SWAP = false>
 __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h, const DevModel *tab, const unsigned short *queue,
                                               int qn, int pc, int si, double xo, double yo, double zo, double xn, double yn, double zn,
                                               PairCount &pcnt, int pj = 0, int sb = 0)
@@ -1555,14 +1548,14 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
     // neighbouring lanes: even lanes take the old position (and subtract), odd lanes the new one (and add).  Which of the
     // two a lane takes never changes, so the position is picked once per slot instead of once per trip, and the exact test
     // `r2 > rcut2` below drops the half of a pair that only rode along.
-    const bool isnew = NEWONLY || (lane & 1) != 0;
+    const bool isnew = (lane & 1) != 0;
     const double xi = isnew ? xn : xo, yi = isnew ? yn : yo, zi = isnew ? zn : zo;
-    const int qe = NEWONLY ? qn : 2 * qn;
+    const int qe = 2 * qn;
     if (pcnt.count_dense) pcnt.dense += (unsigned)qe;
     for (int e0 = 0; e0 < qe; e0 += PMC_WAVE) {
         // lanes behind the last entry re-read it (no branch around the loads) and are masked out of the range test
         const int e = min(e0 + lane, qe - 1);
-        const int k = (int)queue[NEWONLY ? e : (e >> 1)];
+        const int k = (int)queue[e >> 1];
         const double xj = h.cx[k], yj = h.cy[k], zj = (D == 3) ? h.cz[k] : 0.0;
         const double r2 = NOWRAP ? dist2_nowrap<D>(xi, yi, zi, xj, yj, zj) : dist2_fast<D>(a, xi, yi, zi, xj, yj, zj);
         if (SWAP && MULTI) {
@@ -1591,13 +1584,12 @@ __device__ __forceinline__ double queue_flush(const CbArgs &a, const WaveNbh &h,
 // wavefront, result in every lane.  f = this wavefront's register copy; fo* / fn* = float images of the old and new
 // position (rel_float).  Requires h.filt.  `overflow` is set (and nothing returned) when the survivor queue cannot hold
 // the next trip: the caller then takes the direct loop for this slot (dense clusters only).
-// NEWONLY: the energy at the new position alone (returned); otherwise dE, and with `enew` also the new position's part of it.
-template <int D, int KIND, bool MULTI, bool SWAP = false, bool NEWONLY = false>
+template <int D, int KIND, bool MULTI, bool SWAP = false, bool STREAM = false>
 __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
                                                         const FRegs &f, int pc, int si, double xo, double yo, double zo,
                                                         double xn, double yn, double zn, float fxo, float fyo, float fzo,
                                                         float fxn, float fyn, float fzn, PairCount &pcnt, bool &overflow,
-                                                        int pj = 0, int sb = 0, double *enew = nullptr)
+                                                        int pj = 0, int sb = 0)
 {
     const int lane = wave_lane();
     // wave-uniform values the compiler cannot prove uniform (they come from loads and cross-lane moves): pin them to
@@ -1648,28 +1640,51 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
         if (b1) (queue + q1)[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)k1;
         qn = q1 + (unsigned)__popcll(m1);
     };
-    // new position only: the two halves of a packed operation take two trips
-    auto trips2n = [&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        const f2 qx = {fxn, fxn}, qy = {fyn, fyn}, qz = {fzn, fzn};
-        const f2 cx = {f.x[J], f.x[J + 1]}, cy = {f.y[J], f.y[J + 1]};
-        const f2 dx = cx - qx, dy = cy - qy;
-        f2 r2 = __builtin_elementwise_fma(dy, dy, dx * dx);
-        if (D == 3) {
-            const f2 cz = {f.z[J], f.z[J + 1]};
-            const f2 dz = cz - qz;
-            r2 = __builtin_elementwise_fma(dz, dz, r2);
-        }
-        const bool b0 = (r2.x <= thr), b1 = (r2.y <= thr);
-        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0), m1 = __builtin_amdgcn_ballot_w64(b1);
-        const unsigned k0 = (unsigned)lane + (unsigned)(J * PMC_WAVE), k1 = k0 + (unsigned)PMC_WAVE;
-        const unsigned q0 = qn, q1 = q0 + (unsigned)__popcll(m0);
-        if (b0) (queue + q0)[__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = (unsigned short)k0;
-        if (b1) (queue + q1)[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)k1;
-        qn = q1 + (unsigned)__popcll(m1);
-    };
-    auto trips = [&](auto jc) { if constexpr (NEWONLY) trips2n(jc); else trips2(jc); };
+    auto trips = [&](auto jc) { trips2(jc); };
     static_assert(PMC_FTRIPS == 8 && PMC_QCAP >= 2 * 2 * PMC_WAVE, "the first two pairs of trips must fit the queue unchecked");
+    if constexpr (STREAM) {
+        // the float copy of a big neighbourhood lives in LDS (prepare_filter): the same test, two trips of 64 candidates at a time
+        const float nanf_ = __builtin_nanf("");
+        // single-cell box: both float coordinates are folded to within L/2 of the cell centre, their difference can be up to L:
+        // d -= L rint(d / L) in float.  (A pair inside the cutoff has |d_true| <= rcut <= L/2 (1 - 2^-10): the host only
+        // takes boxes of >= 2 (1 + 2^-10) cutoffs as single cells, so its quotient is >= 4.9e-4 from a half-integer, three orders
+        // above the float error of d / L, and rint picks the right image; where it might not, the pair is beyond the cutoff.)
+        const bool single = (a.n[0] == 1);
+        const f2 Lx = {(float)a.L[0], (float)a.L[0]}, Ly = {(float)a.L[1], (float)a.L[1]}, Lz = {(float)a.L[2], (float)a.L[2]};
+        const f2 iLx = {(float)a.invL[0], (float)a.invL[0]}, iLy = {(float)a.invL[1], (float)a.invL[1]}, iLz = {(float)a.invL[2], (float)a.invL[2]};
+        auto wrap = [](f2 d, f2 L, f2 iL) -> f2 {
+            const f2 q = d * iL;
+            const f2 n = {__builtin_rintf(q.x), __builtin_rintf(q.y)};
+            return __builtin_elementwise_fma(-n, L, d);
+        };
+        for (int base = 0; base < nrun; base += 2 * PMC_WAVE) {
+            if (qn > (unsigned)(h.qcap - 2 * PMC_WAVE)) { overflow = true; break; }
+            f2 r2[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int k = base + t * PMC_WAVE + lane;
+                const bool live = k < ncand;
+                const float vx = live ? h.fx[k] : nanf_, vy = live ? h.fy[k] : nanf_, vz = (D == 3 && live) ? h.fz[k] : 0.0f;
+                const f2 cx = {vx, vx}, cy = {vy, vy};
+                f2 dx = cx - px, dy = cy - py;
+                if (single) { dx = wrap(dx, Lx, iLx); dy = wrap(dy, Ly, iLy); }
+                r2[t] = __builtin_elementwise_fma(dy, dy, dx * dx);
+                if (D == 3) {
+                    const f2 cz = {vz, vz};
+                    f2 dz = cz - pz;
+                    if (single) dz = wrap(dz, Lz, iLz);
+                    r2[t] = __builtin_elementwise_fma(dz, dz, r2[t]);
+                }
+            }
+            const bool b0 = (r2[0].x <= thr) | (r2[0].y <= thr), b1 = (r2[1].x <= thr) | (r2[1].y <= thr);
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0), m1 = __builtin_amdgcn_ballot_w64(b1);
+            const unsigned k0 = (unsigned)(base + lane), k1 = k0 + (unsigned)PMC_WAVE;
+            const unsigned q0 = qn, q1 = q0 + (unsigned)__popcll(m0);
+            if (b0) (queue + q0)[__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = (unsigned short)k0;
+            if (b1) (queue + q1)[__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)k1;
+            qn = q1 + (unsigned)__popcll(m1);
+        }
+    } else {
     if (nrun > 0) trips(std::integral_constant<int, 0>{});
     if (nrun > 2 * PMC_WAVE) trips(std::integral_constant<int, 2>{});
     if (nrun > 4 * PMC_WAVE) {
@@ -1679,18 +1694,19 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
     if (nrun > 6 * PMC_WAVE && !overflow) {
         if (qn > (unsigned)(PMC_QCAP - 2 * PMC_WAVE)) overflow = true; else trips(std::integral_constant<int, 6>{});
     }
+    }
     if (overflow) return 0.0;
-    pcnt.tests += (NEWONLY ? 1u : 2u) * (unsigned)ncand;
+    pcnt.tests += 2u * (unsigned)ncand;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PMC_T(tf_1);
-    double acc = h.nowrap ? queue_flush<D, KIND, MULTI, true, SWAP, NEWONLY>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb)
-                          : queue_flush<D, KIND, MULTI, false, SWAP, NEWONLY>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb);
+    double acc = h.nowrap ? queue_flush<D, KIND, MULTI, true, SWAP>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb)
+                          : queue_flush<D, KIND, MULTI, false, SWAP>(a, h, tab, queue, (int)qn, pc, si, xo, yo, zo, xn, yn, zn, pcnt, pj, sb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef PMC_DEBUG_TIME
+    PMC_TIME(
     {
         // the stamp must not be taken before the FP64 work has finished: make it depend on the sum
         const double probe = acc;
@@ -1699,8 +1715,7 @@ __device__ __forceinline__ double wave_delta_e_filtered(const CbArgs &a, const W
         pcnt.t_filter += tf_1 - tf_0;
         pcnt.t_dense += tf_2 - tf_1;
     }
-#endif
-    if (!NEWONLY && !SWAP && enew) *enew = wave_sum_exact((lane & 1) ? acc : 0.0);      // the odd lanes took the new position
+    )
     return wave_sum_exact(acc);
 }
 
@@ -1710,12 +1725,30 @@ __device__ __forceinline__ double wave_delta_e_direct(const CbArgs &a, const Wav
                                                       double xo, double yo, double zo, double xn, double yn, double zn,
                                                       PairCount &pcnt);
 
-template <int D, int KIND, bool MULTI>
+template <int D, int KIND, bool MULTI, bool TEAM = false>
 __device__ __forceinline__ double wave_delta_e(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
                                                const FRegs &f, int pc, int si, double xo, double yo, double zo, double xn,
-                                               double yn, double zn, float &fxn, float &fyn, float &fzn, PairCount &pcnt,
-                                               double *enew = nullptr, bool *got_enew = nullptr)
+                                               double yn, double zn, float &fxn, float &fyn, float &fzn, PairCount &pcnt)
 {
+    if (TEAM && h.fstream) {
+        // the filter streams the team's float copy in LDS, which also holds the particle's own image (kept current)
+        fzn = 0.0f;
+        if (h.nowrap) {
+            fxn = rel_float<true>(xn, h.bc[0], a.L[0], a.invL[0]);
+            fyn = rel_float<true>(yn, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) fzn = rel_float<true>(zn, h.bc[2], a.L[2], a.invL[2]);
+        } else {
+            fxn = rel_float<false>(xn, h.bc[0], a.L[0], a.invL[0]);
+            fyn = rel_float<false>(yn, h.bc[1], a.L[1], a.invL[1]);
+            if (D == 3) fzn = rel_float<false>(zn, h.bc[2], a.L[2], a.invL[2]);
+        }
+        const float fxo = h.fx[pc], fyo = h.fy[pc], fzo = (D == 3) ? h.fz[pc] : 0.0f;
+        bool overflow;
+        const double de = wave_delta_e_filtered<D, KIND, MULTI, false, TEAM>(a, h, tab, queue, f, pc, si, xo, yo, zo, xn, yn, zn,
+                                                                             fxo, fyo, fzo, fxn, fyn, fzn, pcnt, overflow);
+        if (!overflow) return de;
+        return wave_delta_e_direct<D, KIND, MULTI>(a, h, tab, pc, si, xo, yo, zo, xn, yn, zn, pcnt);
+    }
     if (h.filt) {
         float fxo, fyo, fzo = 0.0f;
         fzn = 0.0f;
@@ -1746,31 +1779,10 @@ __device__ __forceinline__ double wave_delta_e(const CbArgs &a, const WaveNbh &h
         }
         bool overflow;
         const double de = wave_delta_e_filtered<D, KIND, MULTI>(a, h, tab, queue, f, pc, si, xo, yo, zo, xn, yn, zn,
-                                                                fxo, fyo, fzo, fxn, fyn, fzn, pcnt, overflow, 0, 0, enew);
-        if (!overflow) { if (got_enew) *got_enew = true; return de; }
+                                                                fxo, fyo, fzo, fxn, fyn, fzn, pcnt, overflow);
+        if (!overflow) return de;
     }
     return wave_delta_e_direct<D, KIND, MULTI>(a, h, tab, pc, si, xo, yo, zo, xn, yn, zn, pcnt);
-}
-
-// The energy of the particle in LDS slot pc at its trial position alone (PMC_ECACHE: its energy at the present position is
-// cached).  Requires h.filt; `overflow` as in wave_delta_e_filtered (the caller then takes the full evaluation).
-template <int D, int KIND, bool MULTI>
-__device__ __forceinline__ double wave_e_new(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
-                                             const FRegs &f, int pc, int si, double xn, double yn, double zn,
-                                             float &fxn, float &fyn, float &fzn, PairCount &pcnt, bool &overflow)
-{
-    fzn = 0.0f;
-    if (h.nowrap) {
-        fxn = rel_float<true>(xn, h.bc[0], a.L[0], a.invL[0]);
-        fyn = rel_float<true>(yn, h.bc[1], a.L[1], a.invL[1]);
-        if (D == 3) fzn = rel_float<true>(zn, h.bc[2], a.L[2], a.invL[2]);
-    } else {
-        fxn = rel_float<false>(xn, h.bc[0], a.L[0], a.invL[0]);
-        fyn = rel_float<false>(yn, h.bc[1], a.L[1], a.invL[1]);
-        if (D == 3) fzn = rel_float<false>(zn, h.bc[2], a.L[2], a.invL[2]);
-    }
-    return wave_delta_e_filtered<D, KIND, MULTI, false, true>(a, h, tab, queue, f, pc, si, xn, yn, zn, xn, yn, zn,
-                                                              fxn, fyn, fzn, fxn, fyn, fzn, pcnt, overflow);
 }
 
 // The same dE by the direct loop (every candidate tested in FP64): visits whose neighbourhood does not fit the LDS
@@ -1877,10 +1889,20 @@ __device__ __forceinline__ double swap_delta(const CbArgs &a, const WaveNbh &h, 
 // dE of one DiscreteSwap slot by one wavefront: through the pre-filter and the survivor queue where they apply (the two
 // particles play the part of the old and the new position: neither moves, so the register copy holds both), the direct loop
 // of swap_delta otherwise.  A swap used to cost 3.4 Displacement slots -- and a team's batch waits for its slowest slot.
-template <int D, int KIND, bool MULTI>
+template <int D, int KIND, bool MULTI, bool TEAM = false>
 __device__ __forceinline__ double wave_swap_delta(const CbArgs &a, const WaveNbh &h, const DevModel *tab, unsigned short *queue,
                                                   const FRegs &f, int pi, int pj, int sa, int sb, PairCount &pcnt)
 {
+    if (MULTI && TEAM && h.fstream) {
+        const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
+        const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
+        bool overflow;
+        const double de = wave_delta_e_filtered<D, KIND, MULTI, true, TEAM>(a, h, tab, queue, f, pi, sa, xi, yi, zi, xj, yj, zj,
+                                                                            h.fx[pi], h.fy[pi], (D == 3) ? h.fz[pi] : 0.0f,
+                                                                            h.fx[pj], h.fy[pj], (D == 3) ? h.fz[pj] : 0.0f, pcnt, overflow, pj, sb);
+        if (!overflow) return de;
+        return swap_delta<D, KIND, MULTI, 1>(a, h, tab, pi, pj, sa, sb);
+    }
     if (MULTI && h.filt) {
         const double xi = h.cx[pi], yi = h.cy[pi], zi = (D == 3) ? h.cz[pi] : 0.0;
         const double xj = h.cx[pj], yj = h.cy[pj], zj = (D == 3) ? h.cz[pj] : 0.0;
@@ -1905,18 +1927,20 @@ __device__ __forceinline__ double wave_swap_delta(const CbArgs &a, const WaveNbh
 // LDS bytes of one workgroup: coordinates, cached cell coordinates, partial sums, [batch records],
 // flags, counters, segment tables, [species].  Kept small on purpose: at N = 10^6 (cap 512) a team of
 // two wavefronts needs <= 13 312 B for twelve workgroups (six wavefronts per SIMD) per CU.
-__host__ __device__ inline size_t pmc_lds_wave_bytes(int cap, bool multi, int batch_nw)
+__host__ __device__ inline size_t pmc_lds_wave_bytes(int cap, bool multi, int batch_nw, int fcap = 0, int qcap = PMC_QCAP)
 {
     // one wavefront per cell (batch_nw == 0): no partial sums, and the segment tables share the survivor queue's bytes -- a visit
     // either reads candidates beyond the LDS capacity through the tables (direct loop, no queue) or queues survivors
     // (everything staged, tables never read): 10 224 B at cap = 384, the 16th workgroup of a CU
     if (batch_nw == 0)
         return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 4 * 4 + 16 * 4 + 24 * 4 + (size_t)PMC_QCAP * 2 + (multi ? cap : 0);
-    return (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (size_t)(2 * PMC_REC * batch_nw + batch_nw * batch_nw) * 8 + 4 * 4 + 16 * 4 +
-           24 * 4 + 2 * 32 * 4 + (size_t)batch_nw * PMC_QCAP * 2 + (multi ? cap : 0);
+    // (big neighbourhoods, fcap > 0: segment tables of PMC_SEGTAB_TEAM entries, queues of qcap entries, and the float copy)
+    const size_t b = (size_t)3 * cap * 8 + 3 * PMC_CFL * 8 + 8 * 8 + (size_t)(2 * PMC_REC * batch_nw + batch_nw * batch_nw) * 8 + 4 * 4 + 16 * 4 +
+                     24 * 4 + 2 * (fcap > 0 ? PMC_SEGTAB_TEAM : 32) * 4 + (size_t)batch_nw * qcap * 2 + (multi ? cap : 0);
+    return fcap > 0 ? ((b + 15) & ~(size_t)15) + (size_t)3 * fcap * 4 : b;
 }
 
-template <int D, bool MULTI, int BATCH = 0>   // BATCH: team size of the speculative slot batches (0: none)
+template <int D, bool MULTI, int BATCH = 0, bool BIG = false>   // BATCH: team size of the speculative slot batches (0: none); BIG: see k_cb_pass
 __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned char *smem, WaveNbh &h)
 {
     h.cap = a.cap;
@@ -1931,18 +1955,29 @@ __device__ __forceinline__ const DevModel *setup_lds(const CbArgs &a, unsigned c
     h.cnt = h.flag + 4;
     h.ptab = h.cnt + 16;
     static_assert(PMC_QCAP * 2 >= 2 * 32 * 4, "the segment tables fit into a survivor queue");
+    h.qcap = BIG ? a.qcap : PMC_QCAP;
+    h.fcap = BIG ? a.fcap : 0;
+    constexpr int SEGN = BIG ? PMC_SEGTAB_TEAM : 32;
     if (BATCH > 0) {
         h.segoff = h.ptab + 24;
-        h.segsrc = h.segoff + 32;
-        h.queue = reinterpret_cast<unsigned short *>(h.segsrc + 32);
+        h.segsrc = h.segoff + SEGN;
+        h.queue = reinterpret_cast<unsigned short *>(h.segsrc + SEGN);
     } else {
         h.segoff = h.ptab + 24;                // (see pmc_lds_wave_bytes: shared with the queue)
         h.segsrc = h.segoff + 32;
         h.queue = reinterpret_cast<unsigned short *>(h.segoff);
     }
-    h.csp = reinterpret_cast<unsigned char *>(h.queue + (BATCH > 0 ? BATCH : 1) * PMC_QCAP);
+    h.csp = reinterpret_cast<unsigned char *>(h.queue + (BATCH > 0 ? BATCH : 1) * h.qcap);
     h.filt = false;
-    DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap, MULTI, BATCH) + 15) & ~(size_t)15));
+    h.fstream = false;
+    h.fx = h.fy = h.fz = nullptr;
+    if (BIG && h.fcap > 0) {
+        // (behind everything else of the big layout -- its wider segment tables included: pmc_lds_wave_bytes adds the float copy last)
+        h.fx = reinterpret_cast<float *>(smem + pmc_lds_wave_bytes(h.cap, MULTI, BATCH, h.fcap, h.qcap) - (size_t)3 * h.fcap * 4);
+        h.fy = h.fx + h.fcap;
+        h.fz = h.fy + h.fcap;
+    }
+    DevModel *tab = reinterpret_cast<DevModel *>(smem + ((pmc_lds_wave_bytes(h.cap, MULTI, BATCH, h.fcap, h.qcap) + 15) & ~(size_t)15));
     if (MULTI) {
         for (int k = threadIdx.x; k < a.S * a.S; k += blockDim.x) tab[k] = a.models[k];
         __syncthreads();
@@ -2061,12 +2096,10 @@ struct CbTotals {
     unsigned long long nnull;
     unsigned long long tests, energies;
     PairCount pcnt;                  // per-wavefront work counters of the current visit
-#ifdef PMC_DEBUG_TIME
-    unsigned long long tp[16];
-#endif
+    PMC_TIME(unsigned long long tp[16];)
 };
 
-template <int D, int KIND, bool MULTI, int NW, bool ONE, bool IMG>
+template <int D, int KIND, bool MULTI, int NW, bool ONE, bool IMG, bool BIG = false>
 __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevModel *tab, int colour, int aidx,
                                          unsigned long long *st, CbTotals &tot)
 {
@@ -2076,13 +2109,13 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     // one wavefront evaluates one slot alone (FP32 pre-filter, survivor queue, dense FP64: wave_delta_e_filtered);
     // teams of NW >= 2 wavefronts evaluate NW slots of the cell speculatively at once and resolve them in order
     constexpr bool BATCH = (NW >= 2);
-    unsigned short *const my_queue = h.queue + wv * PMC_QCAP;
+    unsigned short *const my_queue = h.queue + wv * h.qcap;
     PairCount &pcnt = tot.pcnt;
     unsigned nnull = 0;
-#ifdef PMC_DEBUG_TIME
+    PMC_TIME(
     unsigned long long tp_pro = 0, tp_red = 0, tp_n = 0;
     const unsigned long long tf_base = pcnt.t_filter, td_base = pcnt.t_dense;
-#endif
+    )
     PMC_T(t_0);
     // The instruction arbiter prefers the oldest wavefront of a SIMD, so a workgroup that has just started -- the one whose
     // offsets, flags and coordinates are still to be requested -- issues last.  Raised priority until the slot loop gets
@@ -2100,11 +2133,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     // teams take the fused staging only in the multi-species instances, and there only where a.fuse_teams says so (dense
     // systems: see pmc_hip.hip, cb_fuse_teams); compiling it into the single-species team kernels as well cost them 20 KB of
     // code and 16-20 B more scratch per lane for a path their systems never take
-#ifdef PMC_EXP_FUSE_ALL       // experiments: the fused staging compiled into the single-species team kernels too
-    constexpr bool FUSE = PMC_FUSED_STAGE;
-#else
     constexpr bool FUSE = PMC_FUSED_STAGE && (NW == 1 || MULTI);
-#endif
     stage_neighbourhood<D, MULTI, NW, FUSE>(a, cell, h, a.fused ? colour : 0);
     PMC_T(t_2);
 #if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 2
@@ -2125,9 +2154,9 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     // histogram of the box-filtered neighbourhood sizes, in steps of 64: the host sizes the LDS staging of the next call
     // from it (pmc_hip.hip: cb_cap_sweep)
     if (FUSE && NW == 1 && tid == 0) atomicAdd(&st[PMC_STAT_KEPT + min((h.kept + 63) >> 6, 15)], 1ull);
-    compact_candidates<D, MULTI, NW>(a, h);
+    compact_candidates<D, MULTI, NW, BIG>(a, h);
     FRegs fr;
-    prepare_filter<D>(a, h, fr);
+    prepare_filter<D, NW, BIG>(a, h, fr);
     PMC_T(t_3);
 #if defined(PMC_DEBUG_STOP) && PMC_DEBUG_STOP == 3
     { asm volatile("" :: "v"(fr.x[0]), "v"(fr.y[7]), "v"(fr.z[3])); if (a.fused) publish_done(a, lin, tid == 0); return; }   // (keeps the float copy alive)
@@ -2144,6 +2173,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
     long long efix = 0;
     bool dirty = false;
     int nbatch = 0;
+    const bool single = (a.n[0] == 1);       // the whole periodic box is ONE cell (boxes of 2 ... 4 cutoffs per side): no move leaves it
     const double my_shift = (lane == 0) ? a.shift[0] : ((lane == 1) ? a.shift[1] : a.shift[2]);
     const double my_w = (lane == 0) ? a.w[0] : ((lane == 1) ? a.w[1] : a.w[2]);
     const bool anyimg = IMG && a.simg && ((nc > PMC_WAVE) || (__builtin_amdgcn_ballot_w64(myimg != PMC_IMG_ZERO) != 0ull));
@@ -2157,15 +2187,6 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
         }
     };
 
-    // -DPMC_EXP_ECACHE (one wavefront per cell, one species, one Displacement): energies of re-picked particles, see the slot loop
-#ifdef PMC_EXP_ECACHE      // experiment of round 4, measured and left off: see DESIGN.md 8b and profiles/r04_ecache_ab.json
-    constexpr bool ECACHE = (NW == 1) && !MULTI && ONE;
-#else
-    constexpr bool ECACHE = false;
-#endif
-    const bool use_cache = ECACHE && a.rounds >= PMC_ECACHE_MINROUNDS && h.filt && nc <= PMC_WAVE && !anyimg;
-    double ecache = 0.0;
-    unsigned long long cvalid = 0ull;
     const int nsl = nc * a.rounds;     // proposal slots of this visit
     for (int chunk = 0; chunk < nsl; chunk += PMC_WAVE) {
         // lanes generate the slots of this chunk in parallel
@@ -2206,11 +2227,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
             int s0 = 0;
             while (s0 < nslots) {
                 const int K = min(NW, nslots - s0);
-#ifdef PMC_EXP_SINGLEREC
-                double *const recs = h.rec;
-#else
                 double *const recs = h.rec + (nbatch & 1) * (NW * PMC_REC);   // records of this batch (two buffers alternate)
-#endif
                 nbatch++;
                 PMC_T(tb_0);
                 if (wv < K) {
@@ -2232,7 +2249,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         if (valid) {
                             pi = h.ctr + kth_of_species(h, sa, (int)mulhi32(w1, (uint32_t)na));
                             pj = h.ctr + kth_of_species(h, sb, (int)mulhi32(w2, (uint32_t)nb));
-                            de = wave_swap_delta<D, KIND, MULTI>(a, h, tab, my_queue, fr, pi, pj, sa, sb, pcnt);
+                            de = wave_swap_delta<D, KIND, MULTI, BIG>(a, h, tab, my_queue, fr, pi, pj, sa, sb, pcnt);
                         }
                         if (lane == 0) {
                             double *r = recs + wv * PMC_REC;
@@ -2253,12 +2270,12 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     double yn = yo + readlane_double(g_dy, my);
                     double zn = (D == 3) ? zo + readlane_double(g_dz, my) : 0.0;
                     if (anyimg) settle(__builtin_amdgcn_readfirstlane(pc - h.ctr), xn, yn, zn);
-                    const bool inside = stays_in_cell<D>(a, h, pc - h.ctr, xo, yo, zo, xn, yn, zn, my_shift, my_w);
+                    const bool inside = single || stays_in_cell<D>(a, h, pc - h.ctr, xo, yo, zo, xn, yn, zn, my_shift, my_w);
                     double de = 0.0;
                     if (inside) {
                         const int si = MULTI ? (int)h.csp[pc] : 0;
                         float fxn, fyn, fzn;
-                        de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
+                        de = wave_delta_e<D, KIND, MULTI, BIG>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
                     }
                     if (lane == 0) {
                         double *r = recs + wv * PMC_REC;
@@ -2337,48 +2354,6 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 // Two forms of the in-order resolution below.  The first is round 2's (cross-lane reads of every operand, ~40 instructions per
 // slot); the second lets every lane decide for itself (~8 per slot, +3 % for teams of 8).
-#ifdef PMC_EXP_OLDRESOLVE
-                    // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i
-                    double creg[NW - 1];
-#pragma unroll
-                    for (int i = 0; i < NW - 1; i++) creg[i] = h.cmat[i * NW + jl];
-                    // decisions in slot order; lanes > i accumulate what an accepted slot i does to them
-                    double corr = 0.0;
-                    bool conf = false, stop = false;
-                    int nres = 0;
-                    unsigned accmask = 0;
-#pragma unroll
-                    for (int i = 0; i < NW; i++) {
-                        if (i < K && !stop) {
-                            const double dei = readlane_double(l_de + corr, i);
-                            const bool swapi = (__ballot(l_swap && lane == i) != 0ull);
-                            const bool confi = (__ballot(conf && lane == i) != 0ull);
-                            // a slot that re-selects a moved particle ends the batch and is evaluated again (a swap after accepted
-                            // Displacements of OTHER particles is corrected like a Displacement: c(i,j) above)
-                            if (confi) {
-                                stop = true;
-                            } else {
-                                const bool ini = (__ballot(l_in && lane == i) != 0ull);
-                                const bool oki = ini && (readlane_double(l_tlnu, i) < -dei);
-                                nres = i + 1;
-                                if (oki) {
-                                    accmask |= 1u << i;
-                                    acc1 += 1;
-                                    efix += (long long)(dei * PMC_FIX);
-                                    if (swapi) {
-                                        stop = true;            // later slots saw the old species: next batch
-                                    } else if (i < NW - 1) {
-                                        const int pci = __builtin_amdgcn_readlane(l_pc, i);
-                                        if (lane > i) {
-                                            corr += creg[i < NW - 1 ? i : 0];
-                                            conf = conf || (l_pc == pci) || (l_swap && l_pj == pci);
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-#else
                     // lane j holds column j of the matrix: the corrections it receives from earlier accepted slots i (none from i >= j)
                     double creg[NW - 1];
 #pragma unroll
@@ -2427,7 +2402,6 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         efix += (long long)(readlane_double(dsum, 0) * PMC_FIX);
                         acc1 += (unsigned long long)__popc(accmask);
                     }
-#endif
                     att1 += (unsigned long long)nres;
 #ifdef PMC_DEBUG_SLOTLOG
                     if (g_slotlog && lane < nres) {
@@ -2449,6 +2423,17 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                             h.cx[l_pc] = rl[3];
                             h.cy[l_pc] = rl[4];
                             if (D == 3) h.cz[l_pc] = rl[5];
+                            if (BIG && h.fstream) {         // the team's float copy in LDS (prepare_filter) follows the move
+                                if (h.nowrap) {
+                                    h.fx[l_pc] = rel_float<true>(rl[3], h.bc[0], a.L[0], a.invL[0]);
+                                    h.fy[l_pc] = rel_float<true>(rl[4], h.bc[1], a.L[1], a.invL[1]);
+                                    if (D == 3) h.fz[l_pc] = rel_float<true>(rl[5], h.bc[2], a.L[2], a.invL[2]);
+                                } else {
+                                    h.fx[l_pc] = rel_float<false>(rl[3], h.bc[0], a.L[0], a.invL[0]);
+                                    h.fy[l_pc] = rel_float<false>(rl[4], h.bc[1], a.L[1], a.invL[1]);
+                                    if (D == 3) h.fz[l_pc] = rel_float<false>(rl[5], h.bc[2], a.L[2], a.invL[2]);
+                                }
+                            }
                         }
                     }
                     nnull += (unsigned)__popcll(__ballot(lane < nres && !l_in));
@@ -2456,9 +2441,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                 }
                 PMC_T(tb_3);
                 __syncthreads();           // accepted moves and the number of resolved slots are visible
-#ifdef PMC_DEBUG_TIME
-                { PMC_T(tb_4); tp_pro += tb_1 - tb_0; tp_red += tb_3 - tb_2; tp_n += 1; pcnt.t_filter += tb_2 - tb_1; pcnt.t_dense += tb_4 - tb_3; }
-#endif
+    PMC_TIME({ PMC_T(tb_4); tp_pro += tb_1 - tb_0; tp_red += tb_3 - tb_2; tp_n += 1; pcnt.t_filter += tb_2 - tb_1; pcnt.t_dense += tb_4 - tb_3; })
                 s0 += h.flag[3];
                 if (h.filt) {
                     // every wavefront brings its register copy of the float coordinates up to date with the accepted
@@ -2502,37 +2485,18 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                 double yn = yo + readlane_double(g_dy, s);
                 double zn = (D == 3) ? zo + readlane_double(g_dz, s) : 0.0;
                 if (anyimg) settle(__builtin_amdgcn_readfirstlane(p), xn, yn, zn);
-                const bool inside = stays_in_cell<D>(a, h, p, xo, yo, zo, xn, yn, zn, my_shift, my_w);
+                const bool inside = single || stays_in_cell<D>(a, h, p, xo, yo, zo, xn, yn, zn, my_shift, my_w);
                 if (inside) {
                     // one wavefront per cell here (teams of NW >= 2 take the batch branch above)
                     const int si = MULTI ? (int)h.csp[pc] : 0;
                     float fxn = 0.0f, fyn = 0.0f, fzn = 0.0f;
-#ifdef PMC_DEBUG_TIME
+    PMC_TIME(
                     asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 0" :: "v"(xn + yn + zn) : "memory");
                     PMC_T(ts_1);
                     tp_pro += ts_1 - ts_0;
                     tp_n += 1;
-#endif
-                    // -DPMC_EXP_ECACHE: a particle picked again in this visit has its energy at the present position cached (lane p
-                    // of `ecache`): only the trial position is evaluated, dE = e_new - cache -- the same bits, every term being
-                    // a multiple of 2^-32 and every sum exact (dev_quant)
-                    double de, e_new = 0.0;
-                    bool got_enew = false, cached = false;
-                    const int pu = __builtin_amdgcn_readfirstlane(p);
-                    if (ECACHE && use_cache) cached = ((cvalid >> pu) & 1ull) != 0ull;
-                    if (ECACHE && cached) {
-                        bool ovf;
-                        e_new = wave_e_new<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xn, yn, zn, fxn, fyn, fzn, pcnt, ovf);
-                        if (!ovf) {
-                            got_enew = true;
-                            de = e_new - readlane_double(ecache, pu);
-                        } else {
-                            de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
-                        }
-                    } else {
-                        de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt,
-                                                          (ECACHE && use_cache) ? &e_new : nullptr, &got_enew);
-                    }
+    )
+                    const double de = wave_delta_e<D, KIND, MULTI>(a, h, tab, my_queue, fr, pc, si, xo, yo, zo, xn, yn, zn, fxn, fyn, fzn, pcnt);
                     PMC_T(ts_2);
                     ok = tlnu < -de;
                     if (ok) {
@@ -2547,35 +2511,7 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
                         efix += (long long)(de * PMC_FIX);
                         dirty = true;
                     }
-                    if (ECACHE && use_cache) {
-                        const unsigned long long bit = 1ull << pu;
-                        if (ok) {
-                            // the cached energies of the other centre particles follow the move: the pair term with the mover,
-                            // computed as their own evaluation computes it (they are particle i, the mover is candidate j)
-                            const unsigned long long others = cvalid & ~bit;
-                            if (others) {
-                                if ((lane < nc) && ((others >> lane) & 1ull)) {
-                                    const int kc = h.ctr + lane;
-                                    const double xc = h.cx[kc], yc = h.cy[kc], zc = (D == 3) ? h.cz[kc] : 0.0;
-                                    const DevModel &mm = a.m0;
-                                    const double r2o = h.nowrap ? dist2_nowrap<D>(xc, yc, zc, xo, yo, zo) : dist2_fast<D>(a, xc, yc, zc, xo, yo, zo);
-                                    const double r2n = h.nowrap ? dist2_nowrap<D>(xc, yc, zc, xn, yn, zn) : dist2_fast<D>(a, xc, yc, zc, xn, yn, zn);
-                                    double du = 0.0;
-                                    if (!(r2n > mm.rcut2)) du += dev_quant(pot_kind<KIND>(r2n, mm));
-                                    if (!(r2o > mm.rcut2)) du -= dev_quant(pot_kind<KIND>(r2o, mm));
-                                    ecache += du;
-                                }
-                            }
-                            if (got_enew) { if (lane == pu) ecache = e_new; cvalid |= bit; }
-                            else cvalid &= ~bit;
-                        } else if (!cached && got_enew) {
-                            if (lane == pu) ecache = e_new - de;         // the energy at the position the particle keeps
-                            cvalid |= bit;
-                        }
-                    }
-#ifdef PMC_DEBUG_TIME
-                    { PMC_T(ts_3); tp_red += ts_3 - ts_2; }
-#endif
+    PMC_TIME({ PMC_T(ts_3); tp_red += ts_3 - ts_2; })
                 } else {
                     nnull += 1;
                 }
@@ -2676,7 +2612,11 @@ __device__ __forceinline__ void cb_visit(const CbArgs &a, WaveNbh &h, const DevM
 //    kernel from 84 to 188 VGPRs -- or 128 with scratch spills -- and chunks of tickets let workgroups run ahead by more
 //    than one colour, so cells stall on their neighbours: 1.65 ms against 1.41 ms at N = 10^6.)
 // ONE: the pool is a single Displacement move (no move selection, no per-move select chains)
-template <int D, int KIND, bool MULTI, int NW, bool ONE, int MW = PMC_CB_MINWAVES, bool IMG = false>   // MW: wavefronts per SIMD it is compiled for
+// BIG (teams of eight, systems without periodic images): neighbourhoods beyond the 512 candidates of the register copy -- boxes of
+// 4-5 cutoffs per side at liquid density -- are staged whole (up to PMC_CAP_BIG), with one float copy in LDS that every
+// wavefront's pre-filter streams (prepare_filter, wave_delta_e_filtered<STREAM>; host: cb_big).  Separate instances: compiled
+// into the default team kernels the extra state cost configs 2 and 3 (N = 32768, Kob-Andersen 10^5) 3-6 %.
+template <int D, int KIND, bool MULTI, int NW, bool ONE, int MW = PMC_CB_MINWAVES, bool IMG = false, bool BIG = false>   // MW: wavefronts per SIMD it is compiled for
 __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restrict__ args, int nrep)
 {
     // The arguments of a launch live in DEVICE memory, one CbArgs per replica of the launch (one for a single system,
@@ -2687,10 +2627,10 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     extern __shared__ __align__(16) unsigned char smem[];
     WaveNbh h;
     const CbArgs &a0 = args[0];                      // the shape (grid, models, pool, capacities) is common to all replicas
-    const DevModel *tab = setup_lds<D, MULTI, (NW >= 2 ? NW : 0)>(a0, smem, h);
+    const DevModel *tab = setup_lds<D, MULTI, (NW >= 2 ? NW : 0), BIG>(a0, smem, h);
     const int tid = team_tid<NW>();
     CbTotals tot{};
-    tot.pcnt.count_dense = (NW == 1 && !MULTI);
+    tot.pcnt.count_dense = (NW == 1 && !MULTI) || BIG;
     if (!ONE) {
         if (tid < 16) h.cnt[tid] = 0;
         if (tid < 8) {
@@ -2725,7 +2665,7 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
     }
     const CbArgs &a = args[r];
     unsigned long long *const st = a.stats + (size_t)(aidx & (PMC_NSHARD - 1)) * PMC_NSTATS;   // this workgroup's counter copy
-    cb_visit<D, KIND, MULTI, NW, ONE, IMG>(a, h, tab, colour, aidx, st, tot);
+    cb_visit<D, KIND, MULTI, NW, ONE, IMG, BIG>(a, h, tab, colour, aidx, st, tot);
     if (tid == 0) {
         if (ONE) {
             if (tot.att1) atomicAdd(&st[0], tot.att1);
@@ -2738,16 +2678,16 @@ __global__ __launch_bounds__(NW * 64, MW) void k_cb_pass(const CbArgs *__restric
         }
         if (tot.efix) atomicAdd(&st[16], (unsigned long long)tot.efix);
         if (tot.nnull) atomicAdd(&st[27], tot.nnull);
-#ifdef PMC_DEBUG_TIME
+    PMC_TIME(
         for (int q = 0; q < 15; q++) atomicAdd(&st[32 + q], tot.tp[q]);
         atomicAdd(&st[47], tot.tp[15]);
-#endif
+    )
     }
     // work counters of the roofline (bench.py): every wavefront adds its own
     if (wave_lane() == 0 && tot.pcnt.tests) {
         atomicAdd(&st[25], (unsigned long long)tot.pcnt.tests);
         atomicAdd(&st[26], (unsigned long long)tot.pcnt.energies);
-        if (NW == 1 && !MULTI) atomicAdd(&st[24], (unsigned long long)tot.pcnt.dense);
+        if ((NW == 1 && !MULTI) || BIG) atomicAdd(&st[24], (unsigned long long)tot.pcnt.dense);
     }
 }
 
@@ -2770,14 +2710,18 @@ __device__ double stream_energy(const CbArgs &a, double xi, double yi, double zi
     double e = 0.0;
     for (int o = 0; o < NN; o++) {
         int lin2 = 0, r = o;
+        bool dup = false;              // (single-cell boxes: stage_neighbourhood)
 #pragma unroll
         for (int q = 0; q < D; q++) {
-            int cq = cell[q] + (r % 3) - 1;
+            const int off = (r % 3) - 1;
+            int cq = cell[q] + off;
             r /= 3;
+            dup = dup || (a.n[q] == 1 && off != 0);
             if (cq < 0) cq += a.n[q];
             if (cq >= a.n[q]) cq -= a.n[q];
             lin2 = lin2 * a.n[q] + cq;
         }
+        if (dup) continue;
         int lo = a.start[lin2], hi = a.start[lin2 + 1];
         for (int k = lo + wave_lane(); k < hi; k += PMC_WAVE) {
             if (a.ids[k] == self_id) continue;

@@ -68,6 +68,12 @@ __device__ __forceinline__ int ref_cell_of(const RefArgs &a, const double *x)
     return (int)c;
 }
 
+// The literal chain is ONE wavefront that owns its system for the length of a launch: what a lane stores only ever has to reach
+// the wavefront's own later loads, which a workgroup barrier (with the waits it implies) orders.  Until round 5 every such point
+// was a device-scope __threadfence() -- a write-back of the XCD's L2 and an invalidate of the CU's L1, ~3.5 us each
+// (MI355X_MICROARCH.md), six to ten per step -- for visibility nobody else needed.
+__device__ __forceinline__ void ref_sync() { __syncthreads(); }
+
 // compute_energy_ij, src/atoms.jl:66-75 (literal, division-form minimum image)
 template <int D>
 __device__ __forceinline__ double ref_energy_ij(const RefArgs &a, int i, int j, const double *xi, int spi)
@@ -284,8 +290,7 @@ __device__ void ref_verlet_update(const RefArgs &a, int i, const double *x, int 
         a.vl_cnt[j] = w;
     }
     if (lane == 0) ref_cellvec_update<D>(a, i, x);
-    __threadfence();
-    __syncthreads();
+    ref_sync();
     const int c = ref_cell_of<D>(a, x);
     const int cnt = a.nbrcnt[c];
     int fill = 0;                                           // uniform: entries of neighbours[i] so far
@@ -442,11 +447,9 @@ __device__ void ref_disp_perform(const RefArgs &a, int i, const double *delta, i
 #pragma unroll
         for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = x[q];
     }
-    __threadfence();
-    __syncthreads();
+    ref_sync();
     ref_update_list<D>(a, i, x, lds_ids);                 // update_neighbour_list!, src/moves.jl:47
-    __threadfence();
-    __syncthreads();
+    ref_sync();
     double eb = wave_ordered_energy<D>(a, i, x, sp, lds_ids);
     double d = 0.0;
     if (!(isinf(ea) || isinf(eb))) {                      // src/moves.jl:13-18
@@ -468,11 +471,9 @@ __device__ void ref_disp_revert(const RefArgs &a, int i, const double *mdelta, d
         for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = x[q];
         *a.energy -= de;                                  // src/moves.jl:79
     }
-    __threadfence();
-    __syncthreads();
+    ref_sync();
     ref_update_list<D>(a, i, x, lds_ids);
-    __threadfence();
-    __syncthreads();
+    ref_sync();
 }
 
 // update_species_list!, src/moves.jl:175-179 (0-based)
@@ -497,8 +498,7 @@ __device__ void ref_swap_perform(const RefArgs &a, int i, int j, int s1, int s2,
     double e1i = wave_ordered_energy<D>(a, i, xi, spi, lds_ids);
     double e1j = wave_ordered_energy<D>(a, j, xj, spj, lds_ids);
     if (lane == 0) { a.species[i] = spj; a.species[j] = spi; }
-    __threadfence();
-    __syncthreads();
+    ref_sync();
     double e2i = wave_ordered_energy<D>(a, i, xi, spj, lds_ids);
     double e2j = wave_ordered_energy<D>(a, j, xj, spi, lds_ids);
     double ea = e1i + e1j, eb = e2i + e2j;
@@ -508,8 +508,7 @@ __device__ void ref_swap_perform(const RefArgs &a, int i, int j, int s1, int s2,
         d = eb - ea;
         if (lane == 0) *a.energy += d;
     }
-    __threadfence();
-    __syncthreads();
+    ref_sync();
     *e1 = ea; *e2 = eb; *de = d;
 }
 
@@ -522,8 +521,55 @@ __device__ void ref_swap_revert(const RefArgs &a, int i, int j, int s1, int s2, 
         ref_update_species_list(a, s1, s2, i, j);
         *a.energy -= de;
     }
-    __threadfence();
-    __syncthreads();
+    ref_sync();
+}
+
+// `nsteps` Metropolis steps of the reference's chain following the Arianna mc_step! contract with the Philox stream
+// of DESIGN.md; one wavefront
+template <int D>
+__device__ void ref_steps(const RefArgs &a, const RefOp &o, int *lds_ids)
+{
+    const int lane = wave_lane();
+    double e1 = 0, e2 = 0, de = 0;
+    unsigned long long att[8] = {0}, acc[8] = {0};
+    for (long long t = 0; t < o.nsteps; t++) {
+        unsigned long long g = o.step0 + (unsigned long long)t;
+        uint32_t R[4], Q[4];
+        philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, o.key0, o.key1, R);
+        philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ1, o.key0, o.key1, Q);
+        int m = select_move(o.pool, R[0]);
+        double lnu = det_log(uniform53(R[2], R[3]));
+        bool ok = false;
+        if (o.pool.kind[m] == 0) {
+            int i = (int)mulhi32(R[1], (uint32_t)a.N);
+            double z[4], delta[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+            box_muller(Q[0], Q[1], &z[0], &z[1]);
+            box_muller(Q[2], Q[3], &z[2], &z[3]);
+#pragma unroll
+            for (int q = 0; q < D; q++) { delta[q] = o.pool.sigma[m] * z[q]; md[q] = -delta[q]; }
+            ref_disp_perform<D>(a, i, delta, lds_ids, &e1, &e2, &de);
+            ok = lnu < -(e2 - e1) / a.temperature;
+            if (!ok) ref_disp_revert<D>(a, i, md, de, lds_ids);
+        } else {
+            int sa = o.pool.sp0[m], sb = o.pool.sp1[m];
+            int na = a.sp_off[sa + 1] - a.sp_off[sa], nb = a.sp_off[sb + 1] - a.sp_off[sb];
+            if (na > 0 && nb > 0) {
+                int i = a.sp_ids[a.sp_off[sa] + mulhi32(R[1], (uint32_t)na)];
+                int j = a.sp_ids[a.sp_off[sb] + mulhi32(Q[0], (uint32_t)nb)];
+                ref_swap_perform<D>(a, i, j, sa, sb, lds_ids, &e1, &e2, &de);
+                ok = lnu < -(e2 - e1) / a.temperature;
+                if (!ok) ref_swap_revert(a, j, i, sa, sb, de);
+            }
+        }
+        // runtime-indexed counters stay in registers via a select chain
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            att[q] += (q == m);
+            acc[q] += (q == m && ok);
+        }
+    }
+    if (lane == 0)
+        for (int q = 0; q < 8; q++) { o.stats[q] += att[q]; o.stats[8 + q] += acc[q]; }
 }
 
 // One wavefront runs the reference's strictly sequential chain: per-move verbs
@@ -545,47 +591,19 @@ __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
         // called with the inverted action (src/moves.jl:212-214): o.i currently holds action.species[1]
         ref_swap_revert(a, o.i, o.j, a.species[o.i], a.species[o.j], o.de_in);
     } else {
-        unsigned long long att[8] = {0}, acc[8] = {0};
-        for (long long t = 0; t < o.nsteps; t++) {
-            unsigned long long g = o.step0 + (unsigned long long)t;
-            uint32_t R[4], Q[4];
-            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, o.key0, o.key1, R);
-            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ1, o.key0, o.key1, Q);
-            int m = select_move(o.pool, R[0]);
-            double lnu = det_log(uniform53(R[2], R[3]));
-            bool ok = false;
-            if (o.pool.kind[m] == 0) {
-                int i = (int)mulhi32(R[1], (uint32_t)a.N);
-                double z[4], delta[3] = {0, 0, 0}, md[3] = {0, 0, 0};
-                box_muller(Q[0], Q[1], &z[0], &z[1]);
-                box_muller(Q[2], Q[3], &z[2], &z[3]);
-#pragma unroll
-                for (int q = 0; q < D; q++) { delta[q] = o.pool.sigma[m] * z[q]; md[q] = -delta[q]; }
-                ref_disp_perform<D>(a, i, delta, lds_ids, &e1, &e2, &de);
-                ok = lnu < -(e2 - e1) / a.temperature;
-                if (!ok) ref_disp_revert<D>(a, i, md, de, lds_ids);
-            } else {
-                int sa = o.pool.sp0[m], sb = o.pool.sp1[m];
-                int na = a.sp_off[sa + 1] - a.sp_off[sa], nb = a.sp_off[sb + 1] - a.sp_off[sb];
-                if (na > 0 && nb > 0) {
-                    int i = a.sp_ids[a.sp_off[sa] + mulhi32(R[1], (uint32_t)na)];
-                    int j = a.sp_ids[a.sp_off[sb] + mulhi32(Q[0], (uint32_t)nb)];
-                    ref_swap_perform<D>(a, i, j, sa, sb, lds_ids, &e1, &e2, &de);
-                    ok = lnu < -(e2 - e1) / a.temperature;
-                    if (!ok) ref_swap_revert(a, j, i, sa, sb, de);
-                }
-            }
-            // runtime-indexed counters stay in registers via a select chain
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                att[q] += (q == m);
-                acc[q] += (q == m && ok);
-            }
-        }
-        if (lane == 0)
-            for (int q = 0; q < 8; q++) { o.stats[q] += att[q]; o.stats[8 + q] += acc[q]; }
+        ref_steps<D>(a, o, lds_ids);
     }
     if (lane == 0 && o.result) { o.result[0] = e1; o.result[1] = e2; o.result[2] = de; }
+}
+
+// The chains of a `parallel = true` run (src/ParticlesMC.jl:164,246) on the literal loop, all in ONE launch: workgroup b runs
+// chain b (its own arguments, any shape, any list type).  What the literal loop serves -- VerletList, EmptyList systems beyond
+// the LDS, swap pools between a species and itself -- used to run its chains one after the other.
+template <int D>
+__global__ __launch_bounds__(64) void k_ref_steps_many(const RefArgs *__restrict__ args, const RefOp *__restrict__ ops)
+{
+    __shared__ int lds_ids[PMC_REF_IDS];
+    ref_steps<D>(args[blockIdx.x], ops[blockIdx.x], lds_ids);
 }
 
 // ------------------------------------------------------------------------------

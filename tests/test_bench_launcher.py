@@ -51,3 +51,14 @@ def test_more_ranks_than_devices_is_refused_not_shared():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "visible GPU" in r.stderr or "needs a HIP device" in r.stderr
+
+
+@pytest.mark.timeout(120)
+def test_launch_timeout_kills_the_ranks_and_exits_nonzero():
+    """a rank that hangs must end `bench.py --gpus N` with a non-zero status -- the parent kills the process
+    group of the ranks it started (never a re-exec).  The stub engine sleeps when PMC_BENCH_STUB_HANG names the rank."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--lattice", "6", "--no-cpu", "--launch-timeout", "20"],
+             PMC_BENCH_STUB="1", PMC_BENCH_STUB_HANG="1")
+    assert r.returncode == 5, (r.returncode, r.stderr[-1500:])
+    assert "did not finish within" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

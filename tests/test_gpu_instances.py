@@ -17,13 +17,13 @@ pytestmark = pytest.mark.gpu
 KINDS = ["lj", "soft_int", "soft_odd", "smooth", "mixed"]
 
 
-def _matrix(pmc, O, kind, S):
+def _matrix(pmc, O, kind, S, rcut_over_sigma=2.3):
     arr = (O.Model * (S * S))()
     mm = [[None] * S for _ in range(S)]
     for i in range(S):
         for j in range(i, S):
             eps, sig = 1.0 + 0.2 * (i != j), 1.0 - 0.06 * (i + j)
-            rcut = 2.3 * sig
+            rcut = rcut_over_sigma * sig
             k = kind if kind != "mixed" else ["lj", "soft_int", "smooth"][(i + j) % 3]
             if k == "lj":
                 p, o = pmc.LennardJones(eps, sig, rcut=rcut), O.lennard_jones(eps, sig, rcut)
@@ -86,3 +86,70 @@ def test_every_kernel_instance_against_the_oracle(gpu, monkeypatch, d, kind):
         assert acc[0] > N // 4, tag
         checked += 1
     assert checked == (36 if kind != "mixed" else 18)
+
+
+@pytest.mark.parametrize("d", [3, 2])
+@pytest.mark.parametrize("kind", KINDS)
+def test_every_big_neighbourhood_instance_against_the_oracle(gpu, monkeypatch, d, kind):
+    """The big-neighbourhood instances (k_cb_pass<..., BIG>, round 5): boxes of four cutoffs per side at liquid density have
+    3^d-cell neighbourhoods beyond the 1024 candidates of the default staging and the 512 of the pre-filter's register copy; a
+    team of eight then stages the whole neighbourhood and streams ONE float copy of it in LDS (the reference's own validation
+    example is such a system: examples/lj-mixture/run-validation.py:26-34, rcut = 4 sigma).  Dimension x model kind x {one,
+    two species} x {single-Displacement pool, multi-move pool with swaps}, three sweeps at m = 2 against the oracle, and the same
+    bits with the instances switched off (PMC_NO_BIG=1: the direct FP64 loop these systems took until round 4)."""
+    from oracle import oracle as O
+    pmc = gpu
+    monkeypatch.delenv("PMC_TEAM", raising=False)
+    monkeypatch.delenv("PMC_MINWAVES", raising=False)
+    if d == 3:
+        n, rho, rc = 14, 0.622, 4.0          # box 16.4 = 4 cells of 4.1; 43 particles per cell, 1158 per neighbourhood
+    else:
+        n, rho, rc = 45, 0.84, 12.0          # box 49.1 = 4 cells of 12.3; 127 particles per cell, 1139 per neighbourhood
+    pos, sp1, rho = lj_lattice(n, jitter=0.06, seed=11, rho=rho, d=d)
+    N = len(pos)
+    rng = np.random.default_rng(5)
+    sp2 = np.where(rng.random(N) < 0.4, 2, 1).astype(np.int32)
+    checked = 0
+    for S, multi_pool in itertools.product((1, 2), (False, True)):
+        if kind == "mixed" and S == 1:
+            continue
+        sp = sp1 if S == 1 else sp2
+        mm, mo = _matrix(pmc, O, kind, S, rcut_over_sigma=rc)
+        pm = [pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.07}, 1.0)]
+        po = [{"kind": "Displacement", "sigma": 0.07, "probability": 1.0}]
+        results = []
+        for no_big in (False, True):
+            if no_big:
+                monkeypatch.setenv("PMC_NO_BIG", "1")
+            else:
+                monkeypatch.delenv("PMC_NO_BIG", raising=False)
+            g = pmc.System(pos, sp, rho, 1.1, mm, seed=77)
+            assert tuple(int(v) for v in g.grid()[0][:d]) == (4,) * d
+            g.rounds = 2
+            pmg = list(pm)
+            if multi_pool:
+                pmg.append(pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": 0.3}, 0.3))
+                if S > 1:
+                    pmg.append(pmc.Move(pmc.DiscreteSwap([1, 2], g), pmc.DoubleUniform(), [], 0.4))
+            st = pmc.mc_sweep(g, pmg, nsweeps=3)
+            results.append((st, g.position.copy(), g.species.copy()))
+        pof = list(po)
+        if multi_pool:
+            pof.append({"kind": "Displacement", "sigma": 0.3, "probability": 0.3})
+            if S > 1:
+                pof.append({"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.4})
+        cb = O.Checkerboard(pos, sp, np.asarray(g.box), 1.1, mo, seed=77)
+        att, acc = cb.sweeps(O.make_pool(pof), 0, 3, rounds=2)
+        tag = (d, kind, S, multi_pool)
+        for st, p, spc in results:
+            assert list(st.attempted[: len(pof)]) == list(att) and list(st.accepted[: len(pof)]) == list(acc), tag
+            assert st.energy_fix == cb.energy_fix, tag
+            assert np.array_equal(p, cb.positions()) and np.array_equal(spc, cb.species()), tag
+        big, direct = results[0][0], results[1][0]
+        # the big instance ran its streamed pre-filter (few FP64 distance evaluations per FP32 test); the default one tested
+        # every candidate of every slot in FP64 and does not count them
+        assert 0 < big.dense_evals < 0.5 * big.pair_tests, (tag, big.dense_evals, big.pair_tests)
+        assert direct.dense_evals == 0, tag
+        assert acc[0] > N // 4, tag
+        checked += 1
+    assert checked == (4 if kind != "mixed" else 2)

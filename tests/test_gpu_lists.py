@@ -124,3 +124,45 @@ def test_list_types_per_move_verbs_and_hand_over(gpu):
             o2 = O.System(g.position, g.species, rho, 1.0, O.kob_andersen(), olt, dr)
             _same_lists(g, o2, name)
             assert np.array_equal(pmc.compute_energy_particles(g), o2.energy_particles()), name
+
+
+def test_many_literal_loop_chains_in_one_launch(gpu):
+    """the chains of a `parallel = true` run (src/ParticlesMC.jl:164,246) that only the literal loop
+    serves -- the reference's CI system with a VerletList dr = 0.2 (test/runtests.jl:41-91), an EmptyList chain forced onto engine
+    1, a pool that swaps within one species -- share ONE launch of k_ref_steps_many, one workgroup per chain, any mix of shapes
+    and list types.  Every chain must end exactly as the oracle's sequential driver does with the chain's own key: positions,
+    species, accept counts, system.energy, cells[] and neighbours[] bit for bit."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = _config0(O)
+    spec = [{"kind": "Displacement", "sigma": 0.12, "probability": 0.7},
+            {"kind": "DiscreteSwap", "species": (1, 3), "probability": 0.2},
+            {"kind": "DiscreteSwap", "species": (2, 2), "probability": 0.1}]      # i ~ species 2, j ~ species 2: the literal loop only
+    chains, oracles, names = [], [], []
+    for k in range(5):
+        lt = [("VerletList", pmc.VerletList, O.VERLETLIST, {"dr": 0.2}, 0.2), ("CellList", pmc.CellList, O.CELLLIST, None, 0.0),
+              ("EmptyList", pmc.EmptyList, O.EMPTYLIST, None, 0.0)][k % 3]
+        g = pmc.System(pos, sp, rho, 0.231, pmc.JBB(), list_type=lt[1], list_parameters=lt[3], seed=10, chain=k)
+        chains.append(g)
+        oracles.append(O.System(pos, sp, rho, 0.231, O.jbb(), lt[2], lt[4]))
+        names.append(lt[0])
+    pool = []
+    for m in spec:
+        if m["kind"] == "Displacement":
+            pool.append(pmc.Move(pmc.Displacement(0, None, 0.0), pmc.SimpleGaussian(), {"sigma": m["sigma"]}, m["probability"]))
+        else:
+            pool.append(pmc.Move(pmc.DiscreteSwap(list(m["species"]), chains[0]), pmc.DoubleUniform(), [], m["probability"]))
+    sts = pmc.mc_sweep_many(chains, pool, nsweeps=2, mode="sequential")
+    assert all(st.sweep_kernel_launches == 1 for st in sts)           # one shared launch
+    for k, (g, o) in enumerate(zip(chains, oracles)):
+        att, acc = o.mc_steps(O.make_pool(spec), 10, k, 0, 2 * g.N)
+        assert np.array_equal(sts[k].attempted[:3], att[:3]) and np.array_equal(sts[k].accepted[:3], acc[:3]), (k, names[k])
+        assert np.array_equal(g.position, o.positions()) and np.array_equal(g.species, o.species()), (k, names[k])
+        assert g.energy[0] == o.energy, (k, names[k])
+        _same_lists(g, o, names[k])
+    assert len({tuple(int(v) for v in st.accepted[:3]) for st in sts}) > 1      # the chains differ (own keys)
+    # ... and a second call continues every chain where the first stopped
+    sts = pmc.mc_sweep_many(chains, pool, nsweeps=1, mode="sequential")
+    for k, (g, o) in enumerate(zip(chains, oracles)):
+        att, acc = o.mc_steps(O.make_pool(spec), 10, k, 2 * g.N, g.N)
+        assert np.array_equal(sts[k].accepted[:3], acc[:3]) and np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy, (k, names[k])

@@ -298,7 +298,12 @@ def test_error_paths(gpu):
     bad[1] = bad[0]
     with pytest.raises(ValueError, match="infinite or NaN"):
         pmc.System(bad, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0))
-    s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0))      # box 6 < 4 * rcut
+    # box 6 = 2.4 cutoffs: no two-coloured grid, but a single-cell box since round 5 (tests/test_gpu_single_cell.py)
+    s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0))
+    assert tuple(int(v) for v in s.grid()[0]) == (1, 1, 1)
+    assert pmc.mc_sweep(s, _disp_pool(pmc), nsweeps=1).attempted[0] == len(pos)
+    pos, sp, rho = lj_lattice(4)                                         # box 4 = 1.6 cutoffs: refused; the reference's own chain runs
+    s = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0))
     with pytest.raises(pmc.PMCError) as ei:
         pmc.mc_sweep(s, _disp_pool(pmc), nsweeps=1)
     assert ei.value.code == -4

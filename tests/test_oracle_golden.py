@@ -432,3 +432,54 @@ def test_checkerboard_rounds_and_periodic_images_keep_the_books_exact(O):
     c = O.Checkerboard(pos, sp, box, 1.0, models, seed=3)
     c.sweeps(pool, 0, 5, rounds=2)
     assert not np.array_equal(a.positions(), c.positions())             # m = 2 is a different (equally valid) chain
+
+
+def test_single_cell_boxes_in_the_oracle(O):
+    """Round 5: the parallel schedule on a box of 2 ... 4 cutoffs per side is ONE cell spanning the periodic box (orc_cb_create,
+    n_mc = 1) -- the plain Metropolis chain with a uniformly picked particle and global DoubleUniform picks.  On the reference's own
+    validation example (N = 1000 binary LJ, rcut = 4: examples/lj-mixture/run-validation.py:26-34): the exact total energy equals
+    the reference-order total, no slot is a null move, both acceptance rates and <e> agree with the reference's sequential chain
+    (src/moves.jl:57-81, 187-241) from the same start; boxes below two cutoffs, mixed boxes and more than 1024 particles stay
+    refused."""
+    from mixture import EPS, SIG, RCUT, make_config
+    pos, sp, rho = make_config(0.5, 0.8, seed=4)
+    T = 1.5
+    models = O.model_matrix(O.lennard_jones, EPS, SIG, rcut=RCUT, shift_potential=False)
+    spec = [{"kind": "Displacement", "sigma": 0.05, "probability": 0.9}, {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.1}]
+    pool = O.make_pool(spec)
+    seq = O.System(pos, sp, rho, T, models, O.LINKEDLIST)
+    cb = O.Checkerboard(pos, sp, seq.box, T, models, seed=11)
+    n_mc, w = cb.grid()
+    assert tuple(int(v) for v in n_mc) == (1, 1, 1) and np.array_equal(w, seq.box)
+    N = len(pos)
+    assert abs(cb.energy_fix / 2.0 ** 32 - seq.energy) <= 1e-9 * abs(seq.energy)
+    burn, prod = 40, 60
+    seq.mc_steps(pool, 11, 0, 0, burn * N)
+    cb.sweeps(pool, 0, burn)
+    es, ec = [], []
+    att_s, acc_s, att_c, acc_c = np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(2)
+    for t in range(prod):
+        a, b = seq.mc_steps(pool, 11, 0, (burn + t) * N, N)
+        att_s += a; acc_s += b
+        es.append(seq.energy / N)
+        a, b = cb.sweeps(pool, burn + t, 1)
+        att_c += a; acc_c += b
+        ec.append(cb.energy_fix / 2.0 ** 32 / N)
+    assert att_c.sum() == prod * N                                   # every slot is an attempted move ...
+    assert abs(acc_s[0] / att_s[0] - acc_c[0] / att_c[0]) < 0.02     # ... and none is a cell-leaving null move: same acceptance
+    assert abs(acc_s[1] / att_s[1] - acc_c[1] / att_c[1]) < 0.06
+    es, ec = np.array(es), np.array(ec)
+    def err(x):
+        b = x[: len(x) // 10 * 10].reshape(10, -1).mean(1)
+        return b.std(ddof=1) / np.sqrt(10)
+    assert abs(es.mean() - ec.mean()) < 4 * np.hypot(err(es), err(ec)) + 0.02
+    # the energy the schedule keeps is exact: a recomputation from the final state gives the same integer
+    assert cb.total_energy_fix() == cb.energy_fix
+    # refused: below two cutoffs per side; more than 1024 particles in a small box
+    small, sp_s, rho_s = lj_lattice(5, jitter=0.05, seed=1, rho=1.0)
+    with pytest.raises(ValueError):
+        O.Checkerboard(small, sp_s, np.array([5.0, 5.0, 5.0]), 1.0, O.single(O.lennard_jones(1.0, 1.0, 3.0)), seed=1)
+    big, sp_b, rho_b = lj_lattice(11, jitter=0.05, seed=1, rho=0.8)
+    Lb = (len(big) / 0.8) ** (1 / 3)
+    with pytest.raises(ValueError):
+        O.Checkerboard(big, sp_b, np.array([Lb, Lb, Lb]), 1.0, O.single(O.lennard_jones(1.0, 1.0, 4.0)), seed=1)

@@ -63,3 +63,14 @@ def test_the_guard_sees_the_pattern_it_guards_against():
     ok = "const double t = readlane_double(g_tlnu, my);\nif (lane == 0) { r[7] = t; }\n"
     m = LANE_BRANCH.search(ok)
     assert m and not CROSS.search(branch_body(ok, m.end()))
+
+
+def test_no_experiment_switches_in_the_product_sources():
+    """experiments live in LAB.md and in the history, not in the files the product compiles.  No `PMC_EXP_*`
+    symbol and no matrix-core reduction switch may come back into the kernel sources or the host code."""
+    import glob
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "particlesmc_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + [os.path.join(csrc, "Makefile")]):
+        txt = open(path).read()
+        for sym in ("PMC_EXP_", "PMC_MFMA_REDUCE"):
+            assert sym not in txt, f"{os.path.basename(path)} contains the experiment switch {sym}*"
