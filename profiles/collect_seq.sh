@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 4: profiles of the reference-order chain (PMC_SEQUENTIAL; pmc_seq.h).  Run through gpurun from the repo root:
+# Rounds 4-5: profiles of the reference-order chain, the team instance, the big-neighbourhood and single-cell instances (PMC_SEQUENTIAL; pmc_seq.h).  Run through gpurun from the repo root:
 #   gpurun --timeout 1800 -- 'bash profiles/collect_seq.sh'
 # It summarises ON the box (the raw traces exceed what gpurun merges back) into gpurun_out/seq_summary/; then, here:
 #   cp gpurun_out/seq_summary/* profiles/
@@ -25,7 +25,14 @@ python3 examples/seq_many.py 10 256 20 >> gpurun_out/seq_many_table.jsonl 2>&1
 rm -rf $P/teams_sq $P/teams_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/teams_trace -- python3 profiles/c2_run.py > $P/teams_run.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/teams_sq -- python3 profiles/c2_run.py > /dev/null 2>&1
+# round 5: the big-neighbourhood instance (published mixture at N = 8000) and the single-cell box (the same example as published, N = 1000)
+for w in big single; do
+  rm -rf $P/${w}_sq $P/${w}_trace
+  a=""; [ $w = single ] && a=single
+  rocprofv3 --kernel-trace --stats --output-format csv -d $P/${w}_trace -- python3 profiles/mix_run.py $a > $P/${w}_run.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/${w}_sq -- python3 profiles/mix_run.py $a > /dev/null 2>&1
+done
 mkdir -p gpurun_out/seq_summary
-PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py r04 --seq-only
-rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace
+PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py ${ROUND:-r05} --seq-only
+rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace $P/big_sq $P/big_trace $P/single_sq $P/single_trace
 ls gpurun_out/seq_summary

@@ -158,6 +158,29 @@ def _seq_summary():
         if "SQ_INSTS_VALU" in teams:
             teams["valu_wave_instructions_per_move"] = teams["SQ_INSTS_VALU"]["mean_per_launch"] / 32768.0
         json.dump(teams, open(os.path.join(OUT, f"{tag}_pmc_teams.json"), "w"), indent=1)
+    # round 5: the big-neighbourhood instance of k_cb_pass (published mixture, N = 8000) and the single-cell box (N = 1000 as published):
+    # the last 40 launches are the timed sweeps
+    for w, nmoves in (("big", 8000.0), ("single", 1000.0)):
+        rec = {}
+        for k, v in counters(w + "_sq").items():
+            if "k_cb_pass" in k:
+                rec["kernel"] = k
+                for c, vals in v.items():
+                    vals = vals[-40:]
+                    rec[c] = {"mean_per_launch": sum(vals) / max(1, len(vals)), "launches": len(vals)}
+        st = sorted(glob.glob(os.path.join(SRC, w + "_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+        if st:
+            shutil.copy(st[-1], os.path.join(OUT, f"{tag}_{w}_kernel_stats.csv"))
+            for r in csv.DictReader(open(st[-1])):
+                if "k_cb_pass" in r["Name"]:
+                    rec["avg_launch_us_all_launches"] = float(r["AverageNs"]) / 1e3
+        log = os.path.join(SRC, w + "_run.log")
+        if os.path.exists(log):
+            rec["run"] = [l.strip() for l in open(log) if l.startswith("{")][-1:]
+        if rec:
+            if "SQ_INSTS_VALU" in rec:
+                rec["valu_wave_instructions_per_move"] = rec["SQ_INSTS_VALU"]["mean_per_launch"] / nmoves
+            json.dump(rec, open(os.path.join(OUT, f"{tag}_pmc_{w}.json"), "w"), indent=1)
     if out:
         json.dump(out, open(os.path.join(OUT, f"{tag}_seq.json"), "w"), indent=1)
         print(f"wrote profiles/{tag}_seq.json")
