@@ -100,11 +100,18 @@ struct SqCtl {
     int pad_cur;
     unsigned long long gen_hi;    // steps < gen_hi have their random part in the ring (the host moves it between batches)
     unsigned long long f_next0;   // ... and the step of the first candidate
+    unsigned int arrive;          // k_sq_round_fused: workgroups of the launch that have finished their evaluation (0 between launches)
+    int pad_arrive;
+#ifdef PMC_DEBUG_TIME
+    unsigned long long t_first, t_end, tacc[8];     // stamped builds: phase clock of the fused rounds (s_memtime ticks)
+#endif
 };
 
 struct SqArgs {
     RefArgs a;
     double invbox[3];
+    double invcell[3];            // 1 / a.cell (sq_cell_of_fast)
+    double conf_r2;               // two steps that stay in their cells interact only within this squared distance (sq_sequence); 0: the cell rule
     SqSlot *slots[2];
     const SqGen *gen;
     unsigned long long *M;        // [K][SQ_KW] conflict bits with earlier slots
@@ -151,7 +158,24 @@ PMC_GLOBAL void k_sq_gen(SqGen *__restrict__ gen, unsigned long long gen_mask, u
     gen[g & gen_mask] = o;
 }
 
+#ifdef PMC_DEBUG_TIME
+__device__ unsigned long long g_sqt[16];      // stamped builds: phase clock of the evaluation of slot 0 (sums of s_memtime differences)
+#define SQE(k) do { if (w == 0 && threadIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                    if (wave_lane() == 0) { g_sqt[k] += now_ - g_sqt[15]; g_sqt[15] = now_; } } } while (0)
+#else
+#define SQE(k)
+#endif
+
 // ---- helpers -------------------------------------------------------------------------------------------------------------
+// what the workgroups of ONE launch hand to each other (k_sq_round_fused: the evaluation's results -> the workgroup that arrives
+// last): agent-scope relaxed accesses, as for the hand-off of the fused sweep (pmc_kernels.h, ld_agent / st_agent)
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int D>
 __device__ __forceinline__ void sq_cell_coords(const RefArgs &a, int c, int out[3])
 {
@@ -208,6 +232,41 @@ __device__ __forceinline__ int sq_cell_of(const RefArgs &a, const double *x)
         stride *= a.nc[q];
     }
     return edge ? ref_cell_of<D>(a, x) : (int)c;
+}
+
+// ... with the quotient from a product with 1 / cell and 32-bit cell arithmetic: the product is within two ulps of the division,
+// so outside a (wider) band around the cell edges its floor is the same integer; inside the band, and for positions many
+// boxes away, sq_cell_of decides.  (The three divisions and three 64-bit floor divisions of sq_cell_of were ~2 500 cycles of
+// every evaluation and ~5 000 of every admitted step's preparation.)
+template <int D>
+__device__ __forceinline__ int sq_cell_of_fast(const SqArgs &s, const double *x)
+{
+    const RefArgs &a = s.a;
+    int c = 0, stride = 1;
+    bool slow = false;
+#pragma unroll
+    for (int q = D - 1; q >= 0; q--) {
+        const double qv = x[q] * s.invcell[q];
+        const double f = floor(qv);
+        const double r = qv - f;
+        const double tol = fabs(qv) * 0x1p-44 + 0x1p-60;
+        slow = slow || r < tol || 1.0 - r < tol || !(fabs(qv) < 1.0e9);
+        const int n = a.nc[q];
+        int mc = (int)f;
+        if (mc < 0) mc += n;                       // the image next to the box; anything farther takes the general path
+        else if (mc >= n) mc -= n;
+        slow = slow || mc < 0 || mc >= n;
+        c += mc * stride;
+        stride *= n;
+    }
+    return slow ? sq_cell_of<D>(a, x) : c;
+}
+
+// a barrier among the lanes of ONE wavefront: what they stored has landed before any of them goes on
+__device__ __forceinline__ void sq_wave_sync()
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <int D>
@@ -299,12 +358,17 @@ __device__ __forceinline__ double *sq_terms_buffer(const SqArgs &s, int *lds_ids
 // cells is requested at once -- the populations, the first 64 ids of every row (speculatively: which of them exist is known when
 // the populations arrive) and, for step w >= 0, the heads of the cells' chains of pending steps -- one round trip to memory
 // instead of three.  Earlier pending steps found in those chains are recorded in row w of the conflict matrix (sq_conflicts).
-template <int D>
-__device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids, int w = -1)
+// NW wavefronts (k_sq_round_a / k_sq_round_fused with SQ_EW): each of them works out the cells and offsets, the rows are dealt
+// round-robin, the last wavefront walks the chains of pending steps.
+template <int D, int NW = 1>
+__device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids, int w = -1, const double *pa = nullptr, const double *pb = nullptr)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
+    constexpr int PER = (NN + NW - 1) / NW;
     const RefArgs &a = s.a;
     const int lane = wave_lane();
+    const int wv = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool walker = (NW == 1) || wv == NW - 1;
     // the neighbour cells in the reference's order (src/neighbours.jl:94-111: offsets -1, 0, +1, first dimension fastest).  With
     // three or more cells per side no two of them coincide (`unique!` removes nothing) and they follow from the cell's own
     // coordinates: no table, one memory round trip less; smaller grids read the table (entry and count in one round trip).
@@ -328,15 +392,19 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
         cnt = a.nbrcnt[c];
         cc = (lane < cnt) ? raw : 0;
     }
+    SQE(1);                                       // (entry of sq_sequence: the slot has arrived)
     const int len = (lane < cnt) ? a.ccount[cc] : 0;
-    int e = (w >= 0 && lane < cnt) ? s.cellhead[cc] : -1;
-    const int lane_in_row = lane < a.cl_cap ? lane : 0;
-    int v[NN];
+    int e = (w >= 0 && walker && lane < cnt) ? s.cellhead[cc] : -1;
+    const int cl_cap = a.cl_cap, reverse = s.reverse;
+    const int lane_in_row = lane < cl_cap ? lane : 0;
+    int v[PER];
 #pragma unroll
-    for (int l = 0; l < NN; l++) {
-        const int cc_l = __builtin_amdgcn_readlane(cc, l);
-        v[l] = a.cl_items[(size_t)cc_l * a.cl_cap + lane_in_row];
+    for (int k = 0; k < PER; k++) {
+        const int l = k * NW + wv;
+        const int cc_l = __builtin_amdgcn_readlane(cc, l < NN ? l : 0);
+        v[k] = a.cl_items[(size_t)cc_l * cl_cap + lane_in_row];
     }
+    SQE(2);                                       // populations, chain heads, rows
     int incl = len;
 #pragma unroll
     for (int sft = 1; sft < 32; sft <<= 1) {
@@ -348,33 +416,63 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
     const int maxlen = __reduce_max_sync_compat(len);
     __syncthreads();                              // the previous pass has read its ids
 #pragma unroll
-    for (int l = 0; l < NN; l++) {
-        const int len_l = __builtin_amdgcn_readlane(len, l);
-        const int off_l = __builtin_amdgcn_readlane(off, l);
-        if (lane < len_l) lds_ids[off_l + (s.reverse ? len_l - 1 - lane : lane)] = v[l];
-    }
-    if (maxlen > PMC_WAVE) {                      // rows longer than a wavefront (dense cells, long cutoffs)
-        for (int l = 0; l < cnt; l++) {
-            const int len_l = __shfl(len, l, PMC_WAVE), cc_l = __shfl(cc, l, PMC_WAVE), off_l = __shfl(off, l, PMC_WAVE);
-            for (int k = PMC_WAVE + lane; k < len_l; k += PMC_WAVE)
-                lds_ids[off_l + (s.reverse ? len_l - 1 - k : k)] = a.cl_items[(size_t)cc_l * a.cl_cap + k];
+    for (int k = 0; k < PER; k++) {
+        const int l = k * NW + wv;
+        if (l < NN) {
+            const int len_l = __builtin_amdgcn_readlane(len, l);
+            const int off_l = __builtin_amdgcn_readlane(off, l);
+            if (lane < len_l) lds_ids[off_l + (reverse ? len_l - 1 - lane : lane)] = v[k];
         }
     }
-    if (w >= 0) {
+    if (maxlen > PMC_WAVE) {                      // rows longer than a wavefront (dense cells, long cutoffs)
+        for (int l = wv; l < cnt; l += NW) {
+            const int len_l = __shfl(len, l, PMC_WAVE), cc_l = __shfl(cc, l, PMC_WAVE), off_l = __shfl(off, l, PMC_WAVE);
+            for (int k = PMC_WAVE + lane; k < len_l; k += PMC_WAVE)
+                lds_ids[off_l + (reverse ? len_l - 1 - k : k)] = a.cl_items[(size_t)cc_l * cl_cap + k];
+        }
+    }
+    SQE(3);                                       // ids in LDS
+    if (w >= 0 && walker) {
         // two steps interact iff some cell of one is within one cell of some cell of the other: every pending step is entered
         // under its cell(s) (k_sq_prep); bit t of row w for every EARLIER step t in the chains of this cell's neighbour cells
+        //
+        // Two Displacements that both stay in their cells (pa, pb: this step's position and trial position) interact only if
+        // the moved particle of one can be within a cutoff of the other's particle: whatever the earlier step t turns out to
+        // do, its particle is at x_t, at xn_t or (a reverted move, src/moves.jl:76-90) within an ulp of x_t, it stays in
+        // its row, and a particle that is beyond the largest cutoff of both pa and pb in every one of those places
+        // contributes the term 0 to this step's sums before and after -- the sums skip zeros, and the order of the other terms
+        // does not change.  So the bit is set only if one of the four distances is within the cutoff (conf_r2: the largest
+        // rcut^2 of the system, widened by 2^-20); steps that cross cells (their row operations) and swaps keep the cell rule.
+        // At N = 4096 a pair of pending steps conflicts with probability 3 % instead of 12.5 % (27 of 216 cells).
         unsigned long long *row = s.M + (size_t)w * SQ_KW;   // (zeroed by k_sq_prep)
+        const SqSlot *slots = s.slots[s.ctl->cur];
+        const double r2c = s.conf_r2;
         bool any = false;
         while (__any(e >= 0)) {
             if (e >= 0) {
                 const int t = e >> 1;
-                if (t < w) { atomicOr(&row[t >> 6], 1ull << (t & 63)); any = true; }
-                e = s.cellnext[e];
+                const int nxt = s.cellnext[e];
+                if (t < w) {
+                    bool hit = true;
+                    if (pa != nullptr) {
+                        const SqSlot &st = slots[t];
+                        if (!(st.flags & SQF_SWAP) && st.c0 == st.c1 && st.pk[3]) {
+                            double xt[3] = {0, 0, 0}, xnt[3] = {0, 0, 0};
+#pragma unroll
+                            for (int q = 0; q < D; q++) { xt[q] = st.x[q]; xnt[q] = st.xn[q]; }
+                            hit = !(sq_dist2<D>(s, pa, xt) > r2c) || !(sq_dist2<D>(s, pa, xnt) > r2c) ||
+                                  !(sq_dist2<D>(s, pb, xt) > r2c) || !(sq_dist2<D>(s, pb, xnt) > r2c);
+                        }
+                    }
+                    if (hit) { atomicOr(&row[t >> 6], 1ull << (t & 63)); any = true; }
+                }
+                e = nxt;
             }
         }
         if (__any(any) && lane == 0) atomicOr(&s.cp[w >> 6], 1ull << (w & 63));   // P: the step has an earlier potential conflict
     }
     __syncthreads();
+    SQE(4);                                       // chains of pending steps walked
     return total;
 }
 
@@ -389,7 +487,8 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
-    const int total = sq_sequence<D>(s, c, lds_ids, w);
+    const bool fine = BOTH && s.conf_r2 > 0.0;
+    const int total = sq_sequence<D>(s, c, lds_ids, w, fine ? xa : nullptr, fine ? xb : nullptr);
     double *bufa = sq_terms_buffer(s, lds_ids), *bufb = bufa + SQ_TERMS_BUF;
     double acc_a = 0.0, acc_b = 0.0;
     int na = 0, nb = 0;
@@ -408,6 +507,7 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
             for (int q = 0; q < 3; q++) xj[u][q] = (q < D) ? a.pos[(size_t)jj * D + q] : 0.0;
             sj[u] = (a.S > 1) ? a.species[jj] : 0;
         }
+        SQE(5);                                   // positions of a chunk
 #pragma unroll
         for (int u = 0; u < SQ_CHUNK; u++) {
             if (base + u * PMC_WAVE >= total) break;
@@ -428,8 +528,10 @@ __device__ __forceinline__ void sq_pass(const SqArgs &s, int c, int i, int spi, 
             sq_terms_push(bufa, na, ua);
             if (BOTH) sq_terms_push(bufb, nb, ub);
         }
+        SQE(6);                                   // pair terms of a chunk
     }
     sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
+    SQE(7);                                       // ordered sums
     ea = acc_a;
     eb = acc_b;
 }
@@ -485,19 +587,207 @@ __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int 
     e_after = acc_b;
 }
 
+// ---- the same passes by SQ_EW wavefronts ---------------------------------------------------------------------------------------------
+// One wavefront per pending step spends ~35 000 cycles on it (stamped build, N = 4096: 13 000 in the eight trips of pair terms,
+// 5 000 moving the rows into LDS, 4 500 in the two ordered sums) while the chip is all but empty -- a window is 64 .. 2048
+// steps, the device has 1024 SIMDs.  Here SQ_EW wavefronts share a step: the trips are dealt round-robin, every trip packs its
+// non-zero terms into its own segment of LDS (followed by eight zeros, so that the sums read whole blocks), and once all
+// trips are in, wavefront 0 runs the chain of additions of the first sum and wavefront 1 that of the second, in trip order,
+// the next block's reads in flight while this block's additions run.  Same terms, same order, same bits.
+#define SQ_EW 4
+#define SQ_TRMAX 16                  // trips whose segments the LDS holds at once (1024 candidates; longer sequences: in several goes)
+#define SQ_SEG (PMC_WAVE + SQ_TERMS_PAD)
+
+// the evaluation's dynamic LDS with SQ_EW wavefronts: ids (twice), two sets of segments, the two sums, the segments' term counts
+__host__ __device__ inline size_t sq_eval_lds_bytes(int ids_cap, int nw)
+{
+    const size_t ids = (size_t)((ids_cap + 3) & ~3) * sizeof(int);
+    return nw == 1 ? ids + 2 * (size_t)SQ_TERMS_BUF * sizeof(double)
+                   : 2 * ids + (2 * (size_t)SQ_TRMAX * SQ_SEG + 2) * sizeof(double) + 2 * SQ_TRMAX * sizeof(int);   // (two sequences: a crossing step's)
+}
+
+__device__ __forceinline__ int sq_terms_push_seg(double *seg, double u)
+{
+    const unsigned long long mk = __ballot(u != 0.0);
+    const int n = __popcll(mk), lane = wave_lane();
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+    if (u != 0.0) seg[rank] = u;
+    if (lane < SQ_TERMS_PAD) seg[n + lane] = 0.0;               // (+0.0 leaves a sum as it is: the chain reads blocks of 8)
+    return n;
+}
+
+// acc += every term of the first nt segments, in order; one wavefront, every lane the same chain
+__device__ __forceinline__ double sq_terms_chain(const double *buf, const int *tcount, int nt, double acc)
+{
+    const int lane = wave_lane();
+    const int cntv = (lane < nt) ? tcount[lane] : 0;            // lane l: terms of segment l
+    int tr = 0;
+    while (tr < nt && __builtin_amdgcn_readlane(cntv, tr) == 0) tr++;
+    if (tr >= nt) return acc;
+    int k = 0;
+    double cur[SQ_TERMS_PAD];
+#pragma unroll
+    for (int q = 0; q < SQ_TERMS_PAD; q++) cur[q] = buf[tr * SQ_SEG + q];
+    for (;;) {
+        int ntr = tr, nk = k + SQ_TERMS_PAD;
+        if (nk >= __builtin_amdgcn_readlane(cntv, tr)) {
+            nk = 0;
+            ntr = tr + 1;
+            while (ntr < nt && __builtin_amdgcn_readlane(cntv, ntr) == 0) ntr++;
+        }
+        const bool more = ntr < nt;
+        double nxt[SQ_TERMS_PAD];
+#pragma unroll
+        for (int q = 0; q < SQ_TERMS_PAD; q++) nxt[q] = more ? buf[ntr * SQ_SEG + nk + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < SQ_TERMS_PAD; q++) acc += cur[q];
+        if (!more) break;
+#pragma unroll
+        for (int q = 0; q < SQ_TERMS_PAD; q++) cur[q] = nxt[q];
+        tr = ntr;
+        k = nk;
+    }
+    return acc;
+}
+
+// the trips of one go of one sequence that fall to this wavefront: positions gathered, pair terms packed into the trips' segments
+// TM 0: the term at xa (-> bufa); 1: at xa (-> bufa) and at xb (-> bufb); 2: a DiscreteSwap's particle at xa with species spa
+// (-> bufa) and with spb, the partner `other` then having spa (-> bufb) -- sq_pass / sq_pass_swap above, term for term
+template <int D, int TM, int KIND, int NW>
+__device__ __forceinline__ void sq_mw_trips(const SqArgs &s, const int *ids, int total, int tr0, int ntrip, int wv, int i, int spa, int spb, int other,
+                                            const double *xa, const double *xb, const double *L, const double *iL,
+                                            double *bufa, double *bufb, int *tca, int *tcb, int w)
+{
+    constexpr int PERW = SQ_TRMAX / NW;
+    const RefArgs &a = s.a;
+    const int lane = wave_lane();
+    const int S = a.S;
+    const double *__restrict__ pos = a.pos;
+    const int *__restrict__ species = a.species;
+    const DevModel *rowa = a.models + (size_t)spa * S, *rowb = a.models + (size_t)spb * S;
+    int j[PERW], sj[PERW];
+    double xj[PERW][3];
+#pragma unroll
+    for (int u = 0; u < PERW; u++) {
+        const int t = (tr0 + wv + u * NW) * PMC_WAVE + lane;
+        j[u] = (t < total) ? ids[t] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < PERW; u++) {
+        const int jj = j[u] < 0 ? 0 : j[u];
+#pragma unroll
+        for (int q = 0; q < 3; q++) xj[u][q] = (q < D) ? pos[(size_t)jj * D + q] : 0.0;
+        sj[u] = (S > 1) ? species[jj] : 0;
+    }
+    SQE(5);                                   // positions of this wavefront's trips
+#pragma unroll
+    for (int u = 0; u < PERW; u++) {
+        const int tr = tr0 + wv + u * NW;
+        if (tr >= ntrip) break;
+        double ua = 0.0, ub = 0.0;
+        if (j[u] >= 0 && j[u] != i) {                                        // src/atoms.jl:68
+            double r2a = 0.0, r2b = 0.0;
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                const double va = sq_vector_1d(xa[q], xj[u][q], L[q], iL[q]);
+                r2a = (q == 0) ? va * va : r2a + va * va;
+                if (TM == 1) {
+                    const double vb = sq_vector_1d(xb[q], xj[u][q], L[q], iL[q]);
+                    r2b = (q == 0) ? vb * vb : r2b + vb * vb;
+                }
+            }
+            const DevModel &ma = rowa[sj[u]];
+            if (!(r2a > ma.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2a, ma) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, ma));          // src/atoms.jl:72-73
+            if (TM == 1) {
+                if (!(r2b > ma.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2b, ma) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2b, ma));
+            } else if (TM == 2) {
+                const DevModel &mb = rowb[j[u] == other ? spa : sj[u]];
+                if (!(r2a > mb.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2a, mb) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, mb));
+            }
+        }
+        const int sg = tr - tr0;
+        const int ca = sq_terms_push_seg(bufa + sg * SQ_SEG, ua);
+        if (lane == 0) tca[sg] = ca;
+        if (TM != 0) {
+            const int cb = sq_terms_push_seg(bufb + sg * SQ_SEG, ub);
+            if (lane == 0) tcb[sg] = cb;
+        }
+    }
+    SQE(6);                                   // pair terms of this wavefront's trips
+}
+
+// MODE 0: compute_energy_particle at xa over the sequence of cell c; 1: at xa and at xb over that sequence; 2: a DiscreteSwap's
+// particle (see sq_mw_trips); 3: a Displacement that crosses cells -- at xa over the sequence of c and at xb over the sequence of
+// cb, the two sequences side by side in LDS, their trips in the same goes, their sums on two wavefronts at once (one after the
+// other they made a crossing step 1.7 times as long as any other, and nearly every round has one)
+template <int D, int MODE, int KIND, int NW>
+__device__ __forceinline__ void sq_pass_mw(const SqArgs &s, int c, int cb, int i, int spa, int spb, int other, const double *xa, const double *xb,
+                                           int *lds_ids, double &ea, double &eb, int w)
+{
+    static_assert(NW > 1 && SQ_TRMAX % NW == 0, "the trips of one go are dealt evenly");
+    const RefArgs &a = s.a;
+    const int lane = wave_lane();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int idsz = (s.ids_cap + 3) & ~3;
+    int *idsb = lds_ids + idsz;
+    const bool fine = MODE == 1 && s.conf_r2 > 0.0;
+    const int total = sq_sequence<D, NW>(s, c, lds_ids, w, fine ? xa : nullptr, fine ? xb : nullptr);
+    const int totalb = (MODE == 3) ? sq_sequence<D, NW>(s, cb, idsb, w) : 0;
+    double *bufa = reinterpret_cast<double *>(lds_ids + 2 * idsz), *bufb = bufa + SQ_TRMAX * SQ_SEG, *esum = bufb + SQ_TRMAX * SQ_SEG;
+    int *tcount = reinterpret_cast<int *>(esum + 2);
+    double L[3] = {1, 1, 1}, iL[3] = {1, 1, 1};
+#pragma unroll
+    for (int q = 0; q < D; q++) { L[q] = a.box[q]; iL[q] = s.invbox[q]; }
+    const int ntrip = (total + PMC_WAVE - 1) / PMC_WAVE, ntripb = (totalb + PMC_WAVE - 1) / PMC_WAVE;
+    const int ngo = max(ntrip, ntripb);
+    double acc = 0.0;                                   // wavefront 0: the first sum, wavefront 1: the second
+    for (int tr0 = 0; tr0 < ngo; tr0 += SQ_TRMAX) {
+        if (MODE == 3) {
+            sq_mw_trips<D, 0, KIND, NW>(s, lds_ids, total, tr0, ntrip, wv, i, spa, spa, -1, xa, xa, L, iL, bufa, bufa, tcount, tcount, w);
+            sq_mw_trips<D, 0, KIND, NW>(s, idsb, totalb, tr0, ntripb, wv, i, spa, spa, -1, xb, xb, L, iL, bufb, bufb, tcount + SQ_TRMAX, tcount + SQ_TRMAX, w);
+        } else {
+            sq_mw_trips<D, MODE, KIND, NW>(s, lds_ids, total, tr0, ntrip, wv, i, spa, spb, other, xa, xb, L, iL, bufa, bufb, tcount, tcount + SQ_TRMAX, w);
+        }
+        __syncthreads();
+        if (wv == 0) acc = sq_terms_chain(bufa, tcount, max(0, min(SQ_TRMAX, ntrip - tr0)), acc);
+        else if (MODE != 0 && wv == 1) acc = sq_terms_chain(bufb, tcount + SQ_TRMAX, max(0, min(SQ_TRMAX, (MODE == 3 ? ntripb : ntrip) - tr0)), acc);
+        if (tr0 + SQ_TRMAX < ngo) __syncthreads();                               // (the segments are free for the next go)
+    }
+    if (lane == 0 && wv == 0) esum[0] = acc;
+    if (lane == 0 && wv == 1) esum[1] = (MODE != 0) ? acc : 0.0;
+    __syncthreads();
+    SQE(7);                                       // ordered sums
+    ea = esum[0];
+    eb = esum[1];
+}
+
+template <int D, int MODE, int KIND, int NW>
+__device__ __forceinline__ void sq_energy(const SqArgs &s, int c, int i, int spa, int spb, int other, const double *xa, const double *xb,
+                                          int *lds_ids, double &ea, double &eb, int w)
+{
+    if constexpr (NW == 1) {
+        if constexpr (MODE == 2) sq_pass_swap<D, KIND>(s, c, i, spa, spb, other, xa, lds_ids, ea, eb, w);
+        else sq_pass<D, MODE == 1, KIND>(s, c, i, spa, xa, xb, lds_ids, ea, eb, w);
+    } else {
+        sq_pass_mw<D, MODE, KIND, NW>(s, c, c, i, spa, spb, other, xa, xb, lds_ids, ea, eb, w);
+    }
+}
+
 __device__ __forceinline__ bool sq_bits_differ(double p, double q)
 {
     return __double_as_longlong(p) != __double_as_longlong(q);
 }
 
 // ---- one step, evaluated against the current state (nothing is written but the slot) --------------------------------------
-template <int D, int KIND = 4>
+template <int D, int KIND = 4, int NW = 1>
 __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 {
     const RefArgs &a = s.a;
+    PMC_TIME(if (w == 0 && threadIdx.x == 0) g_sqt[15] = __builtin_amdgcn_s_memtime();)
     SqSlot &sl = s.slots[s.ctl->cur][w];
     const int lane = wave_lane();
     int flags = sl.flags & (SQF_SWAP | SQF_NULL);
+    SQE(0);                                       // control block + first slot word
     if (flags & SQF_NULL) return;
     double e1, e2;
     if (!(flags & SQF_SWAP)) {
@@ -510,14 +800,18 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
             xr[q] = xn[q] + (-sl.d[q]);                // ... and the reverted position (src/moves.jl:76-90)
         }
         const int c0 = sl.c0, c1 = sl.c1;
-        const int c2 = sq_cell_of<D>(a, xr);
+        const int c2 = sq_cell_of_fast<D>(s, xr);
         const int spi = a.S > 1 ? a.species[i] : 0;
         if (c1 == c0) {
-            sq_pass<D, true, KIND>(s, c0, i, spi, x, xn, lds_ids, e1, e2, w);
+            sq_energy<D, 1, KIND, NW>(s, c0, i, spi, spi, -1, x, xn, lds_ids, e1, e2, w);
         } else {
-            double dummy;
-            sq_pass<D, false, KIND>(s, c0, i, spi, x, x, lds_ids, e1, dummy, w);
-            sq_pass<D, false, KIND>(s, c1, i, spi, xn, xn, lds_ids, e2, dummy, w);
+            if constexpr (NW == 1) {
+                double dummy;
+                sq_energy<D, 0, KIND, NW>(s, c0, i, spi, spi, -1, x, x, lds_ids, e1, dummy, w);
+                sq_energy<D, 0, KIND, NW>(s, c1, i, spi, spi, -1, xn, xn, lds_ids, e2, dummy, w);
+            } else {
+                sq_pass_mw<D, 3, KIND, NW>(s, c0, c1, i, spi, spi, -1, x, xn, lds_ids, e1, e2, w);
+            }
             flags |= SQF_CROSSED;
         }
         const bool ok = sl.lnu < -(e2 - e1) / a.temperature;    // src/utils.jl:8-10 (forward / backward log q cancel)
@@ -527,10 +821,10 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
         if (ok) flags |= SQF_ACCEPT;
         if (ok || c1 != c0 || rejchg || c2 != c0) flags |= SQF_CHANGED;
         if (!ok && c2 != c0) flags |= SQF_EXOTIC;
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
 #pragma unroll
-            for (int q = 0; q < D; q++) sl.xr[q] = xr[q];
-            sl.c2 = c2;
+            for (int q = 0; q < D; q++) st_agent(&sl.xr[q], xr[q]);
+            st_agent(&sl.c2, c2);
         }
     } else {
         const int i = sl.i, j = sl.j;
@@ -539,39 +833,41 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
         for (int q = 0; q < D; q++) { xi[q] = sl.x[q]; xj[q] = sl.xn[q]; }
         const int spi = a.species[i], spj = a.species[j];
         double e1i, e2i, e1j, e2j;
-        sq_pass_swap<D, KIND>(s, sl.c0, i, spi, spj, j, xi, lds_ids, e1i, e2i, w);
-        sq_pass_swap<D, KIND>(s, sl.c1, j, spj, spi, i, xj, lds_ids, e1j, e2j, w);
+        sq_energy<D, 2, KIND, NW>(s, sl.c0, i, spi, spj, j, xi, xi, lds_ids, e1i, e2i, w);
+        sq_energy<D, 2, KIND, NW>(s, sl.c1, j, spj, spi, i, xj, xj, lds_ids, e1j, e2j, w);
         e1 = e1i + e1j;                                 // src/moves.jl:166
         e2 = e2i + e2j;
         const bool ok = sl.lnu < -(e2 - e1) / a.temperature;
         if (ok) flags |= SQF_ACCEPT | SQF_CHANGED;      // a reverted swap restores species and SpeciesList exactly
-        if (lane == 0) { sl.spi = spi; sl.spj = spj; }
+        if (threadIdx.x == 0) { st_agent(&sl.spi, spi); st_agent(&sl.spj, spj); }
     }
     double de = 0.0;
     if (!(isinf(e1) || isinf(e2))) {                    // src/moves.jl:13-18
         de = e2 - e1;
         flags |= SQF_FINITE;
     }
-    if (lane == 0) {
-        sl.de = de;
-        sl.flags = flags;
+    if (threadIdx.x == 0) {                             // (agent-scope stores: in a fused round another workgroup of this launch reads them)
+        st_agent(&sl.de, de);
+        st_agent(&sl.flags, flags);
         if (flags & SQF_CHANGED) atomicOr(&s.cp[w >> 6], 1ull << (w & 63));
         if (flags & SQF_EXOTIC) {
-            if (w == 0) s.ctl->exclusive = 1;
+            if (w == 0) st_agent(&s.ctl->exclusive, 1);
             else atomicMin(&s.ctl->trunc, w);
         }
     }
+    SQE(8);                                       // decision, results stored
+    PMC_TIME(if (w == 0 && threadIdx.x == 0) g_sqt[9] += 1;)
 }
 
 // ---- round, third launch: every pending step finds the earlier steps it could interact with and is evaluated --------------------------------------
-template <int D, int KIND = 4>
-__global__ __launch_bounds__(64) void k_sq_round_a(const SqArgs *__restrict__ tab)
+template <int D, int KIND = 4, int NW = 1>
+__global__ __launch_bounds__(NW * 64) void k_sq_round_a(const SqArgs *__restrict__ tab)
 {
     const SqArgs &s = tab[blockIdx.y];
     extern __shared__ int sq_lds[];
     const int b = blockIdx.x;
     if (b < s.ctl->nslots) {
-        if (!(s.dbg & 4)) sq_eval<D, KIND>(s, b, sq_lds);
+        if (!(s.dbg & 4)) sq_eval<D, KIND, NW>(s, b, sq_lds);
     }
 }
 
@@ -600,13 +896,13 @@ __device__ __forceinline__ void sq_row_remove(const SqArgs &s, int c, int i)
         const int k = base + lane;
         int v = 0;
         if (k < n - 1) v = row[k + 1];
-        __syncthreads();
+        sq_wave_sync();
         if (k < n - 1) row[k] = v;
-        __syncthreads();
+        sq_wave_sync();
     }
     if (lane == 0) a.ccount[c] = n - 1;
-    __threadfence();
-    __syncthreads();
+    sq_wave_sync();                                     // (the rows a launch edits are read by this wavefront only: no device-scope fence,
+                                                        // no workgroup barrier -- the other wavefronts of a fused round commit other steps)
 }
 
 __device__ __forceinline__ void sq_row_append(const SqArgs &s, int c, int i)
@@ -627,8 +923,7 @@ __device__ __forceinline__ void sq_row_append(const SqArgs &s, int c, int i)
             a.cs[i] = c;
         }
     }
-    __threadfence();
-    __syncthreads();
+    sq_wave_sync();
 }
 
 template <int D>
@@ -749,7 +1044,8 @@ __device__ __forceinline__ int sq_table_owner(const int *keys, const int *vals, 
 }
 
 // NT threads admit for windows of up to 4 NT slots (k_sq_fill: 1024 threads)
-template <int D, int NT>
+// (AG: the COMMITTED flags were written in this launch -- k_sq_round_fused)
+template <int D, int NT, bool AG = false>
 __device__ __forceinline__ void sq_fill_block(const SqArgs &s, int *sq_table, int *lds)
 {
     const RefArgs &a = s.a;
@@ -784,7 +1080,7 @@ __device__ __forceinline__ void sq_fill_block(const SqArgs &s, int *sq_table, in
     for (int r = 0; r < PER; r++) {
         const int w = r * NT + tid;
         int fl = SQF_COMMITTED, pi = -1, pj = -1;
-        if (w < nold) { fl = src[w].flags; pi = src[w].i; pj = src[w].j; }
+        if (w < nold) { fl = AG ? ld_agent(&src[w].flags) : src[w].flags; pi = src[w].i; pj = src[w].j; }
         const bool keep = !(fl & SQF_COMMITTED);
         int tot;
         const int at = nkeep + sq_block_scan_excl<NT>(keep ? 1 : 0, lds, &tot);   // (its barriers also cover the table's initialisation)
@@ -897,7 +1193,8 @@ __device__ __forceinline__ void sq_prep_thread(const SqArgs &s, const int t)
     if (t < nold) {
         const int to = s.moveto[t];
         if (to >= 0) {
-            const SqSlot sl = s.slots[cur ^ 1][t];
+            SqSlot sl = s.slots[cur ^ 1][t];
+            sl.flags &= (SQF_SWAP | SQF_NULL);          // (what the last evaluation found is void; in a fused round it may not even be visible here)
             dst[to] = sl;
             if (sl.pk[3]) {                             // entered under its cell(s): sq_conflicts walks these chains
                 s.cellnext[2 * to] = atomicExch(&s.cellhead[sl.c0], 2 * to);
@@ -927,8 +1224,8 @@ __device__ __forceinline__ void sq_prep_thread(const SqArgs &s, const int t)
         sl.xr[k] = 0.0;
     }
     if (i >= 0) {                                       // (a null step has no cells and interacts with nothing)
-        sl.c0 = sq_cell_of<D>(a, sl.x);
-        sl.c1 = sq_cell_of<D>(a, sl.xn);
+        sl.c0 = sq_cell_of_fast<D>(s, sl.x);
+        sl.c1 = sq_cell_of_fast<D>(s, sl.xn);
         sl.c2 = sl.c0;
         sl.pk[3] = 1;
         const int to = nkeep + q;
@@ -942,6 +1239,149 @@ template <int D>
 __global__ __launch_bounds__(256) void k_sq_prep(const SqArgs *__restrict__ tab)
 {
     sq_prep_thread<D>(tab[blockIdx.y], (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+// ---- small windows: a round as ONE launch --------------------------------------------------------------------------------------
+// A round of the windows is four launches (fill, prep, evaluation, commit), each with a floor of ~4.5 us however little it
+// does: with windows of 64 .. 256 steps -- what systems below ~10^5 particles get -- that floor IS the round (N = 4096: 7.6
+// steps per 34 us).  Here a launch is the evaluation of the window the last launch prepared, by K workgroups of one wavefront,
+// and then -- in the workgroup that finishes LAST (an arrival counter; no workgroup waits for another) -- the commit of every
+// step, the admission and the preparation of the next window, one lane per slot.  What crosses workgroups inside the launch
+// are the evaluation's results only (slot fields, conflict rows, the cp words, trunc / exclusive): written with agent-scope
+// stores and atomics, drained (s_waitcnt) before the arrival, read with agent-scope loads behind it -- the hand-off of the
+// fused sweep (pmc_kernels.h, publish_done), with no cache write-back or invalidate.  (Four phases behind grid barriers in one
+// persistent launch were measured first: 7-9 us per barrier, slower than the launches -- LAB.md.)  Same chain, bit for bit.
+#define SQ_FUSED_KMAX 256
+
+template <int D, int NW>
+__device__ __forceinline__ void sq_commit_lanes(const SqArgs &s)
+{
+    const RefArgs &a = s.a;
+    const int lane = wave_lane();
+    const int wv = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SqCtl *ctl = s.ctl;
+    const int nslots = ctl->nslots;
+    SqSlot *slots = s.slots[ctl->cur];
+    const int trunc = ld_agent(&ctl->trunc), excl = ld_agent(&ctl->exclusive);
+    unsigned long long cpw[SQ_FUSED_KMAX / 64];
+#pragma unroll
+    for (int k = 0; k < SQ_FUSED_KMAX / 64; k++) cpw[k] = ld_agent(&s.cp[k]);
+    for (int base = wv * PMC_WAVE; base < nslots; base += NW * PMC_WAVE) {
+        const int w = base + lane;
+        const bool valid = w < nslots;
+        SqSlot &sl = slots[valid ? w : 0];
+        const int i = sl.i, c0 = sl.c0, c1 = sl.c1;
+        if (valid && sl.pk[3]) {                            // (atomics of the next preparation act on these words)
+            st_agent(&s.cellhead[c0], -1);
+            st_agent(&s.cellhead[c1], -1);
+        }
+        unsigned long long hit = 0;                         // the hold rule of sq_commit_wave
+#pragma unroll
+        for (int k = 0; k < SQ_FUSED_KMAX / 64; k++)
+            if (valid && k <= (w >> 6)) hit |= ld_agent(&s.M[(size_t)w * SQ_KW + k]) & cpw[k];
+        const bool hold = !valid || hit != 0 || w >= trunc || (excl && w != 0);
+        const int flags = valid ? ld_agent(&sl.flags) : 0;
+        int c2 = c0;
+        bool rows = false;
+        if (!hold && !(flags & SQF_NULL)) {
+            if (!(flags & SQF_SWAP)) {
+                if (flags & SQF_ACCEPT) {
+#pragma unroll
+                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = sl.xn[q];
+                    rows = c1 != c0;
+                } else if (flags & SQF_CHANGED) {
+                    c2 = ld_agent(&sl.c2);
+#pragma unroll
+                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = ld_agent(&sl.xr[q]);
+                    rows = (c1 != c0) || (c2 != c1);
+                }
+            } else if (flags & SQF_ACCEPT) {
+                rows = true;
+            }
+        }
+        // steps that edit cell rows or the SpeciesList: whole-wavefront operations, one step after the other (they touch
+        // disjoint cells / species entries: the order among them is free, as it is among the workgroups of k_sq_commit)
+        unsigned long long todo = __ballot(rows);
+        while (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int fl = __shfl(flags, l, PMC_WAVE), ii = __shfl(i, l, PMC_WAVE);
+            const int d0 = __shfl(c0, l, PMC_WAVE), d1 = __shfl(c1, l, PMC_WAVE), d2 = __shfl(c2, l, PMC_WAVE);
+            if (!(fl & SQF_SWAP)) {
+                if (fl & SQF_ACCEPT) {
+                    sq_row_remove(s, d0, ii); sq_row_append(s, d1, ii);
+                } else if (d1 != d0 && d2 == d0) {
+                    sq_row_remove(s, d0, ii); sq_row_append(s, d0, ii);
+                } else {
+                    if (d1 != d0) { sq_row_remove(s, d0, ii); sq_row_append(s, d1, ii); }
+                    if (d2 != d1) { sq_row_remove(s, d1, ii); sq_row_append(s, d2, ii); }
+                }
+            } else if (lane == 0) {
+                SqSlot &sq = slots[base + l];
+                const int j = sq.j, spi = ld_agent(&sq.spi), spj = ld_agent(&sq.spj);
+                a.species[ii] = spj;                                // src/moves.jl:162-163
+                a.species[j] = spi;
+                ref_update_species_list(a, s.pool.sp0[sq.m], s.pool.sp1[sq.m], ii, j);
+            }
+        }
+        if (!hold) {
+            SqLog &lg = s.log[sl.g & s.ring_mask];
+            lg.de = ld_agent(&sl.de);
+            lg.tag = (uint32_t)sl.g;
+            int f = SQL_DONE | (sl.m << 4);
+            if (flags & SQF_ACCEPT) f |= SQL_ACCEPT;
+            if (flags & SQF_FINITE) f |= SQL_FINITE;
+            if (flags & SQF_NULL) f |= SQL_NULL;
+            lg.flag = f;
+            st_agent(&sl.flags, flags | SQF_COMMITTED);
+        }
+    }
+}
+
+template <int D, int KIND = 4, int NW = 1>
+__global__ __launch_bounds__(NW * 64) void k_sq_round_fused(const SqArgs *__restrict__ tab)
+{
+    const SqArgs &s = tab[blockIdx.y];
+    extern __shared__ int sq_lds[];              // the evaluation's ids and term buffers; the last workgroup also: the admission's hash table
+    __shared__ int fill_lds[NW + 4];
+    SqCtl *ctl = s.ctl;
+    const int b = blockIdx.x;
+    PMC_TIME(const unsigned long long t_in = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicMin(&ctl->t_first, t_in);)
+    if (b < ctl->nslots && !(s.dbg & 4)) sq_eval<D, KIND, NW>(s, b, sq_lds);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wavefront's stores and atomics have landed
+    __syncthreads();                                                  // ... every wavefront's of the workgroup
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old == gridDim.x - 1u) ? 1 : 0;
+        if (last) __hip_atomic_store(&ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fill_lds[NW + 3] = last;
+    }
+    __syncthreads();
+    if (!fill_lds[NW + 3]) return;
+    asm volatile("" ::: "memory");
+    PMC_TIME(const unsigned long long t1 = __builtin_amdgcn_s_memtime();)
+    sq_commit_lanes<D, NW>(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    PMC_TIME(const unsigned long long t2 = __builtin_amdgcn_s_memtime();)
+    sq_fill_block<D, NW * PMC_WAVE, true>(s, sq_lds, fill_lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    PMC_TIME(const unsigned long long t3 = __builtin_amdgcn_s_memtime();)
+    for (int t = threadIdx.x; t < 2 * s.K; t += NW * PMC_WAVE) sq_prep_thread<D>(s, t);
+    PMC_TIME(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+             if (threadIdx.x == 0) {
+                 const unsigned long long t4 = __builtin_amdgcn_s_memtime(), tf = ld_agent(&ctl->t_first);
+                 ctl->tacc[0] += t_in - tf;            // first workgroup of the launch -> entry of the last one to arrive
+                 ctl->tacc[1] += t1 - t_in;            // its evaluation
+                 ctl->tacc[2] += t2 - t1;              // commit
+                 ctl->tacc[3] += t3 - t2;              // admission
+                 ctl->tacc[4] += t4 - t3;              // preparation
+                 if (ctl->t_end) ctl->tacc[5] += tf - ctl->t_end;     // end of the last launch -> first workgroup of this one
+                 ctl->tacc[6] += 1;
+                 ctl->t_end = t4;
+                 ctl->t_first = ~0ull;
+             })
 }
 
 // The rows of a LinkedList whose chains already exist (moves have shaped their order: src/neighbours.jl:276-302): the row of

@@ -204,6 +204,10 @@ struct SeqGroup {
     int n = 0, K = 0;
     size_t lds = 0, lds_fill = 0;
     const void *k_eval = nullptr;     // k_sq_round_a for the group's dimension and model kind
+    const void *k_fused = nullptr;    // k_sq_round_fused likewise
+    int nw = SQ_EW;                   // wavefronts per evaluated step (PMC_SEQ_EW=1: one, the A/B partner)
+    bool fused = false;               // windows of <= SQ_FUSED_KMAX: a round is one launch (evaluate; the last workgroup commits, admits, prepares)
+    bool primed = false;              // ... after the first window of the call has been admitted and prepared by k_sq_fill + k_sq_prep
     long long rounds_last = 0, rounds_folded = 0;     // rounds of the batch enqueued last / of the batch being folded
     hipGraphExec_t graph = nullptr;   // SQ_GRAPH_ROUNDS rounds, captured once per call (a group of one caches it on the handle)
     bool own_graph = false;
@@ -222,15 +226,19 @@ static void seq_launch_round(const SeqGroup &g)
     const int K = g.K, n = g.n;
     const SqArgs *tab = g.d_tab;
     void *kargs[1] = {(void *)&tab};
+    if (g.fused) {
+        (void)hipLaunchKernel(g.k_fused, dim3(K, n), dim3(64 * g.nw), kargs, std::max(g.lds, g.lds_fill), h->stream);
+        return;
+    }
     if (h->D == 3) {
         hipLaunchKernelGGL(k_sq_fill<3>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
         hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
-        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64), kargs, g.lds, h->stream);
+        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64 * g.nw), kargs, g.lds, h->stream);
         hipLaunchKernelGGL(k_sq_commit<3>, dim3(K, n), dim3(64), 0, h->stream, g.d_tab);
     } else {
         hipLaunchKernelGGL(k_sq_fill<2>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
         hipLaunchKernelGGL(k_sq_prep<2>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
-        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64), kargs, g.lds, h->stream);
+        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64 * g.nw), kargs, g.lds, h->stream);
         hipLaunchKernelGGL(k_sq_commit<2>, dim3(K, n), dim3(64), 0, h->stream, g.d_tab);
     }
 }
@@ -242,7 +250,8 @@ static int seq_graph(SeqGroup &g)
 {
     pmc_system *h = g.lead;
     if (g.graph) return PMC_OK;
-    if (g.n == 1 && h->sq_graph && h->sq_graph_K == g.K && memcmp(&h->sq_graph_args, &g.runs[0].s, sizeof(SqArgs)) == 0) {
+    const int graph_key = (g.fused ? -g.K : g.K) * 8 + g.nw;
+    if (g.n == 1 && h->sq_graph && h->sq_graph_K == graph_key && memcmp(&h->sq_graph_args, &g.runs[0].s, sizeof(SqArgs)) == 0) {
         g.graph = h->sq_graph;
         return PMC_OK;
     }
@@ -259,7 +268,7 @@ static int seq_graph(SeqGroup &g)
         if (h->sq_graph) (void)hipGraphExecDestroy(h->sq_graph);
         h->sq_graph = ex;
         h->sq_graph_args = g.runs[0].s;
-        h->sq_graph_K = g.K;
+        h->sq_graph_K = graph_key;
     } else {
         g.own_graph = true;
     }
@@ -282,7 +291,12 @@ static int seq_run_begin(SeqRun &r, pmc_system *h, const pmc_move *pool, int npo
     SqArgs &s = r.s;
     memset(&s, 0, sizeof s);
     s.a = ref_args(h);
-    for (int q = 0; q < 3; q++) s.invbox[q] = 1.0 / s.a.box[q];
+    for (int q = 0; q < 3; q++) { s.invbox[q] = 1.0 / s.a.box[q]; s.invcell[q] = (q < h->D) ? 1.0 / s.a.cell[q] : 1.0; }
+    s.conf_r2 = 0.0;                                       // PMC_SEQ_CELLRULE=1: the cell rule for every pair of steps (the A/B partner)
+    if (!getenv("PMC_SEQ_CELLRULE")) {
+        for (const pmc_pair_model &pm : h->models) s.conf_r2 = std::max(s.conf_r2, pm.rcut2);
+        s.conf_r2 *= 1.0 + 0x1p-20;
+    }
     s.slots[0] = h->d_sq_slots[0];
     s.slots[1] = h->d_sq_slots[1];
     s.gen = h->d_sq_gen;
@@ -309,6 +323,7 @@ static int seq_run_begin(SeqRun &r, pmc_system *h, const pmc_move *pool, int npo
     r.c0.gend = h->step_ctr + (unsigned long long)r.nsteps;
     r.c0.trunc = INT_MAX;
     r.c0.gen_hi = r.c0.next;
+    PMC_TIME(r.c0.t_first = ~0ull;)
     *h->h_sq_ctl = r.c0;
     HIPCHK(h, hipStreamSynchronize(h->stream));            // earlier work on the chain's own stream
     HIPCHK(h, hipMemcpyAsync(h->d_sq_ctl, h->h_sq_ctl, sizeof(SqCtl), hipMemcpyHostToDevice, stream));
@@ -341,7 +356,9 @@ static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *
     int ids_cap = 0;
     for (int k = 0; k < n; k++) ids_cap = std::max(ids_cap, g.runs[k].s.ids_cap);
     for (int k = 0; k < n; k++) g.runs[k].s.ids_cap = ids_cap;     // one LDS layout for the launch
-    g.lds = (size_t)((ids_cap + 3) & ~3) * sizeof(int) + 2 * (size_t)SQ_TERMS_BUF * sizeof(double);   // ids + the two term buffers
+    g.nw = SQ_EW;
+    if (const char *e = getenv("PMC_SEQ_EW")) g.nw = (atoi(e) == 1) ? 1 : SQ_EW;
+    g.lds = sq_eval_lds_bytes(ids_cap, g.nw);                        // ids + the term buffers
     if (g.lds > 160 * 1024 - 256) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine: neighbourhood rows exceed the LDS");
     {
         // the evaluation kernel of a group whose chains all have pair models of ONE kind has that potential compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
@@ -352,15 +369,25 @@ static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *
                 else if ((int)pm.kind != ukind) ukind = 4;
             }
         if (ukind < 0 || ukind > 3 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
-#define SQ_EVAL_PICK(DD) (ukind == 0 ? (const void *)k_sq_round_a<DD, 0> : ukind == 1 ? (const void *)k_sq_round_a<DD, 1> : \
-                          ukind == 2 ? (const void *)k_sq_round_a<DD, 2> : ukind == 3 ? (const void *)k_sq_round_a<DD, 3> : (const void *)k_sq_round_a<DD, 4>)
-        g.k_eval = (m->D == 3) ? SQ_EVAL_PICK(3) : SQ_EVAL_PICK(2);
-#undef SQ_EVAL_PICK
+#define SQ_PICK5(KER, DD, WW) (ukind == 0 ? (const void *)KER<DD, 0, WW> : ukind == 1 ? (const void *)KER<DD, 1, WW> : \
+                               ukind == 2 ? (const void *)KER<DD, 2, WW> : ukind == 3 ? (const void *)KER<DD, 3, WW> : (const void *)KER<DD, 4, WW>)
+        if (g.nw == 1) {
+            g.k_eval = (m->D == 3) ? SQ_PICK5(k_sq_round_a, 3, 1) : SQ_PICK5(k_sq_round_a, 2, 1);
+            g.k_fused = (m->D == 3) ? SQ_PICK5(k_sq_round_fused, 3, 1) : SQ_PICK5(k_sq_round_fused, 2, 1);
+        } else {
+            g.k_eval = (m->D == 3) ? SQ_PICK5(k_sq_round_a, 3, SQ_EW) : SQ_PICK5(k_sq_round_a, 2, SQ_EW);
+            g.k_fused = (m->D == 3) ? SQ_PICK5(k_sq_round_fused, 3, SQ_EW) : SQ_PICK5(k_sq_round_fused, 2, SQ_EW);
+        }
+#undef SQ_PICK5
     }
+    // PMC_SEQ_NOFUSE=1: four launches per round whatever the window (the A/B partner; what windows beyond SQ_FUSED_KMAX run)
+    g.fused = g.K <= SQ_FUSED_KMAX && !getenv("PMC_SEQ_NOFUSE");
     if (g.lds > 48 * 1024) {
         HIPCHK(m, hipFuncSetAttribute(g.k_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
     }
     g.lds_fill = (size_t)8 * g.K * sizeof(int);            // keys[4 K] + vals[4 K]
+    if (g.fused && std::max(g.lds, g.lds_fill) > 48 * 1024)
+        HIPCHK(m, hipFuncSetAttribute(g.k_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(g.lds, g.lds_fill)));
     if (g.lds_fill > 48 * 1024) {
         if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_fill<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
         else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_fill<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
@@ -421,6 +448,16 @@ static int seq_group_enqueue(SeqGroup &g, bool pipelined = false)
     for (SeqRun &r : g.runs)                                 // ... and no chain's ring may overflow in the batch
         if (!r.done && !r.failed) rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)(r.ring / (ring_div * K))));
     g.rounds_last = rounds;
+    if (g.fused && !g.primed) {                               // the first window of the call: admitted and prepared by the launches' own kernels
+        g.primed = true;
+        if (m->D == 3) {
+            hipLaunchKernelGGL(k_sq_fill<3>, dim3(1, g.n), dim3(SQ_FILL_THREADS), g.lds_fill, m->stream, g.d_tab);
+            hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256, g.n), dim3(256), 0, m->stream, g.d_tab);
+        } else {
+            hipLaunchKernelGGL(k_sq_fill<2>, dim3(1, g.n), dim3(SQ_FILL_THREADS), g.lds_fill, m->stream, g.d_tab);
+            hipLaunchKernelGGL(k_sq_prep<2>, dim3((2 * K + 255) / 256, g.n), dim3(256), 0, m->stream, g.d_tab);
+        }
+    }
     long long q = 0;
     if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH")) {
         if (int rg = seq_graph(g)) return rg;
@@ -519,6 +556,21 @@ static int seq_group_end(SeqGroup &g, pmc_stats *out)
         h->img_valid = false;
         if (r.failed) continue;
         r.c.prefix = r.prefix;
+        PMC_TIME({
+            unsigned long long t[16];
+            if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_sqt), sizeof t) == hipSuccess && t[9]) {
+                const double ne = (double)t[9];
+                fprintf(stderr, "evaluation of slot 0, %.0f evaluations; ticks each: ctl+slot %.0f to-sequence %.0f counts+rows %.0f ids->LDS %.0f chains %.0f gather %.0f terms %.0f sums %.0f decide %.0f\n",
+                        ne, t[0] / ne, t[1] / ne, t[2] / ne, t[3] / ne, t[4] / ne, t[5] / ne, t[6] / ne, t[7] / ne, t[8] / ne);
+                memset(t, 0, sizeof t);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sqt), t, sizeof t);
+            }
+        })
+        PMC_TIME(if (r.c.tacc[6]) {
+            const double nl = (double)r.c.tacc[6];
+            fprintf(stderr, "fused rounds: %.0f launches; ticks per launch: spread %.0f eval %.0f commit %.0f fill %.0f prep %.0f gap %.0f\n", nl,
+                    r.c.tacc[0] / nl, r.c.tacc[1] / nl, r.c.tacc[2] / nl, r.c.tacc[3] / nl, r.c.tacc[4] / nl, r.c.tacc[5] / nl);
+        })
         h->sq_last = r.c;
         h->sq_last_steps = (r.c.gend == r.c.next) ? (long long)r.nsteps - (long long)(r.c.gend - r.prefix) : 0;   // steps of THIS call folded
         h->energy = r.energy;
