@@ -129,6 +129,7 @@ struct SqArgs {
     int reverse;                  // 1: LinkedList (chain = row read backwards), 0: CellList (vector order)
     int ids_cap;                  // ints of dynamic LDS of the evaluation (>= 3^d * cl_cap)
     int arith_nbr;                // every dimension has >= 3 cells: the neighbour cells of a cell follow from its coordinates
+    int pk_ok;                    // ... and fewer than 65536: the slots carry their cells' coordinates (SqSlot::pk)
     int dbg;                      // PMC_SEQ_DBG (timing experiments only): 1 no energy fold inside the rounds, 2 no pair matrix, 4 no evaluation
 };
 
@@ -239,11 +240,12 @@ __device__ __forceinline__ int sq_cell_of(const RefArgs &a, const double *x)
 // boxes away, sq_cell_of decides.  (The three divisions and three 64-bit floor divisions of sq_cell_of were ~2 500 cycles of
 // every evaluation and ~5 000 of every admitted step's preparation.)
 template <int D>
-__device__ __forceinline__ int sq_cell_of_fast(const SqArgs &s, const double *x)
+__device__ __forceinline__ int sq_cell_of_fast(const SqArgs &s, const double *x, int *coords = nullptr)
 {
     const RefArgs &a = s.a;
     int c = 0, stride = 1;
     bool slow = false;
+    int fcoord[3] = {0, 0, 0};
 #pragma unroll
     for (int q = D - 1; q >= 0; q--) {
         const double qv = x[q] * s.invcell[q];
@@ -256,10 +258,31 @@ __device__ __forceinline__ int sq_cell_of_fast(const SqArgs &s, const double *x)
         if (mc < 0) mc += n;                       // the image next to the box; anything farther takes the general path
         else if (mc >= n) mc -= n;
         slow = slow || mc < 0 || mc >= n;
+        fcoord[q] = mc;
         c += mc * stride;
         stride *= n;
     }
-    return slow ? sq_cell_of<D>(a, x) : c;
+    if (slow) {
+        c = sq_cell_of<D>(a, x);
+        int r = c;
+#pragma unroll
+        for (int q = D - 1; q >= 0; q--) { fcoord[q] = r % a.nc[q]; r /= a.nc[q]; }
+    }
+    if (coords) { coords[0] = fcoord[0]; coords[1] = fcoord[1]; coords[2] = fcoord[2]; }
+    return c;
+}
+
+// inclusive prefix sum over lanes 0 .. 31 (DPP shifts inside the rows of 16, the first row's total added to the second)
+__device__ __forceinline__ int sq_scan32(int v)
+{
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    const int first = __builtin_amdgcn_readlane(x, 15);
+    const int lane = wave_lane();
+    return x + ((lane >= 16 && lane < 32) ? first : 0);
 }
 
 // a barrier among the lanes of ONE wavefront: what they stored has landed before any of them goes on
@@ -361,7 +384,8 @@ __device__ __forceinline__ double *sq_terms_buffer(const SqArgs &s, int *lds_ids
 // NW wavefronts (k_sq_round_a / k_sq_round_fused with SQ_EW): each of them works out the cells and offsets, the rows are dealt
 // round-robin, the last wavefront walks the chains of pending steps.
 template <int D, int NW = 1>
-__device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids, int w = -1, const double *pa = nullptr, const double *pb = nullptr)
+__device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids, int w = -1, const double *pa = nullptr, const double *pb = nullptr,
+                                           const int *fc = nullptr)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
     constexpr int PER = (NN + NW - 1) / NW;
@@ -376,8 +400,12 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
     if (s.arith_nbr) {
         cnt = NN;
         int f[3] = {0, 0, 0}, r = c;
+        if (fc) {                                  // (the preparation left the cell's coordinates in the slot: no divisions here)
+            f[0] = fc[0]; f[1] = fc[1]; f[2] = fc[2];
+        } else {
 #pragma unroll
-        for (int q = D - 1; q >= 0; q--) { f[q] = r % a.nc[q]; r /= a.nc[q]; }       // last dimension fastest (:79-88)
+            for (int q = D - 1; q >= 0; q--) { f[q] = r % a.nc[q]; r /= a.nc[q]; }   // last dimension fastest (:79-88)
+        }
         int o = lane < NN ? lane : 0, lin = 0;
 #pragma unroll
         for (int q = 0; q < D; q++) {
@@ -405,15 +433,10 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
         v[k] = a.cl_items[(size_t)cc_l * cl_cap + lane_in_row];
     }
     SQE(2);                                       // populations, chain heads, rows
-    int incl = len;
-#pragma unroll
-    for (int sft = 1; sft < 32; sft <<= 1) {
-        const int t = __shfl_up(incl, sft, PMC_WAVE);
-        if (lane >= sft) incl += t;
-    }
+    const int incl = sq_scan32(len);
     const int off = incl - len;
-    const int total = __shfl(incl, 31, PMC_WAVE);
-    const int maxlen = __reduce_max_sync_compat(len);
+    const int total = __builtin_amdgcn_readlane(incl, 31);
+    const bool longrows = __any(len > PMC_WAVE);
     __syncthreads();                              // the previous pass has read its ids
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -424,7 +447,7 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
             if (lane < len_l) lds_ids[off_l + (reverse ? len_l - 1 - lane : lane)] = v[k];
         }
     }
-    if (maxlen > PMC_WAVE) {                      // rows longer than a wavefront (dense cells, long cutoffs)
+    if (longrows) {                               // rows longer than a wavefront (dense cells, long cutoffs)
         for (int l = wv; l < cnt; l += NW) {
             const int len_l = __shfl(len, l, PMC_WAVE), cc_l = __shfl(cc, l, PMC_WAVE), off_l = __shfl(off, l, PMC_WAVE);
             for (int k = PMC_WAVE + lane; k < len_l; k += PMC_WAVE)
@@ -432,6 +455,8 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
         }
     }
     SQE(3);                                       // ids in LDS
+    __syncthreads();
+    // (the walk runs on the last wavefront while the others start on their trips; it has the fewest trips)
     if (w >= 0 && walker) {
         // two steps interact iff some cell of one is within one cell of some cell of the other: every pending step is entered
         // under its cell(s) (k_sq_prep); bit t of row w for every EARLIER step t in the chains of this cell's neighbour cells
@@ -469,9 +494,11 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
                 e = nxt;
             }
         }
-        if (__any(any) && lane == 0) atomicOr(&s.cp[w >> 6], 1ull << (w & 63));   // P: the step has an earlier potential conflict
+        if (__any(any) && lane == 0) {                       // P: the step has an earlier potential conflict
+            atomicOr(&s.cp[w >> 6], 1ull << (w & 63));
+            atomicOr(&s.cp[SQ_KW + (w >> 6)], 1ull << (w & 63));       // (P alone: a step without it has an empty row -- sq_commit_lanes)
+        }
     }
-    __syncthreads();
     SQE(4);                                       // chains of pending steps walked
     return total;
 }
@@ -616,36 +643,33 @@ __device__ __forceinline__ int sq_terms_push_seg(double *seg, double u)
     return n;
 }
 
-// acc += every term of the first nt segments, in order; one wavefront, every lane the same chain
+// acc += every term of the first nt segments, in order; one wavefront, every lane the same chain.  A segment's first block of
+// eight is always added (its terms, then zeros -- an empty segment is eight zeros), the next segment's first block being on its
+// way from LDS meanwhile; the rare segment with more than eight terms takes its further blocks one by one.
 __device__ __forceinline__ double sq_terms_chain(const double *buf, const int *tcount, int nt, double acc)
 {
     const int lane = wave_lane();
     const int cntv = (lane < nt) ? tcount[lane] : 0;            // lane l: terms of segment l
-    int tr = 0;
-    while (tr < nt && __builtin_amdgcn_readlane(cntv, tr) == 0) tr++;
-    if (tr >= nt) return acc;
-    int k = 0;
     double cur[SQ_TERMS_PAD];
 #pragma unroll
-    for (int q = 0; q < SQ_TERMS_PAD; q++) cur[q] = buf[tr * SQ_SEG + q];
-    for (;;) {
-        int ntr = tr, nk = k + SQ_TERMS_PAD;
-        if (nk >= __builtin_amdgcn_readlane(cntv, tr)) {
-            nk = 0;
-            ntr = tr + 1;
-            while (ntr < nt && __builtin_amdgcn_readlane(cntv, ntr) == 0) ntr++;
-        }
-        const bool more = ntr < nt;
+    for (int q = 0; q < SQ_TERMS_PAD; q++) cur[q] = buf[q];
+    for (int sg = 0; sg < nt; sg++) {
+        const int n = __builtin_amdgcn_readlane(cntv, sg);
+        const double *p = buf + sg * SQ_SEG;
         double nxt[SQ_TERMS_PAD];
 #pragma unroll
-        for (int q = 0; q < SQ_TERMS_PAD; q++) nxt[q] = more ? buf[ntr * SQ_SEG + nk + q] : 0.0;
+        for (int q = 0; q < SQ_TERMS_PAD; q++) nxt[q] = p[SQ_SEG + q];       // (behind the last segment: other LDS of the evaluation, not used)
 #pragma unroll
         for (int q = 0; q < SQ_TERMS_PAD; q++) acc += cur[q];
-        if (!more) break;
+        for (int k = SQ_TERMS_PAD; k < n; k += SQ_TERMS_PAD) {
+            double t[SQ_TERMS_PAD];
+#pragma unroll
+            for (int q = 0; q < SQ_TERMS_PAD; q++) t[q] = p[k + q];
+#pragma unroll
+            for (int q = 0; q < SQ_TERMS_PAD; q++) acc += t[q];
+        }
 #pragma unroll
         for (int q = 0; q < SQ_TERMS_PAD; q++) cur[q] = nxt[q];
-        tr = ntr;
-        k = nk;
     }
     return acc;
 }
@@ -722,7 +746,7 @@ __device__ __forceinline__ void sq_mw_trips(const SqArgs &s, const int *ids, int
 // other they made a crossing step 1.7 times as long as any other, and nearly every round has one)
 template <int D, int MODE, int KIND, int NW>
 __device__ __forceinline__ void sq_pass_mw(const SqArgs &s, int c, int cb, int i, int spa, int spb, int other, const double *xa, const double *xb,
-                                           int *lds_ids, double &ea, double &eb, int w)
+                                           int *lds_ids, double &ea, double &eb, int w, const int *fc = nullptr, const int *fcb = nullptr)
 {
     static_assert(NW > 1 && SQ_TRMAX % NW == 0, "the trips of one go are dealt evenly");
     const RefArgs &a = s.a;
@@ -731,8 +755,8 @@ __device__ __forceinline__ void sq_pass_mw(const SqArgs &s, int c, int cb, int i
     const int idsz = (s.ids_cap + 3) & ~3;
     int *idsb = lds_ids + idsz;
     const bool fine = MODE == 1 && s.conf_r2 > 0.0;
-    const int total = sq_sequence<D, NW>(s, c, lds_ids, w, fine ? xa : nullptr, fine ? xb : nullptr);
-    const int totalb = (MODE == 3) ? sq_sequence<D, NW>(s, cb, idsb, w) : 0;
+    const int total = sq_sequence<D, NW>(s, c, lds_ids, w, fine ? xa : nullptr, fine ? xb : nullptr, fc);
+    const int totalb = (MODE == 3) ? sq_sequence<D, NW>(s, cb, idsb, w, nullptr, nullptr, fcb) : 0;
     double *bufa = reinterpret_cast<double *>(lds_ids + 2 * idsz), *bufb = bufa + SQ_TRMAX * SQ_SEG, *esum = bufb + SQ_TRMAX * SQ_SEG;
     int *tcount = reinterpret_cast<int *>(esum + 2);
     double L[3] = {1, 1, 1}, iL[3] = {1, 1, 1};
@@ -749,8 +773,10 @@ __device__ __forceinline__ void sq_pass_mw(const SqArgs &s, int c, int cb, int i
             sq_mw_trips<D, MODE, KIND, NW>(s, lds_ids, total, tr0, ntrip, wv, i, spa, spb, other, xa, xb, L, iL, bufa, bufb, tcount, tcount + SQ_TRMAX, w);
         }
         __syncthreads();
+        SQE(10);                                  // every wavefront's trips
         if (wv == 0) acc = sq_terms_chain(bufa, tcount, max(0, min(SQ_TRMAX, ntrip - tr0)), acc);
         else if (MODE != 0 && wv == 1) acc = sq_terms_chain(bufb, tcount + SQ_TRMAX, max(0, min(SQ_TRMAX, (MODE == 3 ? ntripb : ntrip) - tr0)), acc);
+        SQE(11);                                  // this wavefront's chain of additions
         if (tr0 + SQ_TRMAX < ngo) __syncthreads();                               // (the segments are free for the next go)
     }
     if (lane == 0 && wv == 0) esum[0] = acc;
@@ -763,13 +789,13 @@ __device__ __forceinline__ void sq_pass_mw(const SqArgs &s, int c, int cb, int i
 
 template <int D, int MODE, int KIND, int NW>
 __device__ __forceinline__ void sq_energy(const SqArgs &s, int c, int i, int spa, int spb, int other, const double *xa, const double *xb,
-                                          int *lds_ids, double &ea, double &eb, int w)
+                                          int *lds_ids, double &ea, double &eb, int w, const int *fc = nullptr)
 {
     if constexpr (NW == 1) {
         if constexpr (MODE == 2) sq_pass_swap<D, KIND>(s, c, i, spa, spb, other, xa, lds_ids, ea, eb, w);
         else sq_pass<D, MODE == 1, KIND>(s, c, i, spa, xa, xb, lds_ids, ea, eb, w);
     } else {
-        sq_pass_mw<D, MODE, KIND, NW>(s, c, c, i, spa, spb, other, xa, xb, lds_ids, ea, eb, w);
+        sq_pass_mw<D, MODE, KIND, NW>(s, c, c, i, spa, spb, other, xa, xb, lds_ids, ea, eb, w, fc, nullptr);
     }
 }
 
@@ -778,43 +804,91 @@ __device__ __forceinline__ bool sq_bits_differ(double p, double q)
     return __double_as_longlong(p) != __double_as_longlong(q);
 }
 
+// what an evaluation reads of its slot
+struct SqHead {
+    int flags, i, j, c0, c1, pk[3];
+    double x[3], xn[3], d[3], lnu;
+};
+
+template <int D>
+__device__ __forceinline__ void sq_slot_head(const SqSlot *p, SqHead &h)
+{
+    const SqSlot *v = p;
+    h.flags = v->flags; h.i = v->i; h.j = v->j; h.c0 = v->c0; h.c1 = v->c1;
+    h.pk[0] = v->pk[0]; h.pk[1] = v->pk[1]; h.pk[2] = v->pk[2];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        h.x[q] = (q < D) ? v->x[q] : 0.0;
+        h.xn[q] = (q < D) ? v->xn[q] : 0.0;
+        h.d[q] = (q < D) ? v->d[q] : 0.0;
+    }
+    h.lnu = v->lnu;
+}
+
+// the coordinates of the two cells of a step (SqSlot::pk, written by sq_prep_thread)
+__device__ __forceinline__ void sq_unpack_cells(const int *pk, int *f0, int *f1)
+{
+    f0[0] = pk[0] & 0xffff; f0[1] = (pk[0] >> 16) & 0xffff; f0[2] = pk[1] & 0xffff;
+    f1[0] = (pk[1] >> 16) & 0xffff; f1[1] = pk[2] & 0xffff; f1[2] = (pk[2] >> 16) & 0xffff;
+}
+
 // ---- one step, evaluated against the current state (nothing is written but the slot) --------------------------------------
 template <int D, int KIND = 4, int NW = 1>
 __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 {
     const RefArgs &a = s.a;
     PMC_TIME(if (w == 0 && threadIdx.x == 0) g_sqt[15] = __builtin_amdgcn_s_memtime();)
-    SqSlot &sl = s.slots[s.ctl->cur][w];
-    const int lane = wave_lane();
-    int flags = sl.flags & (SQF_SWAP | SQF_NULL);
-    SQE(0);                                       // control block + first slot word
+    // Everything the step needs from its slot is requested at once, ahead of the branches that would otherwise split it into two
+    // round trips.  (Requesting BOTH window buffers' slots before the control block says which is current, with volatile loads
+    // so that they stay ahead of the branch, was measured: system-scope loads, 10 % slower rounds.)
+    SqCtl *ctl = s.ctl;
+    SqSlot *const buf0 = s.slots[0], *const buf1 = s.slots[1];
+    int nslots = ctl->nslots, cur = ctl->cur;
+    asm volatile("" : "+v"(nslots), "+v"(cur));         // (both words of the control block in one round trip)
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (w >= nslots) return;
+    SqSlot &sl = (cur ? buf1 : buf0)[w];
+    SqHead hd;
+    sq_slot_head<D>(&sl, hd);
+    asm volatile("" : "+v"(hd.flags), "+v"(hd.i), "+v"(hd.j), "+v"(hd.c0), "+v"(hd.c1), "+v"(hd.pk[0]), "+v"(hd.pk[1]), "+v"(hd.pk[2]),
+                      "+v"(hd.x[0]), "+v"(hd.x[1]), "+v"(hd.x[2]), "+v"(hd.xn[0]), "+v"(hd.xn[1]), "+v"(hd.xn[2]),
+                      "+v"(hd.d[0]), "+v"(hd.d[1]), "+v"(hd.d[2]), "+v"(hd.lnu));      // (the whole slot in one round trip)
+    int flags = hd.flags & (SQF_SWAP | SQF_NULL);
+    SQE(0);                                       // control block + slot
     if (flags & SQF_NULL) return;
+    const double lnu = hd.lnu;
+    int fc0s[3], fc1s[3];
+    sq_unpack_cells(hd.pk, fc0s, fc1s);
+    const int *fc0 = s.pk_ok ? fc0s : nullptr, *fc1 = s.pk_ok ? fc1s : nullptr;
     double e1, e2;
     if (!(flags & SQF_SWAP)) {
-        const int i = sl.i;
+        const int i = hd.i;
         double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0}, xr[3] = {0, 0, 0};
 #pragma unroll
         for (int q = 0; q < D; q++) {
-            x[q] = sl.x[q];
-            xn[q] = sl.xn[q];                          // x + d, update_position! (src/moves.jl:46-48)
-            xr[q] = xn[q] + (-sl.d[q]);                // ... and the reverted position (src/moves.jl:76-90)
+            x[q] = hd.x[q];
+            xn[q] = hd.xn[q];                          // x + d, update_position! (src/moves.jl:46-48)
+            xr[q] = xn[q] + (-hd.d[q]);                // ... and the reverted position (src/moves.jl:76-90)
         }
-        const int c0 = sl.c0, c1 = sl.c1;
-        const int c2 = sq_cell_of_fast<D>(s, xr);
+        const int c0 = hd.c0, c1 = hd.c1;
+        bool same = true;                               // (the reverted position differs from x by an ulp at most: its cell is c0 unless ...)
+#pragma unroll
+        for (int q = 0; q < D; q++) same = same && !sq_bits_differ(xr[q], x[q]);
+        const int c2 = same ? c0 : sq_cell_of_fast<D>(s, xr);
         const int spi = a.S > 1 ? a.species[i] : 0;
         if (c1 == c0) {
-            sq_energy<D, 1, KIND, NW>(s, c0, i, spi, spi, -1, x, xn, lds_ids, e1, e2, w);
+            sq_energy<D, 1, KIND, NW>(s, c0, i, spi, spi, -1, x, xn, lds_ids, e1, e2, w, fc0);
         } else {
             if constexpr (NW == 1) {
                 double dummy;
                 sq_energy<D, 0, KIND, NW>(s, c0, i, spi, spi, -1, x, x, lds_ids, e1, dummy, w);
                 sq_energy<D, 0, KIND, NW>(s, c1, i, spi, spi, -1, xn, xn, lds_ids, e2, dummy, w);
             } else {
-                sq_pass_mw<D, 3, KIND, NW>(s, c0, c1, i, spi, spi, -1, x, xn, lds_ids, e1, e2, w);
+                sq_pass_mw<D, 3, KIND, NW>(s, c0, c1, i, spi, spi, -1, x, xn, lds_ids, e1, e2, w, fc0, fc1);
             }
             flags |= SQF_CROSSED;
         }
-        const bool ok = sl.lnu < -(e2 - e1) / a.temperature;    // src/utils.jl:8-10 (forward / backward log q cancel)
+        const bool ok = lnu < -(e2 - e1) / a.temperature;       // src/utils.jl:8-10 (forward / backward log q cancel)
         bool rejchg = false;
 #pragma unroll
         for (int q = 0; q < D; q++) rejchg |= sq_bits_differ(xr[q], x[q]);
@@ -827,17 +901,17 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
             st_agent(&sl.c2, c2);
         }
     } else {
-        const int i = sl.i, j = sl.j;
+        const int i = hd.i, j = hd.j;
         double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < D; q++) { xi[q] = sl.x[q]; xj[q] = sl.xn[q]; }
+        for (int q = 0; q < D; q++) { xi[q] = hd.x[q]; xj[q] = hd.xn[q]; }
         const int spi = a.species[i], spj = a.species[j];
         double e1i, e2i, e1j, e2j;
-        sq_energy<D, 2, KIND, NW>(s, sl.c0, i, spi, spj, j, xi, xi, lds_ids, e1i, e2i, w);
-        sq_energy<D, 2, KIND, NW>(s, sl.c1, j, spj, spi, i, xj, xj, lds_ids, e1j, e2j, w);
+        sq_energy<D, 2, KIND, NW>(s, hd.c0, i, spi, spj, j, xi, xi, lds_ids, e1i, e2i, w, fc0);
+        sq_energy<D, 2, KIND, NW>(s, hd.c1, j, spj, spi, i, xj, xj, lds_ids, e1j, e2j, w, fc1);
         e1 = e1i + e1j;                                 // src/moves.jl:166
         e2 = e2i + e2j;
-        const bool ok = sl.lnu < -(e2 - e1) / a.temperature;
+        const bool ok = lnu < -(e2 - e1) / a.temperature;
         if (ok) flags |= SQF_ACCEPT | SQF_CHANGED;      // a reverted swap restores species and SpeciesList exactly
         if (threadIdx.x == 0) { st_agent(&sl.spi, spi); st_agent(&sl.spj, spj); }
     }
@@ -865,10 +939,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_round_a(const SqArgs *__restrict
 {
     const SqArgs &s = tab[blockIdx.y];
     extern __shared__ int sq_lds[];
-    const int b = blockIdx.x;
-    if (b < s.ctl->nslots) {
-        if (!(s.dbg & 4)) sq_eval<D, KIND, NW>(s, b, sq_lds);
-    }
+    if (!(s.dbg & 4)) sq_eval<D, KIND, NW>(s, (int)blockIdx.x, sq_lds);      // (returns at once for a slot beyond the window's steps)
 }
 
 // ---- round, fourth launch: decide and apply ------------------------------------------------------------------------------------
@@ -1150,7 +1221,7 @@ __device__ __forceinline__ void sq_fill_block(const SqArgs &s, int *sq_table, in
         const int q = r * NT + tid;
         if (q < nadm) { s.cand[3 * q] = ci[r]; s.cand[3 * q + 1] = cj[r]; s.cand[3 * q + 2] = cf[r]; }
     }
-    if (tid < SQ_KW) s.cp[tid] = 0;
+    for (int k = tid; k < 2 * SQ_KW; k += NT) s.cp[k] = 0;
     if (tid == 0) {
         ctl->cur = cur ^ 1;                       // (k_sq_prep fills it from slots[cur])
         ctl->f_nold = nold;
@@ -1224,9 +1295,13 @@ __device__ __forceinline__ void sq_prep_thread(const SqArgs &s, const int t)
         sl.xr[k] = 0.0;
     }
     if (i >= 0) {                                       // (a null step has no cells and interacts with nothing)
-        sl.c0 = sq_cell_of_fast<D>(s, sl.x);
-        sl.c1 = sq_cell_of_fast<D>(s, sl.xn);
+        int f0[3], f1[3];
+        sl.c0 = sq_cell_of_fast<D>(s, sl.x, f0);
+        sl.c1 = sq_cell_of_fast<D>(s, sl.xn, f1);
         sl.c2 = sl.c0;
+        sl.pk[0] = f0[0] | (f0[1] << 16);
+        sl.pk[1] = f0[2] | (f1[0] << 16);
+        sl.pk[2] = f1[1] | (f1[2] << 16);
         sl.pk[3] = 1;
         const int to = nkeep + q;
         s.cellnext[2 * to] = atomicExch(&s.cellhead[sl.c0], 2 * to);
@@ -1253,8 +1328,9 @@ __global__ __launch_bounds__(256) void k_sq_prep(const SqArgs *__restrict__ tab)
 // persistent launch were measured first: 7-9 us per barrier, slower than the launches -- LAB.md.)  Same chain, bit for bit.
 #define SQ_FUSED_KMAX 256
 
-template <int D, int NW>
-__device__ __forceinline__ void sq_commit_lanes(const SqArgs &s)
+// (AG: the evaluation ran in this launch -- k_sq_round_fused; otherwise in the launch before -- k_sq_tail)
+template <int D, int NW, bool AG>
+__device__ __forceinline__ void sq_commit_lanes(const SqArgs &s, unsigned long long *cp_lds)
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
@@ -1262,10 +1338,12 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s)
     SqCtl *ctl = s.ctl;
     const int nslots = ctl->nslots;
     SqSlot *slots = s.slots[ctl->cur];
-    const int trunc = ld_agent(&ctl->trunc), excl = ld_agent(&ctl->exclusive);
-    unsigned long long cpw[SQ_FUSED_KMAX / 64];
-#pragma unroll
-    for (int k = 0; k < SQ_FUSED_KMAX / 64; k++) cpw[k] = ld_agent(&s.cp[k]);
+    const int trunc = AG ? ld_agent(&ctl->trunc) : ctl->trunc, excl = AG ? ld_agent(&ctl->exclusive) : ctl->exclusive;
+    for (int k = threadIdx.x; k < (nslots + 63) / 64; k += NW * PMC_WAVE) {
+        cp_lds[k] = AG ? ld_agent(&s.cp[k]) : s.cp[k];
+        cp_lds[SQ_KW + k] = AG ? ld_agent(&s.cp[SQ_KW + k]) : s.cp[SQ_KW + k];
+    }
+    __syncthreads();
     for (int base = wv * PMC_WAVE; base < nslots; base += NW * PMC_WAVE) {
         const int w = base + lane;
         const bool valid = w < nslots;
@@ -1275,12 +1353,22 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s)
             st_agent(&s.cellhead[c0], -1);
             st_agent(&s.cellhead[c1], -1);
         }
-        unsigned long long hit = 0;                         // the hold rule of sq_commit_wave
+        // the hold rule of sq_commit_wave; a step without the P bit has an empty row
+        unsigned long long hit = 0;
+        const int nwords = (base >> 6) + 1;                 // (the same for every lane of the wavefront)
+        const bool has_row = valid && ((cp_lds[SQ_KW + (base >> 6)] >> lane) & 1ull) != 0;
+        if (__any(has_row)) {
+            const unsigned long long *row = s.M + (size_t)(valid ? w : 0) * SQ_KW;
+            for (int k0 = 0; k0 < nwords; k0 += 8) {
+                unsigned long long m[8];
 #pragma unroll
-        for (int k = 0; k < SQ_FUSED_KMAX / 64; k++)
-            if (valid && k <= (w >> 6)) hit |= ld_agent(&s.M[(size_t)w * SQ_KW + k]) & cpw[k];
+                for (int q = 0; q < 8; q++) m[q] = (has_row && k0 + q < nwords) ? (AG ? ld_agent(&row[k0 + q]) : row[k0 + q]) : 0ull;
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (k0 + q < nwords) hit |= m[q] & cp_lds[k0 + q];
+            }
+        }
         const bool hold = !valid || hit != 0 || w >= trunc || (excl && w != 0);
-        const int flags = valid ? ld_agent(&sl.flags) : 0;
+        const int flags = valid ? (AG ? ld_agent(&sl.flags) : sl.flags) : 0;
         int c2 = c0;
         bool rows = false;
         if (!hold && !(flags & SQF_NULL)) {
@@ -1290,9 +1378,9 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s)
                     for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = sl.xn[q];
                     rows = c1 != c0;
                 } else if (flags & SQF_CHANGED) {
-                    c2 = ld_agent(&sl.c2);
+                    c2 = AG ? ld_agent(&sl.c2) : sl.c2;
 #pragma unroll
-                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = ld_agent(&sl.xr[q]);
+                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = AG ? ld_agent(&sl.xr[q]) : sl.xr[q];
                     rows = (c1 != c0) || (c2 != c1);
                 }
             } else if (flags & SQF_ACCEPT) {
@@ -1318,7 +1406,7 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s)
                 }
             } else if (lane == 0) {
                 SqSlot &sq = slots[base + l];
-                const int j = sq.j, spi = ld_agent(&sq.spi), spj = ld_agent(&sq.spj);
+                const int j = sq.j, spi = AG ? ld_agent(&sq.spi) : sq.spi, spj = AG ? ld_agent(&sq.spj) : sq.spj;
                 a.species[ii] = spj;                                // src/moves.jl:162-163
                 a.species[j] = spi;
                 ref_update_species_list(a, s.pool.sp0[sq.m], s.pool.sp1[sq.m], ii, j);
@@ -1326,7 +1414,7 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s)
         }
         if (!hold) {
             SqLog &lg = s.log[sl.g & s.ring_mask];
-            lg.de = ld_agent(&sl.de);
+            lg.de = AG ? ld_agent(&sl.de) : sl.de;
             lg.tag = (uint32_t)sl.g;
             int f = SQL_DONE | (sl.m << 4);
             if (flags & SQF_ACCEPT) f |= SQL_ACCEPT;
@@ -1344,10 +1432,11 @@ __global__ __launch_bounds__(NW * 64) void k_sq_round_fused(const SqArgs *__rest
     const SqArgs &s = tab[blockIdx.y];
     extern __shared__ int sq_lds[];              // the evaluation's ids and term buffers; the last workgroup also: the admission's hash table
     __shared__ int fill_lds[NW + 4];
+    __shared__ unsigned long long cp_lds[2 * SQ_KW];
     SqCtl *ctl = s.ctl;
     const int b = blockIdx.x;
     PMC_TIME(const unsigned long long t_in = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicMin(&ctl->t_first, t_in);)
-    if (b < ctl->nslots && !(s.dbg & 4)) sq_eval<D, KIND, NW>(s, b, sq_lds);
+    if (!(s.dbg & 4)) sq_eval<D, KIND, NW>(s, b, sq_lds);             // (returns at once for a slot beyond the window's steps)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wavefront's stores and atomics have landed
     __syncthreads();                                                  // ... every wavefront's of the workgroup
     if (threadIdx.x == 0) {
@@ -1360,7 +1449,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_round_fused(const SqArgs *__rest
     if (!fill_lds[NW + 3]) return;
     asm volatile("" ::: "memory");
     PMC_TIME(const unsigned long long t1 = __builtin_amdgcn_s_memtime();)
-    sq_commit_lanes<D, NW>(s);
+    sq_commit_lanes<D, NW, true>(s, cp_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PMC_TIME(const unsigned long long t2 = __builtin_amdgcn_s_memtime();)
@@ -1382,6 +1471,30 @@ __global__ __launch_bounds__(NW * 64) void k_sq_round_fused(const SqArgs *__rest
                  ctl->t_end = t4;
                  ctl->t_first = ~0ull;
              })
+}
+
+// ---- commit, admission and preparation by ONE workgroup ---------------------------------------------------------------------------
+// With no pending step (the first launch of a call) this just admits and prepares the first window: the prologue of the fused
+// rounds.  As the second launch of every round of a LARGER window (PMC_SEQ_TWO=1: k_sq_round_a, then this, instead of
+// k_sq_commit + k_sq_fill + k_sq_prep) it was measured and lost: a lane per slot serialises what the launches spread over the
+// chip -- 38 against 32 us per round at K = 512, 107 against 47 at K = 2048 (LAB.md).
+#define SQ_TAIL_THREADS 1024
+
+template <int D>
+__global__ __launch_bounds__(SQ_TAIL_THREADS) void k_sq_tail(const SqArgs *__restrict__ tab)
+{
+    const SqArgs &s = tab[blockIdx.y];
+    extern __shared__ int sq_table[];            // keys[4 K], vals[4 K]
+    __shared__ int lds[SQ_TAIL_THREADS / 64 + 2];
+    __shared__ unsigned long long cp_lds[2 * SQ_KW];
+    static_assert(SQ_KMAX == 4 * SQ_TAIL_THREADS, "sq_fill_block admits for windows of up to four slots per thread");
+    sq_commit_lanes<D, SQ_TAIL_THREADS / 64, false>(s, cp_lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    sq_fill_block<D, SQ_TAIL_THREADS, false>(s, sq_table, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * s.K; t += SQ_TAIL_THREADS) sq_prep_thread<D>(s, t);
 }
 
 // The rows of a LinkedList whose chains already exist (moves have shaped their order: src/neighbours.jl:276-302): the row of

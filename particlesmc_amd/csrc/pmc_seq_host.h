@@ -207,7 +207,8 @@ struct SeqGroup {
     const void *k_fused = nullptr;    // k_sq_round_fused likewise
     int nw = SQ_EW;                   // wavefronts per evaluated step (PMC_SEQ_EW=1: one, the A/B partner)
     bool fused = false;               // windows of <= SQ_FUSED_KMAX: a round is one launch (evaluate; the last workgroup commits, admits, prepares)
-    bool primed = false;              // ... after the first window of the call has been admitted and prepared by k_sq_fill + k_sq_prep
+    bool two = false;                 // larger windows: two launches (k_sq_round_a, k_sq_tail)
+    bool primed = false;              // ... either after the first window of the call has been admitted and prepared (one k_sq_tail)
     long long rounds_last = 0, rounds_folded = 0;     // rounds of the batch enqueued last / of the batch being folded
     hipGraphExec_t graph = nullptr;   // SQ_GRAPH_ROUNDS rounds, captured once per call (a group of one caches it on the handle)
     bool own_graph = false;
@@ -230,6 +231,12 @@ static void seq_launch_round(const SeqGroup &g)
         (void)hipLaunchKernel(g.k_fused, dim3(K, n), dim3(64 * g.nw), kargs, std::max(g.lds, g.lds_fill), h->stream);
         return;
     }
+    if (g.two) {
+        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64 * g.nw), kargs, g.lds, h->stream);
+        if (h->D == 3) hipLaunchKernelGGL(k_sq_tail<3>, dim3(1, n), dim3(SQ_TAIL_THREADS), g.lds_fill, h->stream, g.d_tab);
+        else hipLaunchKernelGGL(k_sq_tail<2>, dim3(1, n), dim3(SQ_TAIL_THREADS), g.lds_fill, h->stream, g.d_tab);
+        return;
+    }
     if (h->D == 3) {
         hipLaunchKernelGGL(k_sq_fill<3>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
         hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
@@ -250,7 +257,7 @@ static int seq_graph(SeqGroup &g)
 {
     pmc_system *h = g.lead;
     if (g.graph) return PMC_OK;
-    const int graph_key = (g.fused ? -g.K : g.K) * 8 + g.nw;
+    const int graph_key = (g.fused ? -g.K : g.K) * 16 + g.nw + (g.two ? 8 : 0);
     if (g.n == 1 && h->sq_graph && h->sq_graph_K == graph_key && memcmp(&h->sq_graph_args, &g.runs[0].s, sizeof(SqArgs)) == 0) {
         g.graph = h->sq_graph;
         return PMC_OK;
@@ -315,7 +322,11 @@ static int seq_run_begin(SeqRun &r, pmc_system *h, const pmc_move *pool, int npo
     s.reverse = (h->list_type == 1) ? 1 : 0;
     s.ids_cap = h->nn * h->cl_cap;
     s.arith_nbr = 1;
-    for (int q = 0; q < h->D; q++) if (h->p.ncells[q] < 3) s.arith_nbr = 0;
+    s.pk_ok = 1;
+    for (int q = 0; q < h->D; q++) {
+        if (h->p.ncells[q] < 3) s.arith_nbr = 0;
+        if (h->p.ncells[q] > 65535) s.pk_ok = 0;
+    }
     if (getenv("PMC_SEQ_NBRTABLE")) s.arith_nbr = 0;
     if (const char *e = getenv("PMC_SEQ_DBG")) s.dbg = atoi(e);
     memset(&r.c0, 0, sizeof r.c0);
@@ -382,6 +393,7 @@ static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *
     }
     // PMC_SEQ_NOFUSE=1: four launches per round whatever the window (the A/B partner; what windows beyond SQ_FUSED_KMAX run)
     g.fused = g.K <= SQ_FUSED_KMAX && !getenv("PMC_SEQ_NOFUSE");
+    g.two = !g.fused && getenv("PMC_SEQ_TWO") != nullptr;     // (measured: the one-workgroup tail costs 80 us at K = 2048 where the three launches take 23 -- LAB.md)
     if (g.lds > 48 * 1024) {
         HIPCHK(m, hipFuncSetAttribute(g.k_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
     }
@@ -391,6 +403,8 @@ static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *
     if (g.lds_fill > 48 * 1024) {
         if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_fill<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
         else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_fill<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
+        if (m->D == 3) HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_tail<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
+        else HIPCHK(m, hipFuncSetAttribute((const void *)k_sq_tail<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_fill));
     }
     // the table of arguments: a group of one keeps it with the handle
     std::vector<SqArgs> tab((size_t)n);
@@ -448,15 +462,10 @@ static int seq_group_enqueue(SeqGroup &g, bool pipelined = false)
     for (SeqRun &r : g.runs)                                 // ... and no chain's ring may overflow in the batch
         if (!r.done && !r.failed) rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)(r.ring / (ring_div * K))));
     g.rounds_last = rounds;
-    if (g.fused && !g.primed) {                               // the first window of the call: admitted and prepared by the launches' own kernels
+    if ((g.fused || g.two) && !g.primed) {                    // the first window of the call: nothing to commit, admitted and prepared
         g.primed = true;
-        if (m->D == 3) {
-            hipLaunchKernelGGL(k_sq_fill<3>, dim3(1, g.n), dim3(SQ_FILL_THREADS), g.lds_fill, m->stream, g.d_tab);
-            hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256, g.n), dim3(256), 0, m->stream, g.d_tab);
-        } else {
-            hipLaunchKernelGGL(k_sq_fill<2>, dim3(1, g.n), dim3(SQ_FILL_THREADS), g.lds_fill, m->stream, g.d_tab);
-            hipLaunchKernelGGL(k_sq_prep<2>, dim3((2 * K + 255) / 256, g.n), dim3(256), 0, m->stream, g.d_tab);
-        }
+        if (m->D == 3) hipLaunchKernelGGL(k_sq_tail<3>, dim3(1, g.n), dim3(SQ_TAIL_THREADS), g.lds_fill, m->stream, g.d_tab);
+        else hipLaunchKernelGGL(k_sq_tail<2>, dim3(1, g.n), dim3(SQ_TAIL_THREADS), g.lds_fill, m->stream, g.d_tab);
     }
     long long q = 0;
     if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH")) {
@@ -560,8 +569,8 @@ static int seq_group_end(SeqGroup &g, pmc_stats *out)
             unsigned long long t[16];
             if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_sqt), sizeof t) == hipSuccess && t[9]) {
                 const double ne = (double)t[9];
-                fprintf(stderr, "evaluation of slot 0, %.0f evaluations; ticks each: ctl+slot %.0f to-sequence %.0f counts+rows %.0f ids->LDS %.0f chains %.0f gather %.0f terms %.0f sums %.0f decide %.0f\n",
-                        ne, t[0] / ne, t[1] / ne, t[2] / ne, t[3] / ne, t[4] / ne, t[5] / ne, t[6] / ne, t[7] / ne, t[8] / ne);
+                fprintf(stderr, "evaluation of slot 0, %.0f evaluations; ticks each: ctl+slot %.0f to-sequence %.0f counts+rows %.0f ids->LDS %.0f chains %.0f gather %.0f terms %.0f (wait for the others %.0f chain %.0f) sums' end %.0f decide %.0f\n",
+                        ne, t[0] / ne, t[1] / ne, t[2] / ne, t[3] / ne, t[4] / ne, t[5] / ne, t[6] / ne, t[10] / ne, t[11] / ne, t[7] / ne, t[8] / ne);
                 memset(t, 0, sizeof t);
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sqt), t, sizeof t);
             }
