@@ -1336,27 +1336,49 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s, unsigned long l
     const int lane = wave_lane();
     const int wv = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SqCtl *ctl = s.ctl;
-    const int nslots = ctl->nslots;
-    SqSlot *slots = s.slots[ctl->cur];
+    int nslots = ctl->nslots, cur = ctl->cur;
+    asm volatile("" : "+v"(nslots), "+v"(cur));
+    nslots = __builtin_amdgcn_readfirstlane(nslots);
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    SqSlot *slots = cur ? s.slots[1] : s.slots[0];
+    // a wavefront takes blocks of BL consecutive slots: 16 while that keeps every wavefront of the workgroup busy (the steps that
+    // edit rows are whole-wavefront operations, one after the other within a wavefront), else 64
+    const int BL = (nslots <= NW * 16) ? 16 : PMC_WAVE;
+    // -- everything the first block needs of its slots, in one round trip (and the cp words, trunc, exclusive with it)
+    struct Pre { int i, j, c0, c1, c2, pk3, flags, m; unsigned long long g; double xn[3], xr[3], de; } r;
+    auto fetch = [&](int w, bool valid, Pre &o) {
+        const SqSlot &sl = slots[valid ? w : 0];
+        o.i = sl.i; o.j = sl.j; o.c0 = sl.c0; o.c1 = sl.c1; o.pk3 = sl.pk[3]; o.m = sl.m; o.g = sl.g;
+        o.flags = AG ? ld_agent(&sl.flags) : sl.flags;
+        o.c2 = AG ? ld_agent(&sl.c2) : sl.c2;
+        o.de = AG ? ld_agent(&sl.de) : sl.de;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            o.xn[q] = (q < D) ? sl.xn[q] : 0.0;
+            o.xr[q] = (q < D) ? (AG ? ld_agent(&sl.xr[q]) : sl.xr[q]) : 0.0;
+        }
+    };
+    int base = wv * BL;
+    fetch(base + lane, lane < BL && base + lane < nslots, r);
     const int trunc = AG ? ld_agent(&ctl->trunc) : ctl->trunc, excl = AG ? ld_agent(&ctl->exclusive) : ctl->exclusive;
     for (int k = threadIdx.x; k < (nslots + 63) / 64; k += NW * PMC_WAVE) {
         cp_lds[k] = AG ? ld_agent(&s.cp[k]) : s.cp[k];
         cp_lds[SQ_KW + k] = AG ? ld_agent(&s.cp[SQ_KW + k]) : s.cp[SQ_KW + k];
     }
     __syncthreads();
-    for (int base = wv * PMC_WAVE; base < nslots; base += NW * PMC_WAVE) {
+    for (bool first = true; base < nslots; base += NW * BL, first = false) {
         const int w = base + lane;
-        const bool valid = w < nslots;
-        SqSlot &sl = slots[valid ? w : 0];
-        const int i = sl.i, c0 = sl.c0, c1 = sl.c1;
-        if (valid && sl.pk[3]) {                            // (atomics of the next preparation act on these words)
+        const bool valid = lane < BL && w < nslots;
+        if (!first) fetch(w, valid, r);
+        const int i = r.i, c0 = r.c0, c1 = r.c1, flags = valid ? r.flags : 0;
+        if (valid && r.pk3) {                               // (atomics of the next preparation act on these words)
             st_agent(&s.cellhead[c0], -1);
             st_agent(&s.cellhead[c1], -1);
         }
         // the hold rule of sq_commit_wave; a step without the P bit has an empty row
         unsigned long long hit = 0;
-        const int nwords = (base >> 6) + 1;                 // (the same for every lane of the wavefront)
-        const bool has_row = valid && ((cp_lds[SQ_KW + (base >> 6)] >> lane) & 1ull) != 0;
+        const int nwords = ((base + BL - 1) >> 6) + 1;      // (the same for every lane of the wavefront)
+        const bool has_row = valid && ((cp_lds[SQ_KW + (w >> 6)] >> (w & 63)) & 1ull) != 0;
         if (__any(has_row)) {
             const unsigned long long *row = s.M + (size_t)(valid ? w : 0) * SQ_KW;
             for (int k0 = 0; k0 < nwords; k0 += 8) {
@@ -1368,24 +1390,34 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s, unsigned long l
             }
         }
         const bool hold = !valid || hit != 0 || w >= trunc || (excl && w != 0);
-        const int flags = valid ? (AG ? ld_agent(&sl.flags) : sl.flags) : 0;
         int c2 = c0;
         bool rows = false;
         if (!hold && !(flags & SQF_NULL)) {
             if (!(flags & SQF_SWAP)) {
                 if (flags & SQF_ACCEPT) {
 #pragma unroll
-                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = sl.xn[q];
+                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = r.xn[q];
                     rows = c1 != c0;
                 } else if (flags & SQF_CHANGED) {
-                    c2 = AG ? ld_agent(&sl.c2) : sl.c2;
+                    c2 = r.c2;
 #pragma unroll
-                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = AG ? ld_agent(&sl.xr[q]) : sl.xr[q];
+                    for (int q = 0; q < D; q++) a.pos[(size_t)i * D + q] = r.xr[q];
                     rows = (c1 != c0) || (c2 != c1);
                 }
             } else if (flags & SQF_ACCEPT) {
                 rows = true;
             }
+        }
+        if (!hold) {                                        // (before the row operations: nothing below reads what they write)
+            SqLog &lg = s.log[r.g & s.ring_mask];
+            lg.de = r.de;
+            lg.tag = (uint32_t)r.g;
+            int f = SQL_DONE | (r.m << 4);
+            if (flags & SQF_ACCEPT) f |= SQL_ACCEPT;
+            if (flags & SQF_FINITE) f |= SQL_FINITE;
+            if (flags & SQF_NULL) f |= SQL_NULL;
+            lg.flag = f;
+            st_agent(&slots[w].flags, flags | SQF_COMMITTED);
         }
         // steps that edit cell rows or the SpeciesList: whole-wavefront operations, one step after the other (they touch
         // disjoint cells / species entries: the order among them is free, as it is among the workgroups of k_sq_commit)
@@ -1404,24 +1436,16 @@ __device__ __forceinline__ void sq_commit_lanes(const SqArgs &s, unsigned long l
                     if (d1 != d0) { sq_row_remove(s, d0, ii); sq_row_append(s, d1, ii); }
                     if (d2 != d1) { sq_row_remove(s, d1, ii); sq_row_append(s, d2, ii); }
                 }
-            } else if (lane == 0) {
-                SqSlot &sq = slots[base + l];
-                const int j = sq.j, spi = AG ? ld_agent(&sq.spi) : sq.spi, spj = AG ? ld_agent(&sq.spj) : sq.spj;
-                a.species[ii] = spj;                                // src/moves.jl:162-163
-                a.species[j] = spi;
-                ref_update_species_list(a, s.pool.sp0[sq.m], s.pool.sp1[sq.m], ii, j);
+            } else {
+                const int jj = __shfl(r.j, l, PMC_WAVE), mm = __shfl(r.m, l, PMC_WAVE);
+                if (lane == 0) {
+                    const SqSlot &sq = slots[base + l];
+                    const int spi = AG ? ld_agent(&sq.spi) : sq.spi, spj = AG ? ld_agent(&sq.spj) : sq.spj;
+                    a.species[ii] = spj;                            // src/moves.jl:162-163
+                    a.species[jj] = spi;
+                    ref_update_species_list(a, s.pool.sp0[mm], s.pool.sp1[mm], ii, jj);
+                }
             }
-        }
-        if (!hold) {
-            SqLog &lg = s.log[sl.g & s.ring_mask];
-            lg.de = AG ? ld_agent(&sl.de) : sl.de;
-            lg.tag = (uint32_t)sl.g;
-            int f = SQL_DONE | (sl.m << 4);
-            if (flags & SQF_ACCEPT) f |= SQL_ACCEPT;
-            if (flags & SQF_FINITE) f |= SQL_FINITE;
-            if (flags & SQF_NULL) f |= SQL_NULL;
-            lg.flag = f;
-            st_agent(&sl.flags, flags | SQF_COMMITTED);
         }
     }
 }

@@ -142,13 +142,19 @@ static int seq_window(const pmc_system *h)
 {
     int K = h->seq_window;
     if (K <= 0) {
-        // a pair of pending steps interacts with probability ~ 3^d / cells: about two windows' worth of independent steps
+        // Round 5 (distance-based conflicts, a round of a small window as one launch): small systems keep the windows that run
+        // as one launch per round -- 64 below ~400 cells (N = 4096: 19.8 steps per 24.6 us round; 128 commits no more), 128
+        // below ~1500 -- and from there on the window is what the admission can fill, ~16 cells' worth of neighbourhoods,
+        // with the commit / admission / preparation as launches of their own.  Measured (3-D LJ liquid, 10^6 moves/s, window
+        // 128 / 256 / 512 / 1024): N = 32768 3.4 / 3.2 / 3.5 / 3.6; N = 110592 - / 5.4 / 8.7 / 8.9; N = 10^6: 24.2 at 2048,
+        // 23.1 at 4096.  (Round 4, cell-rule conflicts: N = 10^6 1.45 / 1.58 / 1.51e7 with 1024 / 2048 / 4096; N = 4.1e6
+        // 1.73 / 2.49 / 2.65e7; N = 8e6 1.74 / 2.61 / 2.98e7 -- hence 4096 from ~4e6 particles on.)
         long long nn = 1;
         for (int a = 0; a < h->D; a++) nn *= 3;
-        K = (int)(2LL * h->ncell_ref / nn);
-        // (measured, 3-D LJ liquid: N = 10^6 -- 4 400 by this rule -- runs 1.45 / 1.58 / 1.51e7 moves/s with windows of 1024 /
-        // 2048 / 4096; N = 4.1e6 (19 400) 1.73 / 2.49 / 2.65e7; N = 8e6 (35 000) 1.74 / 2.61 / 2.98e7)
-        K = (K >= 16384) ? SQ_KMAX : std::min(K, 2048);
+        const long long nbh = h->ncell_ref / nn;             // disjoint neighbourhoods in the box
+        if (nbh < 15) K = 64;
+        else if (nbh < 56) K = 128;
+        else K = (2 * nbh >= 16384) ? SQ_KMAX : (int)std::min<long long>(16 * nbh, 2048);
         if (const char *e = getenv("PMC_SEQ_WINDOW")) K = std::min(atoi(e), SQ_KMAX);
     }
     int P = 64;                                             // a power of two (the fill kernel's hash table has 4 K entries)
