@@ -658,10 +658,19 @@ def other_configs(pmc, budget_cpu_s=1.2):
     sts = pmc.mc_sweep_many(chains, pool, nsweeps=20, mode="sequential")
     dt = time.perf_counter() - t0
     rate = 32 * 4096 * 20 / dt
+    # ... and ONE such chain (a window of 64 steps, a round as one launch)
+    pmc.mc_sweep(chains[0], pool, nsweeps=5, mode="sequential")
+    t0 = time.perf_counter()
+    st1 = pmc.mc_sweep(chains[0], pool, nsweeps=60, mode="sequential")
+    dt1 = time.perf_counter() - t0
+    info1 = chains[0].sequential_info()
     rows.append({"config": "32 chains (parallel = true) of N=4096 3D LJ rho=1 T=1 on the reference's sequential chain: speculative windows, every "
-                           "launch of a round shared by the chains (pmc_sweep_many PMC_SEQUENTIAL)",
+                           "launch of a round shared by the chains (pmc_sweep_many PMC_SEQUENTIAL); and one such chain alone",
                  "reference_order_chain": {"moves_per_s": rate, "acceptance": [sum(float(x.accepted[0]) for x in sts) / sum(float(x.attempted[0]) for x in sts)],
-                                           "roofline_frac": _seq_flop_frac(4096, 3, chains[0].neighbour_list.ncells, rate, 62.0)}})
+                                           "roofline_frac": _seq_flop_frac(4096, 3, chains[0].neighbour_list.ncells, rate, 62.0),
+                                           "moves_per_s_one_chain": 4096 * 60 / dt1, "window_one_chain": int(info1[2]),
+                                           "steps_per_round_one_chain": 4096 * 60 / max(1, int(info1[0])),
+                                           "us_per_round_one_chain": 1e3 * float(st1.kernel_ms) / max(1, int(info1[0]))}})
     del chains
     # -- the reference's own benchmark system as many chains on its own (sequential) chain
     pos, sp, rho = lj_lattice(6, jitter=0.05, seed=42)

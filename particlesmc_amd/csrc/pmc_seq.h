@@ -1695,9 +1695,9 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
             sq_terms_push(bufa, na, ua);
             if (BOTH) sq_terms_push(bufb, nb, ub);
         } else {
-            int ca = 0, cb = 0;
-            sq_terms_push(bufa + tr * SEG, ca, ua);
-            if (BOTH) sq_terms_push(bufb + tr * SEG, cb, ub);
+            const int ca = sq_terms_push_seg(bufa + tr * SEG, ua);      // (eight zeros behind the terms: the chain reads whole blocks)
+            int cb = 0;
+            if (BOTH) cb = sq_terms_push_seg(bufb + tr * SEG, ub);
             if (lane == 0) { v.tcount[tr] = ca; if (BOTH) v.tcount[s.max_trips + tr] = cb; }
         }
     }
@@ -1708,7 +1708,11 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
         if ((wv == 0 || (BOTH && wv == 1)) && !(s.dbg & 2)) {
             double *seg = wv == 0 ? bufa : bufb;
             double acc = 0.0;
-            for (int tr = 0; tr < ntrip; tr++) acc = sq_terms_sum(seg + tr * SEG, v.tcount[wv * s.max_trips + tr], acc);
+            if (ntrip <= PMC_WAVE) {                                  // one straight chain, the next segment's block in flight (sq_terms_chain)
+                acc = sq_terms_chain(seg, v.tcount + wv * s.max_trips, ntrip, acc);
+            } else {
+                for (int tr = 0; tr < ntrip; tr++) acc = sq_terms_sum(seg + tr * SEG, v.tcount[wv * s.max_trips + tr], acc);
+            }
             if (lane == 0) v.esum[wv] = acc;
         }
         __syncthreads();

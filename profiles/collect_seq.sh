@@ -9,16 +9,19 @@ P=gpurun_out/prof
 mkdir -p $P
 # ---- round 4: the reference-order chain (PMC_SEQUENTIAL; pmc_seq.h) ----------------------------------------------------------
 # engine 2 (speculative windows) on the headline system, engine 3 (state in LDS) on 1000 chains of the reference's benchmark system
-rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write
+rm -rf $P/seq_small_trace $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write
 export STEPS=3000000 NO_ENGINE1=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/seq_trace -- python3 examples/seq_rate.py 100 > $P/seq_rate.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/seq_many_trace -- python3 examples/seq_many.py 6 1000 100 > $P/seq_many.log 2>&1
+# round 5: a small window, one launch per round (k_sq_round_fused; N = 4096, windows of 64)
+rm -rf $P/seq_small_trace
+STEPS=1000000 rocprofv3 --kernel-trace --stats --output-format csv -d $P/seq_small_trace -- python3 examples/seq_rate.py 16 > $P/seq_small.log 2>&1
 export STEPS=1000000
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/seq_sq -- python3 examples/seq_rate.py 100 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/seq_fetch -- python3 examples/seq_rate.py 100 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/seq_write -- python3 examples/seq_rate.py 100 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/seq_many_sq -- python3 examples/seq_many.py 6 1000 20 > /dev/null 2>&1
-python3 examples/seq_rate.py 16 32 48 64 100 > gpurun_out/seq_rate_table.jsonl 2>&1
+STEPS=2000000 python3 examples/seq_rate.py 16 32 48 64 100 > gpurun_out/seq_rate_table.jsonl 2>&1
 for n in 1 64 256 1000 4000; do python3 examples/seq_many.py 6 $n 100; done > gpurun_out/seq_many_table.jsonl 2>&1
 python3 examples/seq_many.py 10 256 20 >> gpurun_out/seq_many_table.jsonl 2>&1
 # the team-of-8 instance of the throughput kernel (config 2), counters for DESIGN 8b / VERDICT r03 item 4
@@ -34,5 +37,5 @@ for w in big single; do
 done
 mkdir -p gpurun_out/seq_summary
 PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py ${ROUND:-r05} --seq-only
-rm -rf $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace $P/big_sq $P/big_trace $P/single_sq $P/single_trace
+rm -rf $P/seq_small_trace $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace $P/big_sq $P/big_trace $P/single_sq $P/single_trace
 ls gpurun_out/seq_summary

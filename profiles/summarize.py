@@ -117,7 +117,7 @@ if not SEQ_ONLY:
 # ---- round 4: the reference-order chain (collect.sh "round 4") -------------------------------------------------------------------
 def _seq_summary():
     out = {}
-    for sub, name in (("seq_trace", "engine2_N1e6"), ("seq_many_trace", "engine3_1000xN216")):
+    for sub, name in (("seq_trace", "engine2_N1e6"), ("seq_small_trace", "engine2_N4096_one_launch_per_round"), ("seq_many_trace", "engine3_1000xN216")):
         st = sorted(glob.glob(os.path.join(SRC, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
         if not st:
             continue
@@ -125,7 +125,7 @@ def _seq_summary():
         rows = [r for r in csv.DictReader(open(st[-1])) if "k_sq" in r["Name"]]
         out[name] = {"kernels": {r["Name"].split("(")[0]: {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                                             "total_ms": float(r["TotalDurationNs"]) / 1e6} for r in rows}}
-        log = os.path.join(SRC, "seq_rate.log" if sub == "seq_trace" else "seq_many.log")
+        log = os.path.join(SRC, {"seq_trace": "seq_rate.log", "seq_small_trace": "seq_small.log"}.get(sub, "seq_many.log"))
         if os.path.exists(log):
             lines = [json.loads(l) for l in open(log) if l.startswith("{")]
             if lines:

@@ -54,6 +54,24 @@ def _draw(pmc, O, case):
     raise AssertionError(f"case {case}: no acceptable geometry in 50 draws")
 
 
+def _engine2_switches(case, monkeypatch):
+    """The launch forms and conflict rules of the speculative windows (round 5), drawn per case from a generator of their own:
+    a round as one launch / four launches / evaluation + one-workgroup tail, one or four wavefronts per evaluated step, the
+    distance rule or the cell rule for conflicts -- the same chain, bit for bit, whichever runs."""
+    r = np.random.default_rng(991000 + case)
+    for var in ("PMC_SEQ_CELLRULE", "PMC_SEQ_NOFUSE", "PMC_SEQ_EW", "PMC_SEQ_TWO"):
+        monkeypatch.delenv(var, raising=False)
+    if r.random() < 0.25:
+        monkeypatch.setenv("PMC_SEQ_CELLRULE", "1")
+    form = r.random()
+    if form < 0.2:
+        monkeypatch.setenv("PMC_SEQ_NOFUSE", "1")
+    elif form < 0.35:
+        monkeypatch.setenv("PMC_SEQ_TWO", "1")
+    if r.random() < 0.2:
+        monkeypatch.setenv("PMC_SEQ_EW", "1")
+
+
 @pytest.mark.parametrize("case", range(FIRST, FIRST + NCASES))
 def test_random_sequential_chain(gpu, case, monkeypatch):
     _run_case(gpu, case, monkeypatch)
@@ -76,6 +94,7 @@ def _run_case(gpu, case, monkeypatch):
     glt = {"linked": pmc.LinkedList, "cell": pmc.CellList, "empty": pmc.EmptyList}[lt]
     monkeypatch.delenv("PMC_SEQ_WAVES", raising=False)
     monkeypatch.delenv("PMC_SEQ_WINDOW", raising=False)
+    _engine2_switches(case, monkeypatch)
     if rng.random() < 0.5:
         monkeypatch.setenv("PMC_SEQ_WAVES", str(int(rng.choice([1, 4]))))
     g = pmc.System(pos, sp, rho, T, mm, list_type=glt, seed=seed, chain=chain)
@@ -133,6 +152,7 @@ def test_random_sequential_chains_in_shared_launches(gpu, case, monkeypatch):
     glt = {"linked": pmc.LinkedList, "cell": pmc.CellList, "empty": pmc.EmptyList}[lt]
     monkeypatch.delenv("PMC_SEQ_WAVES", raising=False)
     monkeypatch.delenv("PMC_SEQ_WINDOW", raising=False)
+    _engine2_switches(500000 + case, monkeypatch)
     if rng.random() < 0.5:
         monkeypatch.setenv("PMC_SEQ_WAVES", str(int(rng.choice([1, 4]))))
     nch = int(rng.integers(2, 13)) if N <= 4000 else int(rng.integers(2, 5))
