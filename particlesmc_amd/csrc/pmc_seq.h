@@ -385,7 +385,7 @@ __device__ __forceinline__ double *sq_terms_buffer(const SqArgs &s, int *lds_ids
 // round-robin, the last wavefront walks the chains of pending steps.
 template <int D, int NW = 1>
 __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids, int w = -1, const double *pa = nullptr, const double *pb = nullptr,
-                                           const int *fc = nullptr)
+                                           const int *fc = nullptr, int room = 0x7fffffff)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
     constexpr int PER = (NN + NW - 1) / NW;
@@ -437,17 +437,18 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
     const int off = incl - len;
     const int total = __builtin_amdgcn_readlane(incl, 31);
     const bool longrows = __any(len > PMC_WAVE);
+    const bool fits = total <= room;              // (a second sequence behind the first one -- a crossing step's -- may not: nothing is written then)
     __syncthreads();                              // the previous pass has read its ids
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int l = k * NW + wv;
-        if (l < NN) {
+        if (l < NN && fits) {
             const int len_l = __builtin_amdgcn_readlane(len, l);
             const int off_l = __builtin_amdgcn_readlane(off, l);
             if (lane < len_l) lds_ids[off_l + (reverse ? len_l - 1 - lane : lane)] = v[k];
         }
     }
-    if (longrows) {                               // rows longer than a wavefront (dense cells, long cutoffs)
+    if (longrows && fits) {                       // rows longer than a wavefront (dense cells, long cutoffs)
         for (int l = wv; l < cnt; l += NW) {
             const int len_l = __shfl(len, l, PMC_WAVE), cc_l = __shfl(cc, l, PMC_WAVE), off_l = __shfl(off, l, PMC_WAVE);
             for (int k = PMC_WAVE + lane; k < len_l; k += PMC_WAVE)
@@ -500,7 +501,7 @@ __device__ __forceinline__ int sq_sequence(const SqArgs &s, int c, int *lds_ids,
         }
     }
     SQE(4);                                       // chains of pending steps walked
-    return total;
+    return fits ? total : -1;
 }
 
 #define SQ_CHUNK 8          // trips of 64 candidates whose position loads are in flight together
@@ -625,12 +626,12 @@ __device__ __forceinline__ void sq_pass_swap(const SqArgs &s, int c, int i, int 
 #define SQ_TRMAX 16                  // trips whose segments the LDS holds at once (1024 candidates; longer sequences: in several goes)
 #define SQ_SEG (PMC_WAVE + SQ_TERMS_PAD)
 
-// the evaluation's dynamic LDS with SQ_EW wavefronts: ids (twice), two sets of segments, the two sums, the segments' term counts
+// the evaluation's dynamic LDS with SQ_EW wavefronts: ids, two sets of segments, the two sums, the segments' term counts
 __host__ __device__ inline size_t sq_eval_lds_bytes(int ids_cap, int nw)
 {
     const size_t ids = (size_t)((ids_cap + 3) & ~3) * sizeof(int);
     return nw == 1 ? ids + 2 * (size_t)SQ_TERMS_BUF * sizeof(double)
-                   : 2 * ids + (2 * (size_t)SQ_TRMAX * SQ_SEG + 2) * sizeof(double) + 2 * SQ_TRMAX * sizeof(int);   // (two sequences: a crossing step's)
+                   : ids + (2 * (size_t)SQ_TRMAX * SQ_SEG + 2) * sizeof(double) + 2 * SQ_TRMAX * sizeof(int);
 }
 
 __device__ __forceinline__ int sq_terms_push_seg(double *seg, double u)
@@ -753,11 +754,19 @@ __device__ __forceinline__ void sq_pass_mw(const SqArgs &s, int c, int cb, int i
     const int lane = wave_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int idsz = (s.ids_cap + 3) & ~3;
-    int *idsb = lds_ids + idsz;
     const bool fine = MODE == 1 && s.conf_r2 > 0.0;
     const int total = sq_sequence<D, NW>(s, c, lds_ids, w, fine ? xa : nullptr, fine ? xb : nullptr, fc);
-    const int totalb = (MODE == 3) ? sq_sequence<D, NW>(s, cb, idsb, w, nullptr, nullptr, fcb) : 0;
-    double *bufa = reinterpret_cast<double *>(lds_ids + 2 * idsz), *bufb = bufa + SQ_TRMAX * SQ_SEG, *esum = bufb + SQ_TRMAX * SQ_SEG;
+    // (a crossing step's second sequence goes behind the first: the region holds 3^d FULL rows, two neighbourhoods of a liquid
+    // fill a fraction of it; if they ever do not fit, the two passes run one after the other)
+    int *idsb = lds_ids + ((total + 3) & ~3);
+    const int totalb = (MODE == 3) ? sq_sequence<D, NW>(s, cb, idsb, w, nullptr, nullptr, fcb, idsz - ((total + 3) & ~3)) : 0;
+    if (MODE == 3 && totalb < 0) {
+        double dummy;
+        sq_pass_mw<D, 0, KIND, NW>(s, c, c, i, spa, spa, -1, xa, xa, lds_ids, ea, dummy, -1, fc, nullptr);
+        sq_pass_mw<D, 0, KIND, NW>(s, cb, cb, i, spa, spa, -1, xb, xb, lds_ids, eb, dummy, -1, fcb, nullptr);
+        return;
+    }
+    double *bufa = reinterpret_cast<double *>(lds_ids + idsz), *bufb = bufa + SQ_TRMAX * SQ_SEG, *esum = bufb + SQ_TRMAX * SQ_SEG;
     int *tcount = reinterpret_cast<int *>(esum + 2);
     double L[3] = {1, 1, 1}, iL[3] = {1, 1, 1};
 #pragma unroll
@@ -934,8 +943,10 @@ __device__ __forceinline__ void sq_eval(const SqArgs &s, int w, int *lds_ids)
 }
 
 // ---- round, third launch: every pending step finds the earlier steps it could interact with and is evaluated --------------------------------------
+// (five waves per SIMD: at 28 KB of LDS a CU then holds five steps, the chip 1280 -- the ~1100 pending steps of a window of 2048
+// are evaluated in one go instead of 1024 and a second helping)
 template <int D, int KIND = 4, int NW = 1>
-__global__ __launch_bounds__(NW * 64) void k_sq_round_a(const SqArgs *__restrict__ tab)
+__global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 5) void k_sq_round_a(const SqArgs *__restrict__ tab)
 {
     const SqArgs &s = tab[blockIdx.y];
     extern __shared__ int sq_lds[];
@@ -1264,12 +1275,20 @@ __device__ __forceinline__ void sq_prep_thread(const SqArgs &s, const int t)
     if (t < nold) {
         const int to = s.moveto[t];
         if (to >= 0) {
-            SqSlot sl = s.slots[cur ^ 1][t];
-            sl.flags &= (SQF_SWAP | SQF_NULL);          // (what the last evaluation found is void; in a fused round it may not even be visible here)
-            dst[to] = sl;
-            if (sl.pk[3]) {                             // entered under its cell(s): sq_conflicts walks these chains
-                s.cellnext[2 * to] = atomicExch(&s.cellhead[sl.c0], 2 * to);
-                if (sl.c1 != sl.c0) s.cellnext[2 * to + 1] = atomicExch(&s.cellhead[sl.c1], 2 * to + 1);
+            // twelve 16-byte words (a local SqSlot went through scratch memory: two more round trips)
+            static_assert(sizeof(SqSlot) == 192 && offsetof(SqSlot, flags) == 36 && offsetof(SqSlot, c0) == 40 && offsetof(SqSlot, pk) == 0, "SqSlot layout");
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(&s.slots[cur ^ 1][t]);
+            uint4 *dst4 = reinterpret_cast<uint4 *>(&dst[to]);
+            uint4 q[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) q[k] = src4[k];
+            q[2].y &= (unsigned)(SQF_SWAP | SQF_NULL);  // flags (bytes 36..39): what the last evaluation found is void; in a fused round it may not even be visible here
+#pragma unroll
+            for (int k = 0; k < 12; k++) dst4[k] = q[k];
+            const int pk3 = (int)q[0].w, kc0 = (int)q[2].z, kc1 = (int)q[2].w;
+            if (pk3) {                                  // entered under its cell(s): sq_conflicts walks these chains
+                s.cellnext[2 * to] = atomicExch(&s.cellhead[kc0], 2 * to);
+                if (kc1 != kc0) s.cellnext[2 * to + 1] = atomicExch(&s.cellhead[kc1], 2 * to + 1);
             }
         }
         return;
@@ -1279,35 +1298,48 @@ __device__ __forceinline__ void sq_prep_thread(const SqArgs &s, const int t)
     const unsigned long long g = ctl->f_next0 + (unsigned long long)q;
     const SqGen &ge = s.gen[g & s.gen_mask];
     const int i = s.cand[3 * q], j = s.cand[3 * q + 1];
-    SqSlot sl;
-    sl.g = g;
-    sl.i = i; sl.j = j; sl.m = ge.m; sl.flags = s.cand[3 * q + 2];
-    sl.c0 = sl.c1 = sl.c2 = 0; sl.spi = sl.spj = 0; sl.pad0 = sl.pad1 = sl.pad2 = 0;
-    sl.lnu = ge.lnu; sl.de = 0.0;
-    sl.pk[0] = sl.pk[1] = sl.pk[2] = sl.pk[3] = 0;
+    // the record is assembled in registers and leaves as twelve 16-byte words (a local SqSlot went through scratch memory)
+    const int m = ge.m, fl = s.cand[3 * q + 2];
+    const double lnu = ge.lnu;
+    double x[3], d[3], xn[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        sl.x[k] = (k < D && i >= 0) ? a.pos[(size_t)i * D + k] : 0.0;
-        sl.d[k] = ge.d[k];
-        sl.xn[k] = (k < D && i >= 0) ? ((j >= 0) ? a.pos[(size_t)j * D + k]      // DiscreteSwap: the partner's position
-                                               : sl.x[k] + ge.d[k])            // update_position! (src/moves.jl:46-48)
-                                   : 0.0;
-        sl.xr[k] = 0.0;
+        x[k] = (k < D && i >= 0) ? a.pos[(size_t)i * D + k] : 0.0;
+        d[k] = ge.d[k];
+        xn[k] = (k < D && i >= 0) ? ((j >= 0) ? a.pos[(size_t)j * D + k]         // DiscreteSwap: the partner's position
+                                            : x[k] + d[k])                     // update_position! (src/moves.jl:46-48)
+                                : 0.0;
     }
+    int c0 = 0, c1 = 0, pk[4] = {0, 0, 0, 0};
     if (i >= 0) {                                       // (a null step has no cells and interacts with nothing)
         int f0[3], f1[3];
-        sl.c0 = sq_cell_of_fast<D>(s, sl.x, f0);
-        sl.c1 = sq_cell_of_fast<D>(s, sl.xn, f1);
-        sl.c2 = sl.c0;
-        sl.pk[0] = f0[0] | (f0[1] << 16);
-        sl.pk[1] = f0[2] | (f1[0] << 16);
-        sl.pk[2] = f1[1] | (f1[2] << 16);
-        sl.pk[3] = 1;
+        c0 = sq_cell_of_fast<D>(s, x, f0);
+        c1 = sq_cell_of_fast<D>(s, xn, f1);
+        pk[0] = f0[0] | (f0[1] << 16);
+        pk[1] = f0[2] | (f1[0] << 16);
+        pk[2] = f1[1] | (f1[2] << 16);
+        pk[3] = 1;
         const int to = nkeep + q;
-        s.cellnext[2 * to] = atomicExch(&s.cellhead[sl.c0], 2 * to);
-        if (sl.c1 != sl.c0) s.cellnext[2 * to + 1] = atomicExch(&s.cellhead[sl.c1], 2 * to + 1);
+        s.cellnext[2 * to] = atomicExch(&s.cellhead[c0], 2 * to);
+        if (c1 != c0) s.cellnext[2 * to + 1] = atomicExch(&s.cellhead[c1], 2 * to + 1);
     }
-    dst[nkeep + q] = sl;
+    auto lo = [](double v) { return (unsigned)(__double_as_longlong(v) & 0xffffffffll); };
+    auto hi = [](double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) >> 32); };
+    uint4 *dst4 = reinterpret_cast<uint4 *>(&dst[nkeep + q]);
+    dst4[0] = make_uint4((unsigned)pk[0], (unsigned)pk[1], (unsigned)pk[2], (unsigned)pk[3]);
+    dst4[1] = make_uint4((unsigned)(g & 0xffffffffull), (unsigned)(g >> 32), (unsigned)i, (unsigned)j);
+    dst4[2] = make_uint4((unsigned)m, (unsigned)fl, (unsigned)c0, (unsigned)c1);
+    dst4[3] = make_uint4((unsigned)c0, 0u, 0u, 0u);                                  // c2 = c0, spi
+    dst4[4] = make_uint4(0u, 0u, lo(x[0]), hi(x[0]));                                // spj, pad0 | bytes 72..: pad1, pad2?  (see the layout assert)
+    static_assert(offsetof(SqSlot, c2) == 48 && offsetof(SqSlot, spj) == 56 && offsetof(SqSlot, x) == 72 && offsetof(SqSlot, d) == 96 &&
+                  offsetof(SqSlot, xn) == 120 && offsetof(SqSlot, xr) == 144 && offsetof(SqSlot, lnu) == 168 && offsetof(SqSlot, de) == 176, "SqSlot layout");
+    dst4[5] = make_uint4(lo(x[1]), hi(x[1]), lo(x[2]), hi(x[2]));
+    dst4[6] = make_uint4(lo(d[0]), hi(d[0]), lo(d[1]), hi(d[1]));
+    dst4[7] = make_uint4(lo(d[2]), hi(d[2]), lo(xn[0]), hi(xn[0]));
+    dst4[8] = make_uint4(lo(xn[1]), hi(xn[1]), lo(xn[2]), hi(xn[2]));
+    dst4[9] = make_uint4(0u, 0u, 0u, 0u);                                            // xr[0], xr[1]
+    dst4[10] = make_uint4(0u, 0u, lo(lnu), hi(lnu));                                 // xr[2], lnu
+    dst4[11] = make_uint4(0u, 0u, 0u, 0u);                                           // de, padding
 }
 
 template <int D>
