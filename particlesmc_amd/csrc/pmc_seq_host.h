@@ -225,7 +225,7 @@ struct SeqGroup {
     }
 };
 
-#define SQ_GRAPH_ROUNDS 16
+#define SQ_GRAPH_ROUNDS 32
 
 static void seq_launch_round(const SeqGroup &g)
 {
