@@ -474,7 +474,11 @@ static int seq_group_enqueue(SeqGroup &g, bool pipelined = false)
         else hipLaunchKernelGGL(k_sq_tail<2>, dim3(1, g.n), dim3(SQ_TAIL_THREADS), g.lds_fill, m->stream, g.d_tab);
     }
     long long q = 0;
-    if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH")) {
+    // (with a rocprofiler-sdk tool attached -- rocprofv3 sets ROCP_TOOL_LIBRARIES -- the rounds go launch by launch: on ROCm 7.2
+    // hipGraphLaunch under `rocprofv3 --kernel-trace` crashes inside the tool's dispatch callback for some of these graphs
+    // (windows of 64 and 1024 in runs of >= 10^6 steps; never without the tool).  PMC_SEQ_GRAPH=1 replays the graph anyway.)
+    const bool tool = getenv("ROCP_TOOL_LIBRARIES") != nullptr && !getenv("PMC_SEQ_GRAPH");
+    if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH") && !tool) {
         if (int rg = seq_graph(g)) return rg;
         for (; q + SQ_GRAPH_ROUNDS <= rounds; q += SQ_GRAPH_ROUNDS) HIPCHK(m, hipGraphLaunch(g.graph, m->stream));
     }
