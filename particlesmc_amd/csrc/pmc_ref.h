@@ -112,6 +112,68 @@ __device__ __forceinline__ double readlane_double(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
+// Ordered FP64 sums through LDS.  The chain acc += u_k must run in iterator order, one rounding per term; terms that are 0 can
+// be left out.  Lanes deposit their non-zero terms, in lane order, behind the terms already there (sq_terms_push); the sum is
+// then one chain of dependent additions fed by LDS reads that do not depend on it (sq_terms_sum): ~10 cycles per term, where
+// a ballot / readlane loop over the lanes of a register takes ~100.  Buffers hold SQ_TERMS terms and are summed down whenever
+// the next 64 might not fit, which keeps the order.
+#define SQ_TERMS 192
+#define SQ_TERMS_PAD 8
+#define SQ_TERMS_BUF (SQ_TERMS + 64 + SQ_TERMS_PAD)     // doubles of one buffer
+
+__device__ __forceinline__ double sq_terms_sum(double *buf, int n, double acc)
+{
+    const int lane = wave_lane();
+    if (lane < SQ_TERMS_PAD) buf[n + lane] = 0.0;               // (+0.0 leaves the sum as it is: the loop runs in blocks of 8)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the terms are in LDS
+    for (int k = 0; k < n; k += SQ_TERMS_PAD) {
+        const double t0 = buf[k], t1 = buf[k + 1], t2 = buf[k + 2], t3 = buf[k + 3];
+        const double t4 = buf[k + 4], t5 = buf[k + 5], t6 = buf[k + 6], t7 = buf[k + 7];
+        acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; acc += t6; acc += t7;
+    }
+    return acc;
+}
+
+// two sums at once: their chains are independent and interleave
+__device__ __forceinline__ void sq_terms_sum2(double *bufa, int na, double &acca, double *bufb, int nb, double &accb)
+{
+    const int lane = wave_lane();
+    if (lane < SQ_TERMS_PAD) { bufa[na + lane] = 0.0; bufb[nb + lane] = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    double a = acca, b = accb;
+    const int n = max(na, nb);
+    // (both buffers are SQ_TERMS + 64 + 8 long: reading one past its own terms is safe, and masked)
+    for (int k = 0; k < n; k += SQ_TERMS_PAD) {
+        double ta[SQ_TERMS_PAD], tb[SQ_TERMS_PAD];
+#pragma unroll
+        for (int q = 0; q < SQ_TERMS_PAD; q++) { ta[q] = bufa[k + q]; tb[q] = bufb[k + q]; }     // sixteen reads in flight
+        const bool ina = k < na, inb = k < nb;              // (a block that starts inside the terms ends inside their zero padding)
+#pragma unroll
+        for (int q = 0; q < SQ_TERMS_PAD; q++) {
+            a += ina ? ta[q] : 0.0;
+            b += inb ? tb[q] : 0.0;
+        }
+    }
+    acca = a;
+    accb = b;
+}
+
+__device__ __forceinline__ void sq_terms_push(double *buf, int &n, double u)
+{
+    const unsigned long long mk = __ballot(u != 0.0);
+    if (mk) {
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (u != 0.0) buf[n + rank] = u;
+        n += __popcll(mk);
+    }
+}
+
+// the LDS of the literal loop's kernels: PMC_REF_IDS neighbour ids, then one buffer of ordered-sum terms
+#define PMC_REF_LDS_INTS (PMC_REF_IDS + 2 * SQ_TERMS_BUF)
+__device__ __forceinline__ double *ref_terms_of(int *lds_ids) { return reinterpret_cast<double *>(lds_ids + PMC_REF_IDS); }
+
 // compute_energy_particle with the LinkedIterator order (src/atoms.jl:81-88,
 // src/neighbours.jl:332-377).  One wavefront: the <= 27 chains are walked by <= 27 lanes
 // concurrently into one LDS id buffer (offsets from the maintained per-cell counts), pair terms
@@ -123,17 +185,35 @@ __device__ double wave_ordered_energy(const RefArgs &a, int i, const double *xi,
     const int lane = wave_lane();
     if (a.list_type == 0 || a.list_type == 3) {
         // EmptyList: j in 1:N (src/neighbours.jl:42-44); VerletList: j in neighbours[i] (:422-424)
+        // (round 5: the non-zero terms go through LDS in order -- sq_terms_push / sq_terms_sum, ~10 cycles per term -- instead of
+        // a readlane loop over all 64 lanes of every trip, ~40 cycles per lane: an EmptyList system of 10^4 particles spent
+        // 4 x 10^5 cycles per energy adding zeros.  A term that is 0 leaves the sum as it is.)
         const int total = (a.list_type == 0) ? a.N : a.vl_cnt[i];
+        double *tb = ref_terms_of(lds_ids);
         double acc = 0.0;
-        for (int base = 0; base < total; base += PMC_WAVE) {
-            const int n = min(PMC_WAVE, total - base);
-            double u = 0.0;
-            if (lane < n) {
-                const int j = (a.list_type == 0) ? base + lane : a.vl_nb[(size_t)i * a.vl_cap + base + lane];
-                u = ref_energy_ij<D>(a, i, j, xi, spi);
+        int nt = 0;
+        constexpr int UN = 4;                                        // trips whose loads are in flight together
+        __syncthreads();
+        for (int base = 0; base < total; base += UN * PMC_WAVE) {
+            double u[UN];
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                const int t = base + q * PMC_WAVE + lane;
+                u[q] = 0.0;
+                if (t < total) {
+                    const int j = (a.list_type == 0) ? t : a.vl_nb[(size_t)i * a.vl_cap + t];
+                    u[q] = ref_energy_ij<D>(a, i, j, xi, spi);
+                }
             }
-            for (int k = 0; k < n; k++) acc += readlane_double(u, k);
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                if (base + q * PMC_WAVE >= total) break;
+                if (nt > SQ_TERMS) { acc = sq_terms_sum(tb, nt, acc); nt = 0; }
+                sq_terms_push(tb, nt, u[q]);
+            }
         }
+        acc = sq_terms_sum(tb, nt, acc);
+        __syncthreads();
         return acc;
     }
     int c = ref_cell_of<D>(a, xi);
@@ -165,12 +245,16 @@ __device__ double wave_ordered_energy(const RefArgs &a, int i, const double *xi,
             }
         }
         __syncthreads();
+        double *tb = ref_terms_of(lds_ids);
+        int nt = 0;
         for (int base = 0; base < total; base += PMC_WAVE) {
             const int n = min(PMC_WAVE, total - base);
             double u = 0.0;
             if (lane < n) u = ref_energy_ij<D>(a, i, lds_ids[base + lane], xi, spi);
-            for (int k = 0; k < n; k++) acc += readlane_double(u, k);
+            if (nt > SQ_TERMS) { acc = sq_terms_sum(tb, nt, acc); nt = 0; }
+            sq_terms_push(tb, nt, u);
         }
+        acc = sq_terms_sum(tb, nt, acc);
     } else if (a.list_type == 2) {
         for (int l = 0; l < cnt; l++) {
             const int cc = a.nbr[(size_t)c * a.nnmax + l];
@@ -195,7 +279,7 @@ template <int D>
 __global__ __launch_bounds__(64) void k_ref_energy(RefArgs a, const int *__restrict__ which, int n,
                                                     double *__restrict__ out)
 {
-    __shared__ int lds_ids[PMC_REF_IDS];
+    __shared__ __attribute__((aligned(16))) int lds_ids[PMC_REF_LDS_INTS];
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         int i = which ? which[b] : b;
         double xi[3] = {0, 0, 0};
@@ -578,7 +662,7 @@ __device__ void ref_steps(const RefArgs &a, const RefOp &o, int *lds_ids)
 template <int D>
 __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
 {
-    __shared__ int lds_ids[PMC_REF_IDS];
+    __shared__ __attribute__((aligned(16))) int lds_ids[PMC_REF_LDS_INTS];
     const int lane = wave_lane();
     double e1 = 0, e2 = 0, de = 0;
     if (o.op == OP_DISP_PERFORM) {
@@ -602,7 +686,7 @@ __global__ __launch_bounds__(64) void k_ref_ops(RefArgs a, RefOp o)
 template <int D>
 __global__ __launch_bounds__(64) void k_ref_steps_many(const RefArgs *__restrict__ args, const RefOp *__restrict__ ops)
 {
-    __shared__ int lds_ids[PMC_REF_IDS];
+    __shared__ __attribute__((aligned(16))) int lds_ids[PMC_REF_LDS_INTS];
     ref_steps<D>(args[blockIdx.x], ops[blockIdx.x], lds_ids);
 }
 

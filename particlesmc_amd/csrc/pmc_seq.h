@@ -312,63 +312,7 @@ __device__ __forceinline__ int __reduce_max_sync_compat(int v)
     return v;
 }
 
-// Ordered FP64 sums through LDS.  The chain acc += u_k must run in iterator order, one rounding per term; terms that are 0 can
-// be left out.  Lanes deposit their non-zero terms, in lane order, behind the terms already there (sq_terms_push); the sum is
-// then one chain of dependent additions fed by LDS reads that do not depend on it (sq_terms_sum): ~10 cycles per term, where
-// a ballot / readlane loop over the lanes of a register takes ~100.  Buffers hold SQ_TERMS terms and are summed down whenever
-// the next 64 might not fit, which keeps the order.
-#define SQ_TERMS 192
-#define SQ_TERMS_PAD 8
-#define SQ_TERMS_BUF (SQ_TERMS + 64 + SQ_TERMS_PAD)     // doubles of one buffer
-
-__device__ __forceinline__ double sq_terms_sum(double *buf, int n, double acc)
-{
-    const int lane = wave_lane();
-    if (lane < SQ_TERMS_PAD) buf[n + lane] = 0.0;               // (+0.0 leaves the sum as it is: the loop runs in blocks of 8)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the terms are in LDS
-    for (int k = 0; k < n; k += SQ_TERMS_PAD) {
-        const double t0 = buf[k], t1 = buf[k + 1], t2 = buf[k + 2], t3 = buf[k + 3];
-        const double t4 = buf[k + 4], t5 = buf[k + 5], t6 = buf[k + 6], t7 = buf[k + 7];
-        acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; acc += t6; acc += t7;
-    }
-    return acc;
-}
-
-// two sums at once: their chains are independent and interleave
-__device__ __forceinline__ void sq_terms_sum2(double *bufa, int na, double &acca, double *bufb, int nb, double &accb)
-{
-    const int lane = wave_lane();
-    if (lane < SQ_TERMS_PAD) { bufa[na + lane] = 0.0; bufb[nb + lane] = 0.0; }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    double a = acca, b = accb;
-    const int n = max(na, nb);
-    // (both buffers are SQ_TERMS + 64 + 8 long: reading one past its own terms is safe, and masked)
-    for (int k = 0; k < n; k += SQ_TERMS_PAD) {
-        double ta[SQ_TERMS_PAD], tb[SQ_TERMS_PAD];
-#pragma unroll
-        for (int q = 0; q < SQ_TERMS_PAD; q++) { ta[q] = bufa[k + q]; tb[q] = bufb[k + q]; }     // sixteen reads in flight
-        const bool ina = k < na, inb = k < nb;              // (a block that starts inside the terms ends inside their zero padding)
-#pragma unroll
-        for (int q = 0; q < SQ_TERMS_PAD; q++) {
-            a += ina ? ta[q] : 0.0;
-            b += inb ? tb[q] : 0.0;
-        }
-    }
-    acca = a;
-    accb = b;
-}
-
-__device__ __forceinline__ void sq_terms_push(double *buf, int &n, double u)
-{
-    const unsigned long long mk = __ballot(u != 0.0);
-    if (mk) {
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-        if (u != 0.0) buf[n + rank] = u;
-        n += __popcll(mk);
-    }
-}
+// (Ordered FP64 sums through LDS -- sq_terms_push / sq_terms_sum / sq_terms_sum2 -- are in pmc_ref.h: the literal loop uses them too.)
 
 // the evaluation's dynamic LDS: ids_cap ints of neighbour ids, then the two term buffers
 __device__ __forceinline__ double *sq_terms_buffer(const SqArgs &s, int *lds_ids)
