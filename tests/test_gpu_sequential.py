@@ -419,3 +419,70 @@ def test_ss142d_hundred_chains_of_eight_particles_in_one_launch(gpu):
         att, acc = o.mc_steps(opool, 42, k, 0, 200 * N)
         assert stats[k].attempted[0] == att[0] == 1600 and stats[k].accepted[0] == acc[0], k
         assert np.array_equal(chains[k].position, o.positions()) and chains[k].energy[0] == o.energy, k
+
+
+_FORMS = {"one launch per round": {}, "four launches": {"PMC_SEQ_NOFUSE": "1"}, "evaluation + one-workgroup tail": {"PMC_SEQ_NOFUSE": "1", "PMC_SEQ_TWO": "1"},
+          "one wavefront per step": {"PMC_SEQ_EW": "1"}, "cell rule": {"PMC_SEQ_CELLRULE": "1"},
+          "cell rule, four launches, one wavefront (round 4's engine)": {"PMC_SEQ_CELLRULE": "1", "PMC_SEQ_NOFUSE": "1", "PMC_SEQ_EW": "1"},
+          "as under a profiler": {"ROCP_TOOL_LIBRARIES": "none"}}
+
+
+@pytest.mark.parametrize("form", list(_FORMS))
+def test_every_launch_form_and_conflict_rule_of_the_windows(gpu, form, monkeypatch):
+    """Round 5 gave the speculative windows three launch forms (a round as one launch: evaluate, the last workgroup commits, admits
+    and prepares; four launches; evaluation + a one-workgroup tail), four wavefronts per evaluated step and a distance-based
+    conflict rule next to the cell rule.  Each combination on one Kob-Andersen liquid with swaps and wide moves (cell crossings,
+    accepted swaps, held-back steps) and on a 2-D soft-sphere system, three calls each: the oracle's chain, bit for bit."""
+    from oracle import oracle as O
+    pmc = gpu
+    for var in ("PMC_SEQ_NOFUSE", "PMC_SEQ_TWO", "PMC_SEQ_EW", "PMC_SEQ_CELLRULE", "PMC_SEQ_GRAPH", "PMC_SEQ_NOGRAPH", "ROCP_TOOL_LIBRARIES"):
+        monkeypatch.delenv(var, raising=False)
+    for var, val in _FORMS[form].items():
+        monkeypatch.setenv(var, val)
+    pos, sp, rho = binary_lattice(2744, frac_b=0.2, rho=1.2, jitter=0.05, seed=11)
+    g = pmc.System(pos, sp, rho, 1.0, pmc.KobAndersen(), seed=21)
+    o = O.System(pos, sp, rho, 1.0, O.kob_andersen(), O.LINKEDLIST)
+    nb = int((sp == 2).sum())
+    pm = [_disp(pmc, 0.05, 0.5), _disp(pmc, 0.4, 0.3), _swap(pmc, (1, 2), (len(sp) - nb, nb), 0.2)]
+    po = O.make_pool([{"kind": "Displacement", "sigma": 0.05, "probability": 0.5}, {"kind": "Displacement", "sigma": 0.4, "probability": 0.3},
+                      {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.2}])
+    done = 0
+    for window, nsw in ((0, 2), (128, 1), (512, 1)):
+        g.set_sequential_engine(2, window)
+        st = pmc.mc_sweep(g, pm, nsweeps=nsw, mode="sequential")
+        att, acc = o.mc_steps(po, 21, 0, done, nsw * len(pos))
+        done += nsw * len(pos)
+        assert np.array_equal(st.attempted, att) and np.array_equal(st.accepted, acc), (form, window, st.accepted, acc)
+        _same_state(g, o, species=True)
+    # 2-D, one species, soft spheres, particles stored boxes away
+    from inputs import lj_lattice as lat
+    pos, sp, rho = lat(40, jitter=0.05, seed=4, rho=0.8, d=2)
+    pos = pos + np.random.default_rng(1).integers(-2, 3, size=pos.shape) * (len(pos) / rho) ** 0.5
+    g = pmc.System(pos, sp, rho, 0.7, pmc.SoftSpheres(1.0, 1.0, 12), seed=8)
+    o = O.System(pos, sp, rho, 0.7, O.single(O.soft_spheres(1.0, 1.0, 12)), O.LINKEDLIST)
+    g.set_sequential_engine(2, 0)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.1)], nsweeps=3, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.1}]), 8, 0, 0, 3 * len(pos))
+    assert np.array_equal(st.accepted, acc), (form, st.accepted, acc)
+    _same_state(g, o)
+
+
+def test_distance_rule_commits_more_steps_per_round(gpu, monkeypatch):
+    """What the distance-based conflict rule is for: on the N = 4096 LJ liquid a round of the cell rule commits ~8 steps (27 of 216
+    cells conflict), a round of the distance rule ~20 -- the same chain either way (`sequential_info`: rounds of the last call)."""
+    pmc = gpu
+    pos, sp, rho = lj_lattice(16, jitter=0.05, seed=42)
+    states, rounds = [], []
+    for rule in (None, "1"):
+        monkeypatch.delenv("PMC_SEQ_CELLRULE", raising=False)
+        if rule:
+            monkeypatch.setenv("PMC_SEQ_CELLRULE", rule)
+        g = pmc.System(pos, sp, rho, 1.0, pmc.LennardJones(1.0, 1.0), seed=42)
+        pmc.mc_sweep(g, [_disp(pmc, 0.05)], nsweeps=10, mode="checkerboard")
+        g.set_sequential_engine(2, 0)
+        pmc.mc_sweep(g, [_disp(pmc, 0.05)], nsweeps=6, mode="sequential")
+        states.append((g.position.copy(), g.energy[0]))
+        rounds.append(g.sequential_info()[0])
+    assert np.array_equal(states[0][0], states[1][0]) and states[0][1] == states[1][1]
+    per_round = [6 * 4096 / r for r in rounds]
+    assert per_round[0] > 14.0 and per_round[0] > 1.8 * per_round[1], per_round
