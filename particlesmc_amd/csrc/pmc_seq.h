@@ -9,14 +9,18 @@
 //     (Philox keyed by step), so it is known for any number of steps ahead (k_sq_gen).
 //  2. Step s reads only the 3^d neighbour cells of the cells its particle is in before and after the move, and writes
 //     only those one or two cells (position, cell membership, list order).  Two steps whose cells are more than one cell
-//     apart commute EXACTLY: same e1, e2, same accept decision, same list order, whatever the order they run in.
+//     apart commute EXACTLY: same e1, e2, same accept decision, same list order, whatever the order they run in -- and
+//     so do two Displacements that stay in their cells and whose particles cannot come within a cutoff of each other
+//     (round 5, sq_sequence: the term of a particle beyond the cutoff is 0 before and after, the sums skip zeros).
 //
-// A WINDOW of K pending steps is therefore evaluated at once, one wavefront per step, against the current state
-// (k_sq_round_a), a K x K bit matrix records which earlier pending steps a step could interact with (found through a
+// A WINDOW of K pending steps is therefore evaluated at once, SQ_EW wavefronts per step, against the current state
+// (sq_eval), a K x K bit matrix records which earlier pending steps a step could interact with (found through a
 // table of the pending steps by cell), and a step COMMITS in this round iff no earlier pending step that could interact
-// with it changes the state or is itself held back (k_sq_commit).  Steps that are held back stay in the window and are evaluated again
-// next round against the state that then exists; the window is refilled in step order (k_sq_fill).  The oldest pending
-// step never has a predecessor, so every round makes progress, and the result is the sequential chain's, bit for bit:
+// with it changes the state or is itself held back.  Steps that are held back stay in the window and are evaluated again
+// next round against the state that then exists; the window is refilled in step order (sq_fill_block).  The oldest pending
+// step never has a predecessor, so every round makes progress, and the result is the sequential chain's, bit for bit.
+// A round is ONE launch for windows of <= SQ_FUSED_KMAX steps (k_sq_round_fused: the workgroup that finishes its evaluation
+// last commits, admits and prepares), four launches beyond (k_sq_fill, k_sq_prep, k_sq_round_a, k_sq_commit).
 //
 //   * e1 / e2 are FP64 sums in LinkedIterator order (src/neighbours.jl:332-377).  Terms that are exactly 0 (the self term,
 //     pairs beyond their cutoff: src/atoms.jl:68,72) do not change a running FP64 sum, so only the non-zero terms are
@@ -175,29 +179,6 @@ __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, 
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int D>
-__device__ __forceinline__ void sq_cell_coords(const RefArgs &a, int c, int out[3])
-{
-    out[0] = out[1] = out[2] = 0;
-#pragma unroll
-    for (int q = D - 1; q >= 0; q--) {          // last dimension fastest (src/neighbours.jl:79-88)
-        out[q] = c % a.nc[q];
-        c /= a.nc[q];
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void sq_pack_cells(const RefArgs &a, int c0, int c1, int pk[4])
-{
-    int u[3], v[3];
-    sq_cell_coords<D>(a, c0, u);
-    sq_cell_coords<D>(a, c1, v);
-    pk[0] = u[0] | (u[1] << 16);
-    pk[1] = u[2] | (v[0] << 16);
-    pk[2] = v[1] | (v[2] << 16);
-    pk[3] = 1;
 }
 
 // vector_1D (src/utils.jl:15-18): dx - round(dx / L) L.  The quotient comes from a product with 1 / L; it can only round
