@@ -221,15 +221,14 @@ __device__ __forceinline__ int sq_cell_of(const RefArgs &a, const double *x)
 // boxes away, sq_cell_of decides.  (The three divisions and three 64-bit floor divisions of sq_cell_of were ~2 500 cycles of
 // every evaluation and ~5 000 of every admitted step's preparation.)
 template <int D>
-__device__ __forceinline__ int sq_cell_of_fast(const SqArgs &s, const double *x, int *coords = nullptr)
+__device__ __forceinline__ int sq_cell_of_fast(const RefArgs &a, const double *invcell, const double *x, int *coords = nullptr)
 {
-    const RefArgs &a = s.a;
     int c = 0, stride = 1;
     bool slow = false;
     int fcoord[3] = {0, 0, 0};
 #pragma unroll
     for (int q = D - 1; q >= 0; q--) {
-        const double qv = x[q] * s.invcell[q];
+        const double qv = x[q] * invcell[q];
         const double f = floor(qv);
         const double r = qv - f;
         const double tol = fabs(qv) * 0x1p-44 + 0x1p-60;
@@ -251,6 +250,12 @@ __device__ __forceinline__ int sq_cell_of_fast(const SqArgs &s, const double *x,
     }
     if (coords) { coords[0] = fcoord[0]; coords[1] = fcoord[1]; coords[2] = fcoord[2]; }
     return c;
+}
+
+template <int D>
+__device__ __forceinline__ int sq_cell_of_fast(const SqArgs &s, const double *x, int *coords = nullptr)
+{
+    return sq_cell_of_fast<D>(s.a, s.invcell, x, coords);
 }
 
 // inclusive prefix sum over lanes 0 .. 31 (DPP shifts inside the rows of 16, the first row's total added to the second)
@@ -1524,6 +1529,7 @@ struct SqChain {             // per-chain arguments (device table)
 struct SqLdsArgs {
     RefArgs a;               // geometry, models, neighbour-cell table, cl_cap (pointers to chain state unused: see SqChain)
     double invbox[3];
+    double invcell[3];       // 1 / a.cell (sq_cell_of_fast)
     SqChain *chains;
     MovePool pool;
     long long nsteps;
@@ -1531,7 +1537,7 @@ struct SqLdsArgs {
     int ncell;
     int empty;               // EmptyList (src/neighbours.jl:13-44): every particle is a neighbour, j in 1:N; no cells, no rows
     // byte offsets of the arrays inside the dynamic LDS block
-    int o_rows, o_ccount, o_cs, o_spids, o_spheads, o_species, o_seq, o_gen, o_nbr, o_nbrcnt, o_spoff, o_terms, o_tmask, o_esum;
+    int o_rows, o_ccount, o_cs, o_spids, o_spheads, o_species, o_seq, o_gen, o_nbr, o_nbrcnt, o_spoff, o_terms, o_tmask, o_esum, o_models;
     int nbr_in_lds;
     int max_trips;           // trips of 64 candidates a neighbourhood can have (3^d rows of cl_cap ids)
     int dbg;                 // PMC_SEQ_DBG, timing experiments only (results invalid): 1 no cell of the trial position, 2 no ordered sums, 4 no pair terms, 8 no sequence
@@ -1553,6 +1559,7 @@ struct SqLdsView {
     double *terms;               // the non-zero pair terms of the two sums of a pass, packed in iterator order (sq_terms_push)
     int *tcount;                 // NW > 1: [2][trips] terms per trip
     double *esum;                // [4]: results of the ordered sums
+    const DevModel *models;      // the S x S pair models, copied into LDS (a pair term's two dependent loads of its model were L1 round trips)
 };
 
 // NW wavefronts per chain: team helpers (NW == 1: no barrier instructions beyond the wave's own)
@@ -1633,11 +1640,11 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
 #pragma unroll
                 for (int q = 0; q < D; q++) xj[q] = v.pos[j * D + q];
                 const int sj = (S > 1) ? (int)v.species[j] : 0;
-                const DevModel &ma = s.a.models[spa * S + sj];
+                const DevModel &ma = v.models[spa * S + sj];
                 const double r2a = sql_dist2<D>(s, xa, xj);
                 if (!(r2a > ma.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2a, ma) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, ma));
                 if (BOTH) {
-                    const DevModel &mb = s.a.models[spb * S + (j == other ? sp_other : sj)];
+                    const DevModel &mb = v.models[spb * S + (j == other ? sp_other : sj)];
                     const double r2b = sql_dist2<D>(s, xb, xj);
                     if (!(r2b > mb.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2b, mb) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2b, mb));
                 }
@@ -1745,6 +1752,14 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
     v.terms = reinterpret_cast<double *>(sql_smem + s.o_terms);
     v.tcount = reinterpret_cast<int *>(sql_smem + s.o_tmask);
     v.esum = reinterpret_cast<double *>(sql_smem + s.o_esum);
+    {
+        DevModel *lm = reinterpret_cast<DevModel *>(sql_smem + s.o_models);
+        static_assert(sizeof(DevModel) % sizeof(int) == 0, "DevModel is copied word by word");
+        const int *src = reinterpret_cast<const int *>(a.models);
+        int *dst = reinterpret_cast<int *>(lm);
+        for (int k = tid; k < S * S * (int)(sizeof(DevModel) / sizeof(int)); k += nth) dst[k] = src[k];
+        v.models = lm;
+    }
     if (s.nbr_in_lds) {
         int *lnbr = reinterpret_cast<int *>(sql_smem + s.o_nbr), *lcnt = reinterpret_cast<int *>(sql_smem + s.o_nbrcnt);
         for (int k = tid; k < s.ncell * a.nnmax; k += nth) lnbr[k] = a.nbr[k];
@@ -1812,7 +1827,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                     xr[q] = xn[q] + (-ge.d[q]);
                 }
                 const int c0 = s.empty ? 0 : (int)v.cs[i];    // the list is current: cs[i] is the cell of x_i
-                const int c1 = (s.empty || (s.dbg & 1)) ? c0 : sq_cell_of<D>(a, xn);
+                const int c1 = (s.empty || (s.dbg & 1)) ? c0 : sq_cell_of_fast<D>(a, s.invcell, xn);
                 const int spi = (S > 1) ? (int)v.species[i] : 0;
                 double e1, e2, dummy;
                 if (c1 == c0) {
@@ -1833,7 +1848,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
 #pragma unroll
                     for (int q = 0; q < D; q++) chg |= sq_bits_differ(xr[q], x[q]);
                     if (chg && tid < D) v.pos[i * D + tid] = xr[tid];
-                    const int c2 = (chg && !s.empty) ? sq_cell_of<D>(a, xr) : c0;
+                    const int c2 = (chg && !s.empty) ? sq_cell_of_fast<D>(a, s.invcell, xr) : c0;
                     if (c1 != c0) sql_row_move<NW>(s, v, c0, c1, i);
                     if (c2 != c1) sql_row_move<NW>(s, v, c1, c2, i);
                 }

@@ -677,6 +677,7 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw 
     const size_t o_terms = o;     o = seq_align(o + (nw > 1 ? 2 * trips * (64 + SQ_TERMS_PAD) : 2 * (size_t)(SQ_TERMS + 64 + SQ_TERMS_PAD)) * sizeof(double), 16);
     const size_t o_tmask = o;     if (nw > 1) o = seq_align(o + 2 * trips * sizeof(int), 16);
     const size_t o_esum = o;      o = seq_align(o + 4 * sizeof(double), 16);
+    const size_t o_models = o;    o = seq_align(o + (size_t)h->S * h->S * sizeof(DevModel), 16);
     const size_t o_spoff = o;     o = seq_align(o + 16 * sizeof(int), 16);
     const bool nbr_in = !empty && nc * nn * 4 <= 16384;
     const size_t o_nbr = o;       if (nbr_in) o = seq_align(o + nc * nn * 4, 16);
@@ -685,7 +686,7 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw 
         s->o_rows = (int)o_rows; s->o_ccount = (int)o_ccount; s->o_cs = (int)o_cs; s->o_spids = (int)o_spids;
         s->o_spheads = (int)o_spheads; s->o_species = (int)o_species; s->o_seq = (int)o_seq; s->o_gen = (int)o_gen;
         s->o_spoff = (int)o_spoff; s->o_nbr = (int)o_nbr; s->o_nbrcnt = (int)o_nbrcnt; s->nbr_in_lds = nbr_in ? 1 : 0;
-        s->o_terms = (int)o_terms; s->o_tmask = (int)o_tmask; s->o_esum = (int)o_esum; s->max_trips = (int)trips;
+        s->o_terms = (int)o_terms; s->o_tmask = (int)o_tmask; s->o_esum = (int)o_esum; s->o_models = (int)o_models; s->max_trips = (int)trips;
     }
     return o;
 }
@@ -750,7 +751,7 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     SqLdsArgs s;
     memset(&s, 0, sizeof s);
     s.a = ref_args(m);
-    for (int q = 0; q < 3; q++) s.invbox[q] = 1.0 / s.a.box[q];
+    for (int q = 0; q < 3; q++) { s.invbox[q] = 1.0 / s.a.box[q]; s.invcell[q] = (q < m->D && m->list_type != 0) ? 1.0 / s.a.cell[q] : 1.0; }
     s.pool = make_pool(pool, npool);
     s.reverse = (m->list_type == 1) ? 1 : 0;
     s.ncell = m->ncell_ref;
