@@ -1536,6 +1536,7 @@ struct SqLdsArgs {
     int reverse;
     int ncell;
     int empty;               // EmptyList (src/neighbours.jl:13-44): every particle is a neighbour, j in 1:N; no cells, no rows
+    int pos_global;          // an EmptyList system too large for the LDS: everything but the positions is in LDS, the positions stay in global memory
     // byte offsets of the arrays inside the dynamic LDS block
     int o_rows, o_ccount, o_cs, o_spids, o_spheads, o_species, o_seq, o_gen, o_nbr, o_nbrcnt, o_spoff, o_terms, o_tmask, o_esum, o_models;
     int nbr_in_lds;
@@ -1550,7 +1551,8 @@ struct SqLdsArgs {
 #endif
 
 struct SqLdsView {
-    double *pos;
+    double *pos;                 // positions in LDS ...
+    double *gpos;                // ... or, for the PG instances (SqLdsArgs::pos_global), in global memory
     unsigned short *rows, *ccount, *cs, *spids, *spheads, *seq;
     unsigned char *species;
     SqGen *gen;
@@ -1616,11 +1618,15 @@ __device__ __forceinline__ double sql_dist2(const SqLdsArgs &s, const double *xi
 // the NW wavefronts; the two sums are then taken in iterator order by wavefront 0 (ea) and wavefront 1 (eb).
 // KIND: the kind every pair model of the system has (the potential is then compiled in: the kernel of a Lennard-Jones or an
 // integer-power soft-sphere system carries no other potential), or 4: read from the model, pair by pair.
-template <int D, bool BOTH, int NW, int KIND = 4>
+#define SQL_TRGO 16              // NW > 1: trips whose packed terms the LDS holds at once (a pass of more trips runs in several goes)
+
+// (PG: the positions are in global memory -- a compile-time choice, so that the LDS instances keep their ds_read accesses)
+template <int D, bool BOTH, int NW, int KIND = 4, bool PG = false>
 __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v, int c, int i, int spa, int spb, int other, int sp_other,
                                          const double *xa, const double *xb, double &ea, double &eb)
 {
     const int lane = wave_lane(), wv = sql_wave<NW>();
+    const double *const P = PG ? v.gpos : v.pos;
     const int S = s.a.S;
     const int total = s.empty ? s.a.N : ((s.dbg & 8) ? 216 : sql_sequence<D, NW>(s, v, c));
     if (s.empty && NW > 1) __syncthreads();                        // (the barrier sql_sequence ends with: the previous pass has read its terms)
@@ -1628,57 +1634,129 @@ __device__ __forceinline__ void sql_pass(const SqLdsArgs &s, const SqLdsView &v,
     constexpr int SEG = PMC_WAVE + SQ_TERMS_PAD;                  // NW > 1: one segment of packed terms per trip and sum
     constexpr int BUF = SQ_TERMS + PMC_WAVE + SQ_TERMS_PAD;      // NW == 1: one buffer per sum, summed down when nearly full
     double acc_a = 0.0, acc_b = 0.0;
-    int na = 0, nb = 0;
-    double *bufa = v.terms, *bufb = v.terms + (NW == 1 ? BUF : s.max_trips * SEG);
-    for (int tr = (NW == 1 ? 0 : wv); tr < ntrip; tr += NW) {
-        const int t = tr * PMC_WAVE + lane;
-        double ua = 0.0, ub = 0.0;
-        if (t < total && !(s.dbg & 4)) {
-            const int j = s.empty ? t : (int)v.seq[t];
-            if (j != i) {
-                double xj[3] = {0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < D; q++) xj[q] = v.pos[j * D + q];
-                const int sj = (S > 1) ? (int)v.species[j] : 0;
-                const DevModel &ma = v.models[spa * S + sj];
-                const double r2a = sql_dist2<D>(s, xa, xj);
-                if (!(r2a > ma.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2a, ma) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, ma));
-                if (BOTH) {
-                    const DevModel &mb = v.models[spb * S + (j == other ? sp_other : sj)];
-                    const double r2b = sql_dist2<D>(s, xb, xj);
-                    if (!(r2b > mb.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2b, mb) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2b, mb));
-                }
+    // one candidate's two terms
+    auto terms = [&](int t, int j, const double *xj, int sj, double &ua, double &ub) {
+        ua = 0.0; ub = 0.0;
+        if (t < total && !(s.dbg & 4) && j != i) {
+            const DevModel &ma = v.models[spa * S + sj];
+            const double r2a = sql_dist2<D>(s, xa, xj);
+            if (!(r2a > ma.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2a, ma) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, ma));
+            if (BOTH) {
+                const DevModel &mb = v.models[spb * S + (j == other ? sp_other : sj)];
+                const double r2b = sql_dist2<D>(s, xb, xj);
+                if (!(r2b > mb.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2b, mb) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2b, mb));
             }
         }
-        if (s.dbg & 2) continue;
-        if (NW == 1) {
+    };
+    if constexpr (NW == 1) {
+        int na = 0, nb = 0;
+        double *bufa = v.terms, *bufb = v.terms + BUF;
+        for (int tr = 0; tr < ntrip; tr++) {
+            const int t = tr * PMC_WAVE + lane;
+            const int j = (t < total) ? (s.empty ? t : (int)v.seq[t]) : 0;
+            double xj[3] = {0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < D; q++) xj[q] = P[j * D + q];
+            const int sj = (S > 1) ? (int)v.species[j] : 0;
+            double ua, ub;
+            terms(t, j, xj, sj, ua, ub);
+            if (s.dbg & 2) continue;
             if (na > SQ_TERMS || nb > SQ_TERMS) {                // the next 64 terms might not fit: sum down, in order
                 sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
                 na = nb = 0;
             }
             sq_terms_push(bufa, na, ua);
             if (BOTH) sq_terms_push(bufb, nb, ub);
-        } else {
-            const int ca = sq_terms_push_seg(bufa + tr * SEG, ua);      // (eight zeros behind the terms: the chain reads whole blocks)
-            int cb = 0;
-            if (BOTH) cb = sq_terms_push_seg(bufb + tr * SEG, ub);
-            if (lane == 0) { v.tcount[tr] = ca; if (BOTH) v.tcount[s.max_trips + tr] = cb; }
         }
-    }
-    if (NW == 1) {
         if (!(s.dbg & 2)) sq_terms_sum2(bufa, na, acc_a, bufb, nb, acc_b);
     } else {
-        __syncthreads();
-        if ((wv == 0 || (BOTH && wv == 1)) && !(s.dbg & 2)) {
-            double *seg = wv == 0 ? bufa : bufb;
-            double acc = 0.0;
-            if (ntrip <= PMC_WAVE) {                                  // one straight chain, the next segment's block in flight (sq_terms_chain)
-                acc = sq_terms_chain(seg, v.tcount + wv * s.max_trips, ntrip, acc);
-            } else {
-                for (int tr = 0; tr < ntrip; tr++) acc = sq_terms_sum(seg + tr * SEG, v.tcount[wv * s.max_trips + tr], acc);
+        // the trips in goes of SQL_TRGO, dealt round-robin; a wavefront's trips of a go have their loads in flight together (the
+        // positions of a large EmptyList system come from global memory: SqLdsArgs::pos_global); every trip packs its non-zero
+        // terms into its segment; wavefront 0 then adds the first sum's segments in order, wavefront 1 the second's
+        static_assert(SQL_TRGO % NW == 0, "the trips of a go are dealt evenly");
+        constexpr int PER = SQL_TRGO / NW;
+        const int gtr = PG ? SQL_TRGO : s.max_trips;              // segments in LDS (seq_lds_layout)
+        double *bufa = v.terms, *bufb = v.terms + gtr * SEG;
+        double acc = 0.0;
+        if constexpr (!PG) {
+            // state in LDS: one trip after the other per wavefront, a segment for every trip the neighbourhood can have
+            // (measured: the goes below, compiled into these instances, cost chains of N = 216 9-17 %)
+            for (int tr = wv; tr < ntrip; tr += NW) {
+                const int t = tr * PMC_WAVE + lane;
+                double ua = 0.0, ub = 0.0;
+                if (t < total && !(s.dbg & 4)) {
+                    const int j1 = s.empty ? t : (int)v.seq[t];
+                    if (j1 != i) {
+                        double x1[3] = {0, 0, 0};
+#pragma unroll
+                        for (int q = 0; q < D; q++) x1[q] = P[j1 * D + q];
+                        const int s1 = (S > 1) ? (int)v.species[j1] : 0;
+                        const DevModel &ma = v.models[spa * S + s1];
+                        const double r2a = sql_dist2<D>(s, xa, x1);
+                        if (!(r2a > ma.rcut2)) ua = (KIND == 4 ? dev_potential_dyn(r2a, ma) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2a, ma));
+                        if (BOTH) {
+                            const DevModel &mb = v.models[spb * S + (j1 == other ? sp_other : s1)];
+                            const double r2b = sql_dist2<D>(s, xb, x1);
+                            if (!(r2b > mb.rcut2)) ub = (KIND == 4 ? dev_potential_dyn(r2b, mb) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2b, mb));
+                        }
+                    }
+                }
+                const int ca = sq_terms_push_seg(bufa + tr * SEG, ua);
+                int cb = 0;
+                if (BOTH) cb = sq_terms_push_seg(bufb + tr * SEG, ub);
+                if (lane == 0) { v.tcount[tr] = ca; v.tcount[gtr + tr] = cb; }
             }
-            if (lane == 0) v.esum[wv] = acc;
+            __syncthreads();
+            if ((wv == 0 || (BOTH && wv == 1)) && !(s.dbg & 2)) {
+                double *seg = wv == 0 ? bufa : bufb;
+                if (ntrip <= PMC_WAVE) {                              // one straight chain, the next segment's block in flight (sq_terms_chain)
+                    acc = sq_terms_chain(seg, v.tcount + wv * gtr, ntrip, acc);
+                } else {
+                    for (int tr = 0; tr < ntrip; tr++) acc = sq_terms_sum(seg + tr * SEG, v.tcount[wv * gtr + tr], acc);
+                }
+            }
+        } else
+        for (int tr0 = 0; tr0 < ntrip; tr0 += SQL_TRGO) {
+            int j[PER], sj[PER];
+            double xj[PER][3];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int t = (tr0 + wv + u * NW) * PMC_WAVE + lane;
+                j[u] = 0;
+                if (tr0 + wv + u * NW < ntrip) j[u] = (t < total) ? (s.empty ? t : (int)v.seq[t]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                xj[u][0] = xj[u][1] = xj[u][2] = 0.0;
+                sj[u] = 0;
+                if (tr0 + wv + u * NW < ntrip) {                    // (a wavefront without a u-th trip in this go loads nothing for it)
+#pragma unroll
+                    for (int q = 0; q < D; q++) xj[u][q] = P[j[u] * D + q];
+                    if (S > 1) sj[u] = (int)v.species[j[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int tr = tr0 + wv + u * NW;
+                if (tr >= ntrip) break;
+                double ua, ub;
+                terms(tr * PMC_WAVE + lane, j[u], xj[u], sj[u], ua, ub);
+                const int sg = tr - tr0;
+                const int ca = sq_terms_push_seg(bufa + sg * SEG, ua);  // (eight zeros behind the terms: the chain reads whole blocks)
+                int cb = 0;
+                if (BOTH) cb = sq_terms_push_seg(bufb + sg * SEG, ub);
+                if (lane == 0) { v.tcount[sg] = ca; v.tcount[gtr + sg] = cb; }
+            }
+            __syncthreads();
+            const int nt = min(SQL_TRGO, ntrip - tr0);
+            if (!(s.dbg & 2)) {
+                if (wv == 0) acc = sq_terms_chain(bufa, v.tcount, nt, acc);
+                else if (BOTH && wv == 1) acc = sq_terms_chain(bufb, v.tcount + gtr, nt, acc);
+            }
+            if (tr0 + SQL_TRGO < ntrip) __syncthreads();            // (the segments are free for the next go)
         }
+        if (lane == 0 && wv == 0) v.esum[0] = acc;
+        if (lane == 0 && wv == 1) v.esum[1] = BOTH ? acc : 0.0;
         __syncthreads();
         acc_a = v.esum[0];
         if (BOTH) acc_b = v.esum[1];
@@ -1730,7 +1808,7 @@ __device__ __forceinline__ void sql_row_move(const SqLdsArgs &s, const SqLdsView
     __syncthreads();
 }
 
-template <int D, int NW, int KIND = 4>
+template <int D, int NW, int KIND = 4, bool PG = false>
 __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sql_smem[];
@@ -1740,6 +1818,8 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
     const int N = a.N, S = a.S, cap = a.cl_cap;
     SqLdsView v;
     v.pos = reinterpret_cast<double *>(sql_smem);
+    v.gpos = ch.pos;
+    double *const P = PG ? v.gpos : v.pos;
     v.rows = reinterpret_cast<unsigned short *>(sql_smem + s.o_rows);
     v.ccount = reinterpret_cast<unsigned short *>(sql_smem + s.o_ccount);
     v.cs = reinterpret_cast<unsigned short *>(sql_smem + s.o_cs);
@@ -1769,7 +1849,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
         v.nbr = a.nbr; v.nbrcnt = a.nbrcnt;
     }
     // -- the chain's state into LDS
-    for (int k = tid; k < N * D; k += nth) v.pos[k] = ch.pos[k];
+    if (!PG) for (int k = tid; k < N * D; k += nth) v.pos[k] = ch.pos[k];
     for (int k = tid; k < N; k += nth) {
         v.species[k] = (unsigned char)ch.species[k];
         v.cs[k] = (unsigned short)ch.cs[k];
@@ -1822,7 +1902,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                 double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0}, xr[3] = {0, 0, 0};
 #pragma unroll
                 for (int q = 0; q < D; q++) {
-                    x[q] = v.pos[i * D + q];
+                    x[q] = P[i * D + q];
                     xn[q] = x[q] + ge.d[q];
                     xr[q] = xn[q] + (-ge.d[q]);
                 }
@@ -1831,23 +1911,23 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                 const int spi = (S > 1) ? (int)v.species[i] : 0;
                 double e1, e2, dummy;
                 if (c1 == c0) {
-                    sql_pass<D, true, NW, KIND>(s, v, c0, i, spi, spi, -1, 0, x, xn, e1, e2);
+                    sql_pass<D, true, NW, KIND, PG>(s, v, c0, i, spi, spi, -1, 0, x, xn, e1, e2);
                 } else {
-                    sql_pass<D, false, NW, KIND>(s, v, c0, i, spi, spi, -1, 0, x, x, e1, dummy);
-                    sql_pass<D, false, NW, KIND>(s, v, c1, i, spi, spi, -1, 0, xn, xn, e2, dummy);
+                    sql_pass<D, false, NW, KIND, PG>(s, v, c0, i, spi, spi, -1, 0, x, x, e1, dummy);
+                    sql_pass<D, false, NW, KIND, PG>(s, v, c1, i, spi, spi, -1, 0, xn, xn, e2, dummy);
                 }
                 double de = 0.0;
                 if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }           // src/moves.jl:13-18
                 ok = ge.lnu < -(e2 - e1) / T;
                 if (ok) {
-                    if (tid < D) v.pos[i * D + tid] = xn[tid];
+                    if (tid < D) P[i * D + tid] = xn[tid];
                     if (c1 != c0) sql_row_move<NW>(s, v, c0, c1, i);
                 } else {
                     E -= de;                                                         // src/moves.jl:79
                     bool chg = false;
 #pragma unroll
                     for (int q = 0; q < D; q++) chg |= sq_bits_differ(xr[q], x[q]);
-                    if (chg && tid < D) v.pos[i * D + tid] = xr[tid];
+                    if (chg && tid < D) P[i * D + tid] = xr[tid];
                     const int c2 = (chg && !s.empty) ? sq_cell_of_fast<D>(a, s.invcell, xr) : c0;
                     if (c1 != c0) sql_row_move<NW>(s, v, c0, c1, i);
                     if (c2 != c1) sql_row_move<NW>(s, v, c1, c2, i);
@@ -1861,11 +1941,11 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
                     const int j = v.spids[v.spoff[sb] + mulhi32(ge.q0, (uint32_t)nb)];
                     double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
 #pragma unroll
-                    for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
+                    for (int q = 0; q < D; q++) { xi[q] = P[i * D + q]; xj[q] = P[j * D + q]; }
                     const int spi = v.species[i], spj = v.species[j];
                     double e1i, e2i, e1j, e2j;
-                    sql_pass<D, true, NW, KIND>(s, v, s.empty ? 0 : (int)v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
-                    sql_pass<D, true, NW, KIND>(s, v, s.empty ? 0 : (int)v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
+                    sql_pass<D, true, NW, KIND, PG>(s, v, s.empty ? 0 : (int)v.cs[i], i, spi, spj, j, spi, xi, xi, e1i, e2i);
+                    sql_pass<D, true, NW, KIND, PG>(s, v, s.empty ? 0 : (int)v.cs[j], j, spj, spi, i, spj, xj, xj, e1j, e2j);
                     const double e1 = e1i + e1j, e2 = e2i + e2j;
                     double de = 0.0;
                     if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
@@ -1896,7 +1976,7 @@ __global__ __launch_bounds__(NW * 64) void k_sq_lds(SqLdsArgs s)
     }
     // -- back to global memory: positions, species, SpeciesList, rows, cs, ccount, and head / list rebuilt from the rows
     __syncthreads();
-    for (int k = tid; k < N * D; k += nth) ch.pos[k] = v.pos[k];
+    if (!PG) for (int k = tid; k < N * D; k += nth) ch.pos[k] = v.pos[k];
     for (int k = tid; k < N; k += nth) {
         ch.species[k] = v.species[k];
         ch.cs[k] = v.cs[k];

@@ -664,7 +664,11 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw 
     const bool empty = h->list_type == 0;                       // EmptyList: no cells, no rows; the neighbours are 1:N
     const size_t N = (size_t)h->N, nc = empty ? 1 : (size_t)h->ncell_ref, nn = empty ? 1 : (size_t)h->nn;
     if (empty) cap = 1;
-    size_t o = seq_align(N * h->D * sizeof(double), 16);
+    // an EmptyList system whose positions alone outgrow the LDS keeps them in global memory (everything else -- species, the
+    // SpeciesList, the random parts, the ordered sums' segments -- is in LDS): the all-pairs chain of 10^4 particles on four
+    // wavefronts instead of the literal loop's one
+    const bool pos_global = empty && N * h->D * sizeof(double) > 96 * 1024;
+    size_t o = pos_global ? 0 : seq_align(N * h->D * sizeof(double), 16);
     const size_t o_rows = o;      o = seq_align(o + nc * cap * 2, 16);
     const size_t o_ccount = o;    o = seq_align(o + nc * 2, 16);
     const size_t o_cs = o;        o = seq_align(o + N * 2, 16);
@@ -674,8 +678,9 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw 
     const size_t o_seq = o;       o = seq_align(o + nn * cap * 2, 16);
     const size_t o_gen = o;       o = seq_align(o + (size_t)nw * 64 * sizeof(SqGen), 16);
     const size_t trips = empty ? (N + 63) / 64 : (nn * cap + 63) / 64;
-    const size_t o_terms = o;     o = seq_align(o + (nw > 1 ? 2 * trips * (64 + SQ_TERMS_PAD) : 2 * (size_t)(SQ_TERMS + 64 + SQ_TERMS_PAD)) * sizeof(double), 16);
-    const size_t o_tmask = o;     if (nw > 1) o = seq_align(o + 2 * trips * sizeof(int), 16);
+    const size_t gtr = pos_global ? (size_t)SQL_TRGO : trips;    // NW > 1: a segment per trip; positions in global memory: per trip of one go (sql_pass)
+    const size_t o_terms = o;     o = seq_align(o + (nw > 1 ? 2 * gtr * (64 + SQ_TERMS_PAD) : 2 * (size_t)(SQ_TERMS + 64 + SQ_TERMS_PAD)) * sizeof(double), 16);
+    const size_t o_tmask = o;     if (nw > 1) o = seq_align(o + 2 * gtr * sizeof(int), 16);
     const size_t o_esum = o;      o = seq_align(o + 4 * sizeof(double), 16);
     const size_t o_models = o;    o = seq_align(o + (size_t)h->S * h->S * sizeof(DevModel), 16);
     const size_t o_spoff = o;     o = seq_align(o + 16 * sizeof(int), 16);
@@ -687,6 +692,7 @@ static size_t seq_lds_layout(const pmc_system *h, int cap, SqLdsArgs *s, int nw 
         s->o_spheads = (int)o_spheads; s->o_species = (int)o_species; s->o_seq = (int)o_seq; s->o_gen = (int)o_gen;
         s->o_spoff = (int)o_spoff; s->o_nbr = (int)o_nbr; s->o_nbrcnt = (int)o_nbrcnt; s->nbr_in_lds = nbr_in ? 1 : 0;
         s->o_terms = (int)o_terms; s->o_tmask = (int)o_tmask; s->o_esum = (int)o_esum; s->o_models = (int)o_models; s->max_trips = (int)trips;
+        s->pos_global = pos_global ? 1 : 0;
     }
     return o;
 }
@@ -699,6 +705,7 @@ static bool seq_lds_fits(const pmc_system *h, size_t limit)
     if (h->N > 65535 || h->S > 8) return false;
     if (h->list_type == 3) return false;                        // VerletList: its own update rule (engine 1)
     const int cap = h->d_cl_items ? h->cl_cap : seq_rows_cap(h);
+    if (h->list_type == 0 && seq_lds_layout(h, cap, nullptr, 4) <= SQ_LDS_MAX) return true;     // (EmptyList has no other fast engine: the whole LDS, positions in global memory if need be)
     return seq_lds_layout(h, cap, nullptr) <= limit;
 }
 
@@ -763,6 +770,9 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     // 4.3 / 7.3 / 7.2 / 7.3, one 3.2 / 6.1 / 11.6 / 11.9 -- a team's ceiling falls with its width)
     int nw = (n <= 320) ? 4 : (n <= 608 ? 2 : 1);
     if (const char *e = getenv("PMC_SEQ_WAVES")) { nw = atoi(e); if (nw != 4 && nw != 2) nw = 1; }
+    SqLdsArgs probe;
+    (void)seq_lds_layout(m, cap, &probe, 4);
+    if (probe.pos_global) nw = 4;                            // (positions in global memory: the four-wavefront instance is the only one)
     if (nw > 1 && seq_lds_layout(m, cap, nullptr, nw) > SQ_LDS_MAX) nw = 1;
     const size_t lds = seq_lds_layout(m, cap, &s, nw);
     if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: the chain's state does not fit the LDS");
@@ -776,6 +786,9 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     if (m->D == 3) kfn = (nw == 4) ? SQ_LDS_PICK(3, 4) : (nw == 2) ? SQ_LDS_PICK(3, 2) : SQ_LDS_PICK(3, 1);
     else kfn = (nw == 4) ? SQ_LDS_PICK(2, 4) : (nw == 2) ? SQ_LDS_PICK(2, 2) : SQ_LDS_PICK(2, 1);
 #undef SQ_LDS_PICK
+    if (s.pos_global) {                                     // positions in global memory: the general-potential instance on four wavefronts
+        kfn = (m->D == 3) ? (const void *)k_sq_lds<3, 4, 4, true> : (const void *)k_sq_lds<2, 4, 4, true>;
+    }
     HIPCHK(m, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<SqChain> tab((size_t)n);
     for (int r = 0; r < n; r++) {

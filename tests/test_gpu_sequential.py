@@ -486,3 +486,29 @@ def test_distance_rule_commits_more_steps_per_round(gpu, monkeypatch):
     assert np.array_equal(states[0][0], states[1][0]) and states[0][1] == states[1][1]
     per_round = [6 * 4096 / r for r in rounds]
     assert per_round[0] > 14.0 and per_round[0] > 1.8 * per_round[1], per_round
+
+
+def test_empty_list_beyond_the_lds_runs_with_positions_in_global_memory(gpu):
+    """An EmptyList system whose positions alone outgrow the LDS (N = 4913: 118 KB) used to fall to the literal one-wavefront loop
+    (146 us per step at N = 10 648, 2.6 x slower than one host core).  Round 5: engine 3 keeps everything but the positions in
+    LDS and runs the all-pairs sums on four wavefronts, the trips in goes (k_sq_lds<.., PG>): the oracle's chain, bit for bit --
+    a Kob-Andersen mixture with swaps, two calls, the second through pmc_sweep_many with a second chain."""
+    from oracle import oracle as O
+    pmc = gpu
+    pos, sp, rho = binary_lattice(4913, frac_b=0.2, rho=1.2, jitter=0.05, seed=3)
+    nA, nB = int((sp == 1).sum()), int((sp == 2).sum())
+    pm = [_disp(pmc, 0.08, 0.8), _swap(pmc, (1, 2), (nA, nB), 0.2)]
+    po = O.make_pool([{"kind": "Displacement", "sigma": 0.08, "probability": 0.8}, {"kind": "DiscreteSwap", "species": (1, 2), "probability": 0.2}])
+    gs = [pmc.System(pos, sp, rho, 1.0, pmc.KobAndersen(), list_type=pmc.EmptyList, seed=5, chain=k) for k in range(2)]
+    os_ = [O.System(pos, sp, rho, 1.0, O.kob_andersen(), O.EMPTYLIST) for _ in range(2)]
+    st = pmc.mc_sweep(gs[0], pm, nsweeps=1, mode="sequential")
+    att, acc = os_[0].mc_steps(po, 5, 0, 0, 4913)
+    assert np.array_equal(st.accepted, acc), (st.accepted, acc)
+    sts = pmc.mc_sweep_many(gs, pm, nsweeps=1, mode="sequential")
+    for k, (g, o) in enumerate(zip(gs, os_)):
+        att, acc = o.mc_steps(po, 5, k, 4913 if k == 0 else 0, 4913)
+        assert np.array_equal(sts[k].accepted, acc), (k, sts[k].accepted, acc)
+        assert np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy, k
+        assert np.array_equal(g.species, o.species())
+        for s_ in (1, 2):
+            assert np.array_equal(g.species_ids(s_), o.species_ids(s_)), (k, s_)
