@@ -235,9 +235,9 @@ int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
  * system (positions, species, cell rows, SpeciesList: up to 160 KB) lives in LDS and one wavefront walks the chain with no
  * global-memory traffic; pmc_sweep_many runs any number of such chains of one shape in one launch (the reference's own
  * workloads: benchmark/particles_benchmarks.jl:10-28, N = 216; test/ss142d.jl:8-21, 100 chains of N = 8).  engine 0 (default):
- * 3 for LinkedList / CellList / EmptyList systems of at most 7 cells per side (EmptyList: any) whose state fits 64 KB of LDS,
- * else 2 for LinkedList / CellList; 1 for VerletList, for EmptyList systems too large for the LDS and for swap moves between a
- * species and itself.  window: pending steps per round of engine 2 (0: chosen from the cell
+ * 3 for LinkedList / CellList systems of at most 7 cells per side whose state fits 64 KB of LDS and for EmptyList systems of up
+ * to ~17 000 particles (beyond 4096 in 3-D their positions stay in global memory, everything else in LDS), else 2 for
+ * LinkedList / CellList; 1 for VerletList, for still larger EmptyList systems and for swap moves between a species and itself.  window: pending steps per round of engine 2 (0: chosen from the cell
  * count; at most 4096). */
 int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window);
 /* diagnostics of the last PMC_SEQUENTIAL call that ran engine 2: out[0] rounds, out[1] step evaluations, out[2] window,
