@@ -715,6 +715,21 @@ def other_configs(pmc, budget_cpu_s=1.2):
                  "cpu_oracle_moves_per_s": cpu, "cpu_oracle_us_per_step": 1e6 / cpu,
                  "reference_published": {"us_per_mc_step": 5.114, "us_per_step_in_mc_sweep": 1737.0 / 216, "hardware": "not stated (source comment)",
                                          "source": "benchmark/particles_benchmarks.jl:28-29"}})
+    del chains
+    # -- an EmptyList system too large for the LDS (the benchmark's list type at 50 x its size): all pairs in id order per step;
+    #    engine 3 with the positions in global memory (round 5; the literal loop took 146 us per step)
+    posl, spl, rhol = lj_lattice(22, jitter=0.05, seed=3)
+    big = pmc.System(posl, spl, rhol, TEMPERATURE, pmc.LennardJones(1.0, 1.0), list_type=pmc.EmptyList, seed=5)
+    t0 = time.perf_counter()
+    stl = pmc.mc_sweep(big, [disp()], nsweeps=1, mode="sequential")
+    dtl = time.perf_counter() - t0
+    cpul = _oracle_rate(lambda: O.System(posl, spl, rhol, TEMPERATURE, O.single(O.lennard_jones(1.0, 1.0)), O.EMPTYLIST),
+                        O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}]), 5, min(budget_cpu_s, 1.0))
+    rows.append({"config": "EmptyList beyond the LDS: N=10648 3D LJ rho=1 T=1, all pairs in id order every step (src/neighbours.jl:13-44); the reference's "
+                           "sequential chain, positions in global memory, everything else in LDS, four wavefronts",
+                 "reference_order_chain": {"us_per_step_one_chain": 1e6 * dtl / len(posl), "moves_per_s_one_chain": len(posl) / dtl,
+                                           "acceptance": [float(stl.accepted[0]) / max(1.0, float(stl.attempted[0]))]},
+                 "cpu_oracle_moves_per_s": cpul, "cpu_oracle_us_per_step": 1e6 / cpul})
     return rows
 
 
