@@ -512,3 +512,24 @@ def test_empty_list_beyond_the_lds_runs_with_positions_in_global_memory(gpu):
         assert np.array_equal(g.species, o.species())
         for s_ in (1, 2):
             assert np.array_equal(g.species_ids(s_), o.species_ids(s_)), (k, s_)
+
+
+@pytest.mark.parametrize("d,n,model", [(2, 81, "soft"), (3, 18, "lj")])
+def test_empty_list_beyond_the_lds_other_instances(gpu, d, n, model):
+    """The 2-D instance of the positions-in-global-memory kernel (N = 6561 soft spheres, particles stored boxes away) and a 3-D
+    single-species Lennard-Jones system (N = 5832), one sweep each against the oracle."""
+    from oracle import oracle as O
+    from inputs import lj_lattice as lat
+    pmc = gpu
+    pos, sp, rho = lat(n, jitter=0.05, seed=9, rho=0.9, d=d)
+    N = len(pos)
+    if d == 2:
+        pos = pos + np.random.default_rng(2).integers(-1, 2, size=pos.shape) * (N / rho) ** 0.5
+    mg, mo = ((pmc.SoftSpheres(1.0, 1.0, 12), O.soft_spheres(1.0, 1.0, 12)) if model == "soft"
+              else (pmc.LennardJones(1.0, 1.0), O.lennard_jones(1.0, 1.0)))
+    g = pmc.System(pos, sp, rho, 0.8, mg, list_type=pmc.EmptyList, seed=13)
+    o = O.System(pos, sp, rho, 0.8, O.single(mo), O.EMPTYLIST)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.07)], nsweeps=1, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.07}]), 13, 0, 0, N)
+    assert np.array_equal(st.accepted, acc), (st.accepted, acc)
+    assert np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
