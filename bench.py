@@ -153,6 +153,31 @@ def _free_port():
     return p
 
 
+def _descendants(pid):
+    """Every live descendant of `pid`, from /proc/*/stat (field 4 = ppid; the command name in field 2 may contain spaces and
+    parentheses, so the line is split after its last ')')."""
+    parent = {}
+    try:
+        entries = os.listdir("/proc")
+    except OSError:
+        return []
+    for e in entries:
+        if not e.isdigit():
+            continue
+        try:
+            with open(f"/proc/{e}/stat") as f:
+                st = f.read()
+            parent[int(e)] = int(st[st.rindex(")") + 2:].split()[1])
+        except (OSError, ValueError, IndexError):
+            continue
+    out, front = [], [pid]
+    while front:
+        nxt = [c for c, pp in parent.items() if pp in front and c not in out]
+        out.extend(nxt)
+        front = nxt
+    return out
+
+
 def launch_ranks(ngpus, argv, timeout=None):
     """Start `ngpus` ranks of this script (one process per GPU) as CHILD processes and return their
     exit status.  Nothing in this (parent) process has touched the GPU: no torch import, no HIP call."""
@@ -171,23 +196,34 @@ def launch_ranks(ngpus, argv, timeout=None):
         return p.wait(timeout=timeout)
     except subprocess.TimeoutExpired:
         # exactly the processes this call started: the launcher, its process group, and the ranks it spawned (the elastic agent
-        # gives its workers sessions of their own, so the group alone would leave them -- and the caller's pipes -- alive)
-        kids = []
+        # gives its workers sessions of their own, so the group alone would leave them -- and the caller's pipes -- alive).
+        # The descendants are read from /proc (no optional package); the launcher gets SIGTERM and a short grace first, because
+        # the elastic agent tears its workers down itself on SIGTERM; whatever is left is killed
+        kids = _descendants(p.pid)
         try:
-            import psutil
-            kids = psutil.Process(p.pid).children(recursive=True)
-        except Exception:
+            os.killpg(p.pid, signal.SIGTERM)
+        except ProcessLookupError:
             pass
+        try:
+            p.wait(timeout=5.0)
+        except subprocess.TimeoutExpired:
+            pass
+        kids = sorted(set(kids) | set(_descendants(p.pid)))
         try:
             os.killpg(p.pid, signal.SIGKILL)
         except ProcessLookupError:
             pass
+        left = []
         for k in kids:
             try:
-                k.kill()
-            except Exception:
+                os.kill(k, signal.SIGKILL)
+            except ProcessLookupError:
                 pass
+            except Exception:
+                left.append(k)
         p.wait()
+        if left:
+            print(f"bench.py: could not signal {len(left)} descendant process(es) of the launcher: {left}", file=sys.stderr)
         print(f"bench.py: the {ngpus} ranks did not finish within {timeout:.0f} s: killed", file=sys.stderr)
         return 5
 

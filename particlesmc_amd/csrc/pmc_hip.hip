@@ -194,6 +194,15 @@ struct DevTmp {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// Declared AFTER the host vectors and device temporaries that asynchronous copies on `s` read or write: whichever way the function
+// is left -- an error return between the first copy and the function's own synchronize included -- the stream is drained before
+// those buffers are destroyed (destruction runs in reverse order of declaration).  On the normal path the stream is already idle.
+struct StreamDrain {
+    hipStream_t s;
+    explicit StreamDrain(hipStream_t st) : s(st) {}
+    ~StreamDrain() { (void)hipStreamSynchronize(s); }
+};
+
 static int fail(pmc_system *h, int code, const char *msg)
 {
     if (h) h->err = msg;
@@ -1984,6 +1993,9 @@ static int sweep_sequential_ref_many(pmc_system **hs, int n, const pmc_move *poo
     if (rc) return rc;
     std::vector<RefArgs> args((size_t)n);
     std::vector<RefOp> ops((size_t)n);
+    std::vector<unsigned long long> st((size_t)n * PMC_NSTATS);
+    DevTmp d_args, d_ops;
+    StreamDrain drain(m->stream);       // (the copies below read args / ops / h->energy and write st / h->energy: none outlives the stream's work)
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
         if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
@@ -2002,7 +2014,6 @@ static int sweep_sequential_ref_many(pmc_system **hs, int n, const pmc_move *poo
         o.pool = make_pool(pool, npool);
         o.stats = h->d_stats;
     }
-    DevTmp d_args, d_ops;
     HIPCHK(m, d_args.alloc((size_t)n * sizeof(RefArgs)));
     HIPCHK(m, d_ops.alloc((size_t)n * sizeof(RefOp)));
     HIPCHK(m, hipMemcpyAsync(d_args.p, args.data(), (size_t)n * sizeof(RefArgs), hipMemcpyHostToDevice, m->stream));
@@ -2012,7 +2023,6 @@ static int sweep_sequential_ref_many(pmc_system **hs, int n, const pmc_move *poo
     else hipLaunchKernelGGL(k_ref_steps_many<2>, dim3(n), dim3(64), 0, m->stream, d_args.as<RefArgs>(), d_ops.as<RefOp>());
     HIPCHK(m, hipGetLastError());
     HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
-    std::vector<unsigned long long> st((size_t)n * PMC_NSTATS);
     for (int r = 0; r < n; r++) {
         HIPCHK(hs[r], hipMemcpyAsync(&hs[r]->energy, hs[r]->d_energy, sizeof(double), hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hs[r], hipMemcpyAsync(st.data() + (size_t)r * PMC_NSTATS, hs[r]->d_stats, PMC_NSTATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));

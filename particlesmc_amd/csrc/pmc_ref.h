@@ -309,8 +309,10 @@ __device__ void ref_relink(const RefArgs &a, int i, const double *x)
     a.cs[i] = c2;
     if (a.cl_items) {
         // rows of the fast sequential engine (pmc_seq.h): a cell's chain read backwards, so push-front = append
+        // (a row that overflowed earlier in this launch -- error bit 4, the host drops the rows after the launch -- counts more
+        // particles than it holds: the scan stays inside the row, it never reaches the next cell's or the end of the array)
         int *v = a.cl_items + (size_t)c * a.cl_cap;
-        const int n = a.ccount[c];
+        const int n = min(a.ccount[c], a.cl_cap);
         int w = 0;
         for (int r = 0; r < n; r++) {
             const int t = v[r];

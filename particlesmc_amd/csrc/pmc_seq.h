@@ -1461,9 +1461,8 @@ __global__ __launch_bounds__(NW * 64) void k_sq_round_fused(const SqArgs *__rest
 
 // ---- commit, admission and preparation by ONE workgroup ---------------------------------------------------------------------------
 // With no pending step (the first launch of a call) this just admits and prepares the first window: the prologue of the fused
-// rounds.  As the second launch of every round of a LARGER window (PMC_SEQ_TWO=1: k_sq_round_a, then this, instead of
-// k_sq_commit + k_sq_fill + k_sq_prep) it was measured and lost: a lane per slot serialises what the launches spread over the
-// chip -- 38 against 32 us per round at K = 512, 107 against 47 at K = 2048 (LAB.md).
+// rounds.  (As the second launch of every round of a LARGER window -- k_sq_round_a, then this, instead of k_sq_commit +
+// k_sq_fill + k_sq_prep -- it was measured and lost: LAB.md, round 5.  That launch form is gone from the library.)
 #define SQ_TAIL_THREADS 1024
 
 template <int D>

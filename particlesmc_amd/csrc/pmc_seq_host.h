@@ -213,8 +213,7 @@ struct SeqGroup {
     const void *k_fused = nullptr;    // k_sq_round_fused likewise
     int nw = SQ_EW;                   // wavefronts per evaluated step (PMC_SEQ_EW=1: one, the A/B partner)
     bool fused = false;               // windows of <= SQ_FUSED_KMAX: a round is one launch (evaluate; the last workgroup commits, admits, prepares)
-    bool two = false;                 // larger windows: two launches (k_sq_round_a, k_sq_tail)
-    bool primed = false;              // ... either after the first window of the call has been admitted and prepared (one k_sq_tail)
+    bool primed = false;              // ... after the first window of the call has been admitted and prepared (one k_sq_tail)
     long long rounds_last = 0, rounds_folded = 0;     // rounds of the batch enqueued last / of the batch being folded
     hipGraphExec_t graph = nullptr;   // SQ_GRAPH_ROUNDS rounds, captured once per call (a group of one caches it on the handle)
     bool own_graph = false;
@@ -237,12 +236,6 @@ static void seq_launch_round(const SeqGroup &g)
         (void)hipLaunchKernel(g.k_fused, dim3(K, n), dim3(64 * g.nw), kargs, std::max(g.lds, g.lds_fill), h->stream);
         return;
     }
-    if (g.two) {
-        (void)hipLaunchKernel(g.k_eval, dim3(K, n), dim3(64 * g.nw), kargs, g.lds, h->stream);
-        if (h->D == 3) hipLaunchKernelGGL(k_sq_tail<3>, dim3(1, n), dim3(SQ_TAIL_THREADS), g.lds_fill, h->stream, g.d_tab);
-        else hipLaunchKernelGGL(k_sq_tail<2>, dim3(1, n), dim3(SQ_TAIL_THREADS), g.lds_fill, h->stream, g.d_tab);
-        return;
-    }
     if (h->D == 3) {
         hipLaunchKernelGGL(k_sq_fill<3>, dim3(1, n), dim3(SQ_FILL_THREADS), g.lds_fill, h->stream, g.d_tab);
         hipLaunchKernelGGL(k_sq_prep<3>, dim3((2 * K + 255) / 256, n), dim3(256), 0, h->stream, g.d_tab);
@@ -263,7 +256,7 @@ static int seq_graph(SeqGroup &g)
 {
     pmc_system *h = g.lead;
     if (g.graph) return PMC_OK;
-    const int graph_key = (g.fused ? -g.K : g.K) * 16 + g.nw + (g.two ? 8 : 0);
+    const int graph_key = (g.fused ? -g.K : g.K) * 16 + g.nw;
     if (g.n == 1 && h->sq_graph && h->sq_graph_K == graph_key && memcmp(&h->sq_graph_args, &g.runs[0].s, sizeof(SqArgs)) == 0) {
         g.graph = h->sq_graph;
         return PMC_OK;
@@ -399,7 +392,6 @@ static int seq_group_begin(SeqGroup &g, pmc_system **hs, int n, const pmc_move *
     }
     // PMC_SEQ_NOFUSE=1: four launches per round whatever the window (the A/B partner; what windows beyond SQ_FUSED_KMAX run)
     g.fused = g.K <= SQ_FUSED_KMAX && !getenv("PMC_SEQ_NOFUSE");
-    g.two = !g.fused && getenv("PMC_SEQ_TWO") != nullptr;     // (measured: the one-workgroup tail costs 80 us at K = 2048 where the three launches take 23 -- LAB.md)
     if (g.lds > 48 * 1024) {
         HIPCHK(m, hipFuncSetAttribute(g.k_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
     }
@@ -468,17 +460,17 @@ static int seq_group_enqueue(SeqGroup &g, bool pipelined = false)
     for (SeqRun &r : g.runs)                                 // ... and no chain's ring may overflow in the batch
         if (!r.done && !r.failed) rounds = std::min<long long>(rounds, std::max<long long>(1, (long long)(r.ring / (ring_div * K))));
     g.rounds_last = rounds;
-    if ((g.fused || g.two) && !g.primed) {                    // the first window of the call: nothing to commit, admitted and prepared
+    if (g.fused && !g.primed) {                    // the first window of the call: nothing to commit, admitted and prepared
         g.primed = true;
         if (m->D == 3) hipLaunchKernelGGL(k_sq_tail<3>, dim3(1, g.n), dim3(SQ_TAIL_THREADS), g.lds_fill, m->stream, g.d_tab);
         else hipLaunchKernelGGL(k_sq_tail<2>, dim3(1, g.n), dim3(SQ_TAIL_THREADS), g.lds_fill, m->stream, g.d_tab);
     }
     long long q = 0;
-    // (with a rocprofiler-sdk tool attached -- rocprofv3 sets ROCP_TOOL_LIBRARIES -- the rounds go launch by launch: on ROCm 7.2
-    // hipGraphLaunch under `rocprofv3 --kernel-trace` crashes inside the tool's dispatch callback for some of these graphs
-    // (windows of 64 and 1024 in runs of >= 10^6 steps; never without the tool).  PMC_SEQ_GRAPH=1 replays the graph anyway.)
-    const bool tool = getenv("ROCP_TOOL_LIBRARIES") != nullptr && !getenv("PMC_SEQ_GRAPH");
-    if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH") && !tool) {
+    // PMC_SEQ_NOGRAPH=1: the rounds go launch by launch.  The profile scripts set it: on ROCm 7.2 hipGraphLaunch under
+    // `rocprofv3 --kernel-trace` crashes inside the tool's dispatch callback for some of these graphs (windows of 64 and 1024 in
+    // runs of >= 10^6 steps; never without the tool).  The library itself never looks for a profiler: what runs under one is
+    // what runs without, unless the caller says otherwise.
+    if (rounds >= SQ_GRAPH_ROUNDS && !getenv("PMC_SEQ_NOGRAPH")) {
         if (int rg = seq_graph(g)) return rg;
         for (; q + SQ_GRAPH_ROUNDS <= rounds; q += SQ_GRAPH_ROUNDS) HIPCHK(m, hipGraphLaunch(g.graph, m->stream));
     }
@@ -705,7 +697,15 @@ static bool seq_lds_fits(const pmc_system *h, size_t limit)
     if (h->N > 65535 || h->S > 8) return false;
     if (h->list_type == 3) return false;                        // VerletList: its own update rule (engine 1)
     const int cap = h->d_cl_items ? h->cl_cap : seq_rows_cap(h);
-    if (h->list_type == 0 && seq_lds_layout(h, cap, nullptr, 4) <= SQ_LDS_MAX) return true;     // (EmptyList has no other fast engine: the whole LDS, positions in global memory if need be)
+    if (h->list_type == 0) {
+        // EmptyList has no other fast engine: the whole LDS, positions in global memory if need be.  With the positions in
+        // global memory the four-wavefront instance is the only one: its layout has to fit, a narrower one does not count
+        // (N of about 18 900 .. 22 200: the one-wavefront layout would fit and the kernel would overrun it)
+        SqLdsArgs probe;
+        const size_t l4 = seq_lds_layout(h, cap, &probe, 4);
+        if (l4 <= SQ_LDS_MAX) return true;
+        if (probe.pos_global) return false;
+    }
     return seq_lds_layout(h, cap, nullptr) <= limit;
 }
 
@@ -773,7 +773,12 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     SqLdsArgs probe;
     (void)seq_lds_layout(m, cap, &probe, 4);
     if (probe.pos_global) nw = 4;                            // (positions in global memory: the four-wavefront instance is the only one)
-    if (nw > 1 && seq_lds_layout(m, cap, nullptr, nw) > SQ_LDS_MAX) nw = 1;
+    if (nw > 1 && seq_lds_layout(m, cap, nullptr, nw) > SQ_LDS_MAX) {
+        // (the positions-in-global-memory kernel deals its trips over four wavefronts and sums on two of them: there is no
+        // one-wavefront form of it to fall back to)
+        if (probe.pos_global) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: an EmptyList system of this size does not fit the LDS even with its positions in global memory");
+        nw = 1;
+    }
     const size_t lds = seq_lds_layout(m, cap, &s, nw);
     if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 3: the chain's state does not fit the LDS");
     // the kernel of a system whose pair models are all of one kind has that potential compiled in (PMC_SEQ_ANYKIND=1: the general kernel, for A/B)
@@ -804,6 +809,7 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
         c.temperature = h->p.temperature;
     }
     DevTmp dtab;
+    StreamDrain drain(m->stream);       // (tab and dtab are read and written by copies on the stream: drained before they go, error returns included)
     HIPCHK(m, dtab.alloc((size_t)n * sizeof(SqChain)));
     s.chains = dtab.as<SqChain>();
     HIPCHK(m, hipMemcpyAsync(s.chains, tab.data(), (size_t)n * sizeof(SqChain), hipMemcpyHostToDevice, m->stream));

@@ -6,6 +6,9 @@
 # `--only-headline` makes the LAST steps / rounds launches of the sweep kernel the timed region of the run.
 cd /tmp; export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
+# rounds of the reference-order windows launch by launch under the profiler (hipGraphLaunch + --kernel-trace crashes in the tool
+# for some windows on ROCm 7.2); the library itself never looks for a profiler
+export PMC_SEQ_NOGRAPH=1
 P=gpurun_out/prof
 mkdir -p $P; rm -rf $P/trace $P/trace_m1 $P/fetch $P/write $P/sq $P/sq2 $P/sq_m1
 python3 bench.py > $P/bench_full.json 2> $P/bench_full.err

@@ -5,6 +5,9 @@
 #   cp gpurun_out/seq_summary/* profiles/
 cd /tmp; export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
+# rounds of the reference-order windows launch by launch under the profiler (hipGraphLaunch + --kernel-trace crashes in the tool
+# for some windows on ROCm 7.2); the library itself never looks for a profiler
+export PMC_SEQ_NOGRAPH=1
 P=gpurun_out/prof
 mkdir -p $P
 # ---- round 4: the reference-order chain (PMC_SEQUENTIAL; pmc_seq.h) ----------------------------------------------------------

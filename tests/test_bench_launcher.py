@@ -11,6 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
+MARK = f"pmc-launch-timeout-test-{os.getpid()}"
 
 
 def _run(args, **env):
@@ -58,7 +59,21 @@ def test_launch_timeout_kills_the_ranks_and_exits_nonzero():
     """a rank that hangs must end `bench.py --gpus N` with a non-zero status -- the parent kills the process
     group of the ranks it started (never a re-exec).  The stub engine sleeps when PMC_BENCH_STUB_HANG names the rank."""
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--lattice", "6", "--no-cpu", "--launch-timeout", "20"],
-             PMC_BENCH_STUB="1", PMC_BENCH_STUB_HANG="1")
+             PMC_BENCH_STUB="1", PMC_BENCH_STUB_HANG="1", PMC_BENCH_TEST_MARK=MARK)
     assert r.returncode == 5, (r.returncode, r.stderr[-1500:])
     assert "did not finish within" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # ADVICE r05: the ranks themselves must be gone (the elastic agent's workers are not in the launcher's process group; the
+    # parent finds them in /proc, no optional package).  Every process of the job carries the marker in its environment.
+    import time
+    time.sleep(0.5)
+    left = []
+    for e in os.listdir("/proc"):
+        if e.isdigit():
+            try:
+                with open(f"/proc/{e}/environ", "rb") as f:
+                    if MARK.encode() in f.read():
+                        left.append(int(e))
+            except OSError:
+                pass
+    assert not left, f"processes of the hung job survived the kill: {left}"

@@ -56,10 +56,10 @@ def _draw(pmc, O, case):
 
 def _engine2_switches(case, monkeypatch):
     """The launch forms and conflict rules of the speculative windows (round 5), drawn per case from a generator of their own:
-    a round as one launch / four launches / evaluation + one-workgroup tail, one or four wavefronts per evaluated step, the
+    a round as one launch / four launches, replayed from a graph or launch by launch, one or four wavefronts per evaluated step, the
     distance rule or the cell rule for conflicts -- the same chain, bit for bit, whichever runs."""
     r = np.random.default_rng(991000 + case)
-    for var in ("PMC_SEQ_CELLRULE", "PMC_SEQ_NOFUSE", "PMC_SEQ_EW", "PMC_SEQ_TWO"):
+    for var in ("PMC_SEQ_CELLRULE", "PMC_SEQ_NOFUSE", "PMC_SEQ_EW", "PMC_SEQ_NOGRAPH"):
         monkeypatch.delenv(var, raising=False)
     if r.random() < 0.25:
         monkeypatch.setenv("PMC_SEQ_CELLRULE", "1")
@@ -67,7 +67,7 @@ def _engine2_switches(case, monkeypatch):
     if form < 0.2:
         monkeypatch.setenv("PMC_SEQ_NOFUSE", "1")
     elif form < 0.35:
-        monkeypatch.setenv("PMC_SEQ_TWO", "1")
+        monkeypatch.setenv("PMC_SEQ_NOGRAPH", "1")
     if r.random() < 0.2:
         monkeypatch.setenv("PMC_SEQ_EW", "1")
 

@@ -421,21 +421,21 @@ def test_ss142d_hundred_chains_of_eight_particles_in_one_launch(gpu):
         assert np.array_equal(chains[k].position, o.positions()) and chains[k].energy[0] == o.energy, k
 
 
-_FORMS = {"one launch per round": {}, "four launches": {"PMC_SEQ_NOFUSE": "1"}, "evaluation + one-workgroup tail": {"PMC_SEQ_NOFUSE": "1", "PMC_SEQ_TWO": "1"},
+_FORMS = {"one launch per round": {}, "four launches": {"PMC_SEQ_NOFUSE": "1"},
           "one wavefront per step": {"PMC_SEQ_EW": "1"}, "cell rule": {"PMC_SEQ_CELLRULE": "1"},
           "cell rule, four launches, one wavefront (round 4's engine)": {"PMC_SEQ_CELLRULE": "1", "PMC_SEQ_NOFUSE": "1", "PMC_SEQ_EW": "1"},
-          "as under a profiler": {"ROCP_TOOL_LIBRARIES": "none"}}
+          "launch by launch (the profile scripts' PMC_SEQ_NOGRAPH)": {"PMC_SEQ_NOGRAPH": "1"}}
 
 
 @pytest.mark.parametrize("form", list(_FORMS))
 def test_every_launch_form_and_conflict_rule_of_the_windows(gpu, form, monkeypatch):
-    """Round 5 gave the speculative windows three launch forms (a round as one launch: evaluate, the last workgroup commits, admits
-    and prepares; four launches; evaluation + a one-workgroup tail), four wavefronts per evaluated step and a distance-based
+    """Round 5 gave the speculative windows two launch forms (a round as one launch: evaluate, the last workgroup commits, admits
+    and prepares; four launches), replayed from a captured graph or launch by launch, four wavefronts per evaluated step and a distance-based
     conflict rule next to the cell rule.  Each combination on one Kob-Andersen liquid with swaps and wide moves (cell crossings,
     accepted swaps, held-back steps) and on a 2-D soft-sphere system, three calls each: the oracle's chain, bit for bit."""
     from oracle import oracle as O
     pmc = gpu
-    for var in ("PMC_SEQ_NOFUSE", "PMC_SEQ_TWO", "PMC_SEQ_EW", "PMC_SEQ_CELLRULE", "PMC_SEQ_GRAPH", "PMC_SEQ_NOGRAPH", "ROCP_TOOL_LIBRARIES"):
+    for var in ("PMC_SEQ_NOFUSE", "PMC_SEQ_EW", "PMC_SEQ_CELLRULE", "PMC_SEQ_NOGRAPH"):
         monkeypatch.delenv(var, raising=False)
     for var, val in _FORMS[form].items():
         monkeypatch.setenv(var, val)
@@ -533,3 +533,32 @@ def test_empty_list_beyond_the_lds_other_instances(gpu, d, n, model):
     att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.07}]), 13, 0, 0, N)
     assert np.array_equal(st.accepted, acc), (st.accepted, acc)
     assert np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
+
+
+def test_empty_list_too_large_for_engine_3_is_refused_not_overrun(gpu):
+    """an EmptyList system of about 18 900 .. 22 200 particles does not fit the four-wavefront layout of the
+    positions-in-global-memory kernel, while the one-wavefront layout (23 KB smaller) would -- engine 3 used to launch the
+    four-wavefront kernel with one wavefront and that layout (three of four trips never computed, the segments past the end of
+    the LDS).  Now engine 3 refuses the system when it is asked for, and the default selection runs the literal loop: N = 19 683,
+    one sweep, the oracle's chain bit for bit."""
+    from oracle import oracle as O
+    from inputs import lj_lattice as lat
+    from particlesmc_amd import _lib
+    pmc = gpu
+    pos, sp, rho = lat(27, jitter=0.05, seed=4, rho=0.9, d=3)
+    N = len(pos)
+    assert N == 19683
+    g = pmc.System(pos, sp, rho, 0.9, pmc.LennardJones(1.0, 1.0), list_type=pmc.EmptyList, seed=17)
+    with pytest.raises(_lib.PMCError) as ei:
+        g.set_sequential_engine(3, 0)
+    assert ei.value.code == _lib.PMC_ERR_UNSUPPORTED
+    o = O.System(pos, sp, rho, 0.9, O.single(O.lennard_jones(1.0, 1.0)), O.EMPTYLIST)
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.07)], nsweeps=1, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.07}]), 17, 0, 0, N)
+    assert np.array_equal(st.accepted, acc), (st.accepted, acc)
+    assert np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
+    # two such chains in one call: the shared-launch path takes the same decision
+    gs = [pmc.System(pos, sp, rho, 0.9, pmc.LennardJones(1.0, 1.0), list_type=pmc.EmptyList, seed=17, chain=k) for k in range(2)]
+    for h in gs:
+        with pytest.raises(_lib.PMCError):
+            h.set_sequential_engine(3, 0)

@@ -74,3 +74,7 @@ def test_no_experiment_switches_in_the_product_sources():
         txt = open(path).read()
         for sym in ("PMC_EXP_", "PMC_MFMA_REDUCE"):
             assert sym not in txt, f"{os.path.basename(path)} contains the experiment switch {sym}*"
+        # round 6: the measured-and-lost two-launch round of the windows is gone, and the library never changes its
+        # execution path because a profiler is attached (the profile scripts say PMC_SEQ_NOGRAPH=1 themselves)
+        for sym in ("PMC_SEQ_TWO", "ROCP_TOOL_LIBRARIES", "PMC_SEQ_GRAPH\""):
+            assert sym not in txt, f"{os.path.basename(path)} contains {sym}"
