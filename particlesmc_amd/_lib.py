@@ -109,6 +109,7 @@ SYMBOLS = {
     "pmc_get_rounds": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pmc_set_sequential_engine": (C.c_int, [_h, C.c_int32, C.c_int32]),
     "pmc_sequential_info": (C.c_int, [_h, _lp]),
+    "pmc_verlet_info": (C.c_int, [_h, _lp]),
     "pmc_sweep": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64, C.POINTER(Stats)]),
     "pmc_sweep_begin": (C.c_int, [_h, C.c_int32, C.POINTER(Move), C.c_int32, C.c_int64]),
     "pmc_sweep_end": (C.c_int, [_h, C.POINTER(Stats)]),

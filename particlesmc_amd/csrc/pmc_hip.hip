@@ -103,6 +103,7 @@ struct pmc_system {
     int *d_cl_items = nullptr, *d_vl_nb = nullptr, *d_vl_cnt = nullptr, *d_ref_err = nullptr;
     double *d_vl_last = nullptr;
     int cl_cap = 0, vl_cap = 0;
+    long long sqv_last[4] = {0, 0, 0, 0};     // engine 4, last call: batches, steps run by wavefront 0 alone, list rebuilds, steps it ran
     int cap_hint = 0;       // LDS staging capacity learnt from the last sweeps' histogram (cb_cap_learn); 0: none yet
     unsigned long long kept_seen[16] = {0};   // the part of the current call's histogram cb_cap_learn has already used
     // proposal slots of the current sweep (k_mc_slots)
@@ -1905,13 +1906,16 @@ extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const dou
     return PMC_OK;
 }
 
+#include "pmc_verlet.h"
 #include "pmc_seq_host.h"
 
 extern "C" int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: null handle");
-    if (engine < 0 || engine > 3 || window < 0 || window > SQ_KMAX)
-        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront), 2 (speculative windows) or 3 (state in LDS); window 0..4096");
+    if (engine < 0 || engine > 4 || window < 0 || window > SQ_KMAX)
+        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront), 2 (speculative windows), 3 (state in LDS) or 4 (VerletList state in LDS); window 0..4096");
+    if (engine == 4 && !seq_verlet_fits(h))
+        return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 4 needs a VerletList system whose positions, cell vectors and neighbour lists fit 160 KB of LDS");
     if (engine == 3 && !seq_lds_fits(h, SQ_LDS_MAX))
         return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 3 needs a LinkedList, CellList or EmptyList system whose state fits 160 KB of LDS");
     if (h->pending) return fail(h, PMC_ERR_STATE, "a sweep is in flight on this handle: call pmc_sweep_end first");
@@ -1930,22 +1934,17 @@ extern "C" int pmc_sequential_info(pmc_system *h, int64_t *out)
     return PMC_OK;
 }
 
-static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+extern "C" int pmc_verlet_info(pmc_system *h, int64_t *out)
 {
-    if (nsweeps > 0 && seq_pool_ok(pool, npool) && h->seq_engine != 1 && h->seq_engine != 2 &&
-        (h->seq_engine == 3 || (h->ncell_ref <= 343 && seq_lds_fits(h, SQ_LDS_AUTO)))) {
-        // few cells per side: every step interacts with every other, and the whole state fits the LDS (pmc_seq.h, engine 3)
-        pmc_system *one[1] = {h};
-        const int rl = sweep_sequential_lds(one, 1, pool, npool, nsweeps, out);
-        // (a crowded cell can make the rows outgrow the LDS after all: nothing has run then, and the windows take over)
-        if (rl != PMC_ERR_UNSUPPORTED || h->seq_engine == 3) return rl;
-    }
-    if (nsweeps > 0 && h->seq_engine != 3 && seq_fast_applicable(h, pool, npool)) {
-        const int rf = sweep_sequential_fast(h, pool, npool, nsweeps, out);
-        // (neighbourhood rows beyond the LDS -- a cell of thousands of particles -- are refused before anything runs: the
-        // literal loop below has no such limit)
-        if (rf != PMC_ERR_UNSUPPORTED || h->seq_engine == 2) return rf;
-    }
+    if (!h || !out) return fail(h, PMC_ERR_BADARG, "pmc_verlet_info: null argument");
+    for (int q = 0; q < 4; q++) out[q] = (int64_t)h->sqv_last[q];
+    return PMC_OK;
+}
+
+// `nsteps` steps of the chain on the literal loop (engine 1, k_ref_ops); `credit_sweeps` whole sweeps are added to the sweep counter.
+// add: the counts are added to *out (the steps of the call that another engine already ran), otherwise they replace it.
+static int sweep_literal_steps(pmc_system *h, const pmc_move *pool, int npool, long long nsteps, int64_t credit_sweeps, pmc_stats *out, bool add)
+{
     if (!h->cells_built) {
         int rc = pmc_build_cells(h);
         if (rc) return rc;
@@ -1955,7 +1954,7 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
     memset(&o, 0, sizeof o);
     o.op = OP_STEPS;
     o.step0 = h->step_ctr;
-    o.nsteps = nsweeps * (int64_t)h->N;   // sweepstep = N, src/ParticlesMC.jl:246
+    o.nsteps = nsteps;
     o.key0 = h->key[0];
     o.key1 = h->key[1];
     o.pool = make_pool(pool, npool);
@@ -1966,20 +1965,60 @@ static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int6
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[1]));
     h->step_ctr += (uint64_t)o.nsteps;
-    h->sweep_ctr += (uint64_t)nsweeps;
+    h->sweep_ctr += (uint64_t)credit_sweeps;
     if (out) {
         unsigned long long st[PMC_NSTATS];
         HIPCHK(h, hipMemcpy(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost));
-        for (int m = 0; m < PMC_MAX_MOVES; m++) { out->attempted[m] = (int64_t)st[m]; out->accepted[m] = (int64_t)st[8 + m]; }
+        for (int m = 0; m < PMC_MAX_MOVES; m++) {
+            out->attempted[m] = (add ? out->attempted[m] : 0) + (int64_t)st[m];
+            out->accepted[m] = (add ? out->accepted[m] : 0) + (int64_t)st[8 + m];
+        }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
-        out->kernel_ms = ms;
-        out->sweep_kernel_ms = ms;
-        out->sweep_kernel_launches = 1;
+        out->kernel_ms = (add ? out->kernel_ms : 0) + ms;
+        out->sweep_kernel_ms = (add ? out->sweep_kernel_ms : 0) + ms;
+        out->sweep_kernel_launches = (add ? out->sweep_kernel_launches : 0) + 1;
         out->energy = h->energy;
         out->energy_fix = 0;
     }
     return PMC_OK;
+}
+
+static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    if (nsweeps > 0 && seq_pool_ok(pool, npool) && h->seq_engine != 1 && h->seq_engine != 2 && h->seq_engine != 4 &&
+        (h->seq_engine == 3 || (h->ncell_ref <= 343 && seq_lds_fits(h, SQ_LDS_AUTO)))) {
+        // few cells per side: every step interacts with every other, and the whole state fits the LDS (pmc_seq.h, engine 3)
+        pmc_system *one[1] = {h};
+        const int rl = sweep_sequential_lds(one, 1, pool, npool, nsweeps, out);
+        // (a crowded cell can make the rows outgrow the LDS after all: nothing has run then, and the windows take over)
+        if (rl != PMC_ERR_UNSUPPORTED || h->seq_engine == 3) return rl;
+    }
+    if (nsweeps > 0 && h->seq_engine != 3 && h->seq_engine != 4 && seq_fast_applicable(h, pool, npool)) {
+        const int rf = sweep_sequential_fast(h, pool, npool, nsweeps, out);
+        // (neighbourhood rows beyond the LDS -- a cell of thousands of particles -- are refused before anything runs: the
+        // literal loop below has no such limit)
+        if (rf != PMC_ERR_UNSUPPORTED || h->seq_engine == 2) return rf;
+    }
+    if (nsweeps > 0 && h->list_type == 3 && (h->seq_engine == 0 || h->seq_engine == 4) && seq_pool_ok(pool, npool)) {
+        // VerletList (the reference's CI system): state in LDS, steps evaluated a batch at a time (pmc_verlet.h, engine 4)
+        if (!h->cells_built) {
+            int rc = pmc_build_cells(h);
+            if (rc) return rc;
+        }
+        if (seq_verlet_fits(h)) {
+            pmc_system *one[1] = {h};
+            long long did = 0;
+            const int rv = sweep_sequential_verlet(one, 1, pool, npool, nsweeps, out, &did);
+            if (rv) return rv;
+            const long long total = nsweeps * (int64_t)h->N;
+            if (did == total) return PMC_OK;
+            // a neighbour list or cell vector outgrew its LDS row: the rest of the call on the literal loop (rows in global memory)
+            return sweep_literal_steps(h, pool, npool, total - did, nsweeps, out, true);
+        }
+        if (h->seq_engine == 4) return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine 4: the system's state does not fit the LDS");
+    }
+    return sweep_literal_steps(h, pool, npool, nsweeps * (int64_t)h->N, nsweeps, out, false);   // sweepstep = N, src/ParticlesMC.jl:246
 }
 
 // The chains of a `parallel = true` run on the literal loop (engine 1: VerletList, EmptyList systems beyond the LDS, swap pools
@@ -2463,6 +2502,28 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
             for (int q = 0; q < r; q++) if (hs[q] == hs[r]) fast = false;
         }
         if (fast) return sweep_sequential_fast_many(hs, n, pool, npool, nsweeps, out);
+    }
+    if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0 && seq_pool_ok(pool, npool) && hs[0]->list_type == 3) {
+        // VerletList chains of one shape: one workgroup per chain, state in LDS (pmc_verlet.h, engine 4)
+        bool vok = true;
+        for (int r = 0; r < n && vok; r++) {
+            if (hs[r]->seq_engine != 0 && hs[r]->seq_engine != 4) vok = false;
+            if (vok && !hs[r]->cells_built) { const int rb = pmc_build_cells(hs[r]); if (rb) return rb; }
+        }
+        if (vok && seq_verlet_compatible(hs, n) && seq_verlet_fits(hs[0])) {
+            std::vector<long long> did((size_t)n, 0);
+            const int rv = sweep_sequential_verlet(hs, n, pool, npool, nsweeps, out, did.data());
+            if (rv) return rv;
+            int first = PMC_OK;
+            for (int r = 0; r < n; r++) {
+                const long long total = nsweeps * (int64_t)hs[r]->N;
+                if (did[(size_t)r] == total) continue;
+                // (a list outgrew its LDS row on this chain: the rest of its call on the literal loop)
+                const int rl = sweep_literal_steps(hs[r], pool, npool, total - did[(size_t)r], nsweeps, out ? &out[r] : nullptr, true);
+                if (rl && !first) first = rl;
+            }
+            return first;
+        }
     }
     if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0) {
         // chains only the literal loop serves (VerletList, EmptyList beyond the LDS, swaps within a species, engine 1 chosen): one

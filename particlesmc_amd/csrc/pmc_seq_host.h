@@ -862,3 +862,165 @@ static int sweep_sequential_lds(pmc_system **hs, int n, const pmc_move *pool, in
     }
     return first;
 }
+
+// ---- engine 4: VerletList chains with their state in LDS, steps evaluated a batch at a time (pmc_verlet.h) ----------------------
+
+// LDS bytes of k_sq_verlet for this system's shape with rows of `vcap` ids and cell vectors of `ccap` (and the offsets of its arrays):
+// pmc_sqv_layout, next to the kernel (pmc_verlet_inst.hip)
+static size_t seq_verlet_layout(const pmc_system *h, int vcap, int ccap, int nw, SqvArgs *s)
+{
+    (void)nw;
+    return pmc_sqv_layout(h->N, h->D, h->S, h->ncell_ref, h->nn, vcap, ccap, s);
+}
+
+// the capacities engine 4 would run this system with: cell vectors of 1.5 x the mean + 12 ids (at most the device rows' own
+// capacity, and one wavefront's 64), Verlet rows as long as the rest of the LDS allows (a multiple of 4, at most the device
+// rows' capacity); false if such rows would not even hold the expected list (1.15 x the mean number of particles within rcut + dr, + 3)
+static bool seq_verlet_caps(const pmc_system *h, int *vcap_out, int *ccap_out)
+{
+    if (h->list_type != 3 || h->N > 65535 || h->S > 8 || h->ncell_ref > 65535 || !h->d_vl_nb || h->vl_cap < 4) return false;
+    const double mean_c = (double)h->N / (double)h->ncell_ref;
+    int ccap = std::min(std::min(h->cl_cap, 64), (int)(1.5 * mean_c) + 12);
+    if (const char *e = getenv("PMC_SQV_CCAP")) ccap = std::max(1, std::min(std::min(h->cl_cap, 64), atoi(e)));      // (tests: forces the overflow path)
+    double vol = 1.0;
+    for (int a = 0; a < h->D; a++) vol *= h->p.box[a];
+    const double r = h->maxcut + h->list_dr;
+    const double sphere = (h->D == 3) ? 4.18879020478639 * r * r * r : 3.14159265358979 * r * r;
+    const double mean_v = sphere * (double)h->N / vol;
+    int vcap = std::min(h->vl_cap / 4 * 4, 1024);
+    while (vcap >= 4 && seq_verlet_layout(h, vcap, ccap, SQV_NW, nullptr) > SQ_LDS_MAX) vcap -= 4;
+    if (vcap < 4 || (double)vcap < 1.15 * mean_v + 3.0) return false;
+    // rows of up to 4 * SQV_HW ids leave a list in registers (sqv_update): no more than that unless the expected list needs it
+    if (vcap > 4 * SQV_HW && 1.5 * mean_v + 4.0 <= 4.0 * SQV_HW) vcap = 4 * SQV_HW;
+    if (const char *e = getenv("PMC_SQV_VCAP")) vcap = std::max(4, std::min(vcap, atoi(e) / 4 * 4));                 // (tests: forces the overflow path)
+    if (vcap_out) *vcap_out = vcap;
+    if (ccap_out) *ccap_out = ccap;
+    return true;
+}
+
+static bool seq_verlet_fits(const pmc_system *h) { return seq_verlet_caps(h, nullptr, nullptr); }
+
+static bool seq_verlet_compatible(pmc_system **hs, int n)
+{
+    const pmc_system *m = hs[0];
+    for (int r = 1; r < n; r++) {
+        const pmc_system *h = hs[r];
+        for (int q = 0; q < r; q++) if (hs[q] == h) return false;
+        if (h->p.device != m->p.device || h->D != m->D || h->N != m->N || h->S != m->S || h->list_type != m->list_type ||
+            h->ncell_ref != m->ncell_ref || h->nn != m->nn || h->list_dr != m->list_dr || h->cl_cap != m->cl_cap || h->vl_cap != m->vl_cap)
+            return false;
+        for (int a = 0; a < h->D; a++)
+            if (h->p.box[a] != m->p.box[a] || h->p.cell[a] != m->p.cell[a] || h->p.ncells[a] != m->p.ncells[a]) return false;
+        if (h->models.size() != m->models.size() || memcmp(h->models.data(), m->models.data(), m->models.size() * sizeof(pmc_pair_model)) != 0)
+            return false;
+    }
+    return true;
+}
+
+// n VerletList chains of one shape, nsweeps sweeps each of the reference's sequential chain, in shared launches of k_sq_verlet (one
+// workgroup per chain).  steps_done[r] (may be null): the steps of the call chain r has behind it when this returns -- fewer than
+// nsweeps N only if a row or cell vector outgrew its LDS capacity, in which case the caller runs the rest on the literal loop.
+static int sweep_sequential_verlet(pmc_system **hs, int n, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out, long long *steps_done)
+{
+    pmc_system *m = hs[0];
+    int rc = set_device(m);
+    if (rc) return rc;
+    bool swaps = false;
+    for (int k = 0; k < npool; k++) if (pool[k].kind == PMC_MOVE_SWAP) swaps = true;
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
+        if (int rs = refresh_stale_energy(h)) return rs;
+        rc = ensure_species_list(h);
+        if (rc) return rc;
+    }
+    SqvArgs s;
+    memset(&s, 0, sizeof s);
+    int vcap = 0, ccap = 0;
+    if (!seq_verlet_caps(m, &vcap, &ccap)) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 4: not a VerletList system whose state fits the LDS");
+    const size_t lds = seq_verlet_layout(m, vcap, ccap, SQV_NW, &s);
+    s.a = ref_args(m);
+    for (int q = 0; q < 3; q++) { s.invbox[q] = 1.0 / s.a.box[q]; s.invcell[q] = (q < m->D) ? 1.0 / s.a.cell[q] : 1.0; }
+    s.pool = make_pool(pool, npool);
+    s.ncell = m->ncell_ref;
+    int ukind = m->models.empty() ? 4 : (int)m->models[0].kind;
+    for (const pmc_pair_model &pm : m->models) if ((int)pm.kind != ukind) ukind = 4;
+    if (ukind > 3 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
+    const void *kfn = pmc_sqv_kernel(m->D, ukind);
+    HIPCHK(m, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<SqvChain> tab((size_t)n);
+    DevTmp dtab, dwork, dlast;
+    StreamDrain drain(m->stream);       // (tab and the temporaries are read and written by work on the stream: drained before they go)
+    // swaps edit the SpeciesList as they are accepted; a launch that gives up must leave no trace, so the chains work on copies
+    // that are copied back by the launch that finishes (k_sq_verlet)
+    const size_t N = (size_t)m->N;
+    if (swaps) HIPCHK(m, dwork.alloc((size_t)n * 2 * N * sizeof(int)));
+    HIPCHK(m, dlast.alloc((size_t)n * N * m->D * sizeof(double)));
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        SqvChain &c = tab[r];
+        memset(&c, 0, sizeof c);
+        c.pos = h->d_pos; c.species = h->d_species;
+        c.cs = h->d_cs; c.ccount = h->d_ccount; c.cl_items = h->d_cl_items;
+        c.vl_nb = h->d_vl_nb; c.vl_cnt = h->d_vl_cnt; c.vl_last = h->d_vl_last;
+        c.sp_ids = h->d_sp_ids; c.sp_heads = h->d_sp_heads; c.sp_off = h->d_sp_off;
+        c.sp_ids_work = swaps ? dwork.as<int>() + (size_t)r * 2 * N : nullptr;
+        c.sp_heads_work = swaps ? dwork.as<int>() + (size_t)r * 2 * N + N : nullptr;
+        c.last_work = dlast.as<double>() + (size_t)r * N * m->D;
+        c.key0 = h->key[0]; c.key1 = h->key[1];
+        c.step0 = h->step_ctr;
+        c.energy = h->energy;
+        c.temperature = h->p.temperature;
+    }
+    HIPCHK(m, dtab.alloc((size_t)n * sizeof(SqvChain)));
+    s.chains = dtab.as<SqvChain>();
+    HIPCHK(m, hipMemcpyAsync(s.chains, tab.data(), (size_t)n * sizeof(SqvChain), hipMemcpyHostToDevice, m->stream));
+    for (int r = 1; r < n; r++) HIPCHK(hs[r], hipStreamSynchronize(hs[r]->stream));   // earlier work on the chains' own streams
+    HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
+    const long long total = nsweeps * (int64_t)m->N;          // sweepstep = N, src/ParticlesMC.jl:246
+    const long long chunk = 1 << 20;                          // steps per launch and chain (a launch stays well under a second)
+    long long launches = 0;
+    for (long long done = 0; done < total; done += chunk) {
+        s.nsteps = std::min(chunk, total - done);
+        void *kargs[1] = {(void *)&s};
+        HIPCHK(m, hipLaunchKernel(kfn, dim3(n), dim3(SQV_NW * 64), kargs, lds, m->stream));
+        HIPCHK(m, hipGetLastError());
+        launches++;
+    }
+    HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
+    HIPCHK(m, hipMemcpyAsync(tab.data(), s.chains, (size_t)n * sizeof(SqvChain), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, m->ev[0], m->ev[1]);
+    if (getenv("PMC_SQV_TIMES")) {                          // stamped builds (-DPMC_DEBUG_TIME on pmc_verlet_inst.hip): chain 0's phase clock
+        unsigned long long t[16];
+        pmc_sqv_times(t);
+        fprintf(stderr, "sqv phase clock (s_memtime ticks): gen %llu  A %llu  B %llu | taken %llu  alone-to-update %llu  leave-lists %llu  scan %llu  rest %llu | rebuilds %llu  (%.2f ms)\n",
+                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], ms);
+    }
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        const SqvChain &c = tab[r];
+        h->mc_binned = false;
+        h->e_fix_valid = false;
+        h->img_valid = false;
+        // (a launch that gave up changed nothing, and so did every launch behind it: the chain stands where the last good launch left it)
+        const long long did = (long long)(c.step0 - h->step_ctr);
+        h->energy = c.energy;
+        h->step_ctr = c.step0;
+        if (did == total) h->sweep_ctr += (uint64_t)nsweeps;
+        h->sqv_last[0] = (long long)c.n_batches; h->sqv_last[1] = (long long)c.n_serial; h->sqv_last[2] = (long long)c.n_rebuild; h->sqv_last[3] = did;
+        if (steps_done) steps_done[r] = did;
+        if (out) {
+            pmc_stats &o = out[r];
+            memset(&o, 0, sizeof o);
+            for (int q = 0; q < PMC_MAX_MOVES; q++) { o.attempted[q] = (int64_t)c.att[q]; o.accepted[q] = (int64_t)c.acc[q]; }
+            o.kernel_ms = ms;
+            o.sweep_kernel_ms = ms;
+            o.sweep_kernel_launches = launches;
+            o.energy = h->energy;
+        }
+        if (c.err & SQV_ERR_LIST) return fail(h, PMC_ERR_STATE, "sequential engine 4: a particle was missing from a neighbour's list or from its cell vector");
+    }
+    return PMC_OK;
+}

@@ -274,12 +274,20 @@ class Atoms(Particles):
     # --- how PMC_SEQUENTIAL sweeps run (same chain bit for bit; include/pmc.h) --------------------
     def set_sequential_engine(self, engine=0, window=0):
         """engine 0 auto, 1 the one-wavefront literal loop, 2 speculative windows, 3 the chain's state in LDS (small systems;
-        any number of chains per launch through mc_sweep_many); window: pending steps per round of engine 2 (0 auto)."""
+        any number of chains per launch through mc_sweep_many), 4 a VerletList system's state in LDS with batches of steps;
+        window: pending steps per round of engine 2 (0 auto)."""
         _lib.check(_lib.lib().pmc_set_sequential_engine(self._h, int(engine), int(window)), self._h)
 
     def debug_inject(self, what=1):
         """Fault injection for the tests (include/pmc.h: pmc_debug_inject); 1 = the next fused launch is declared starved."""
         _lib.check(_lib.lib().pmc_debug_inject(self._h, int(what)), self._h)
+
+    def verlet_info(self):
+        """(batches, steps wavefront 0 ran alone, list rebuilds, steps the engine ran) of the last PMC_SEQUENTIAL call that ran
+        engine 4 (VerletList state in LDS)."""
+        out = (C.c_int64 * 4)()
+        _lib.check(_lib.lib().pmc_verlet_info(self._h, out), self._h)
+        return tuple(int(x) for x in out)
 
     def sequential_info(self):
         """(rounds, step evaluations, window, steps of that call folded into system.energy) of the last PMC_SEQUENTIAL call that
