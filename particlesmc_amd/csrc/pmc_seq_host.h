@@ -995,8 +995,8 @@ static int sweep_sequential_verlet(pmc_system **hs, int n, const pmc_move *pool,
     if (getenv("PMC_SQV_TIMES")) {                          // stamped builds (-DPMC_DEBUG_TIME on pmc_verlet_inst.hip): chain 0's phase clock
         unsigned long long t[16];
         pmc_sqv_times(t);
-        fprintf(stderr, "sqv phase clock (s_memtime ticks): gen %llu  A %llu  B %llu | taken %llu  alone-to-update %llu  leave-lists %llu  scan %llu  rest %llu | rebuilds %llu  (%.2f ms)\n",
-                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], ms);
+        fprintf(stderr, "sqv phase clock (resolver, s_memtime ticks): barrier %llu  clear %llu | taken %llu  applied %llu  alone-to-update %llu  leave-lists %llu  scan %llu  rest %llu  swaps %llu | own rebuilds %llu  applied %llu  alone %llu  (%.2f ms; chain 0: %llu batches, %llu alone, %llu rebuilds, %llu applied)\n",
+                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], ms, tab[0].n_batches, tab[0].n_serial, tab[0].n_rebuild, tab[0].n_applied);
     }
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];

@@ -1,24 +1,30 @@
 // pmc_verlet.h -- engine 4 of the reference-order chain: VerletList systems (src/neighbours.jl:387-543) with their whole state in
-// LDS, steps evaluated a BATCH at a time and resolved in step order.
+// LDS, one wavefront RESOLVING the steps in order while six others EVALUATE the steps behind them.
 //
 // The reference's only CI system (test/runtests.jl:22-91: config_0, N = 1290, 2-D ternary JBB) runs with a VerletList, dr = 0.2.
 // On the literal loop (pmc_ref.h, engine 1) a step of that chain is ~1 us of work behind a dozen dependent global-memory round
-// trips: 11 us per step, 12 x slower than one host core.  Two things are different here:
+// trips: 11 us per step, 12 x slower than one host core.  What is different here:
 //
 //  1. The state -- positions, species, the cell vectors, neighbours[i] for every i -- lives in the LDS of ONE workgroup for the
 //     length of a launch (ids as 16-bit words: 1290 rows of 40 ids are 103 KB).  positions_at_last_update is read once per step
 //     and written once per rebuild: it stays in global memory (a working copy, L2), its load issued before the sums it hides behind.
 //  2. The random part of a step is a pure function of the step counter, so the particle of step t + k is known in advance; and a
 //     Verlet row is short (27 ids), so a step reads almost nothing: x_i, last_i, neighbours[i] and the positions / species of its
-//     members.  The NW wavefronts of the workgroup each evaluate ONE of the next NW steps against the state at the start of the
-//     batch (phase A: e1, e2 in row order, whether the trial position asks for a rebuild); wavefront 0 then walks the batch in
-//     step order (phase B).  A step whose inputs nobody has touched since the batch started -- `dirty[i] == 0`: neither i nor any
-//     member of neighbours[i] has been moved, re-listed or changed species by an earlier step of the batch -- takes its
-//     evaluation as it is: decision, position store, dirty marks for i and its row.  Any other step (and every step whose trial
-//     position is dr / 2 from the last update, i.e. rebuilds neighbours[i]; and every swap) is run by wavefront 0 on the current
-//     state, exactly as the literal loop runs it.  Lists are symmetric (j in neighbours[i] <=> i in neighbours[j]) at every
-//     point of the reference's algorithm, so "i or a member of its row changed" is one mark per member of the changed
-//     particle's row.
+//     members.  The workgroup is a pipeline of eight wavefronts over batches of SQV_NB = 6 steps:
+//       * six EVALUATORS each take one step of batch b + 1 and work it out against the state as they find it: e1 and e2 in row
+//         order, the decision, the position to store; and if the trial position is dr / 2 from the last update, the REBUILT list
+//         (the scan of the neighbourhood in cell / vector order, src/neighbours.jl:523-538), e2 over it, and the list of the
+//         reverted position if the step is rejected far from where it was re-listed;
+//       * wavefront 0, the RESOLVER, meanwhile walks batch b in step order.  A step whose inputs nobody has touched since its
+//         evaluation began -- no mark on i in the two epochs of `dirty` (the resolver marks i and every member of neighbours[i]
+//         whenever it moves, re-lists or re-labels i: lists are symmetric at every point of the reference's algorithm), and for
+//         a rebuilt list no mark on the cells its scan read -- IS its evaluation: energy update, position store, marks; a
+//         rebuild is applied from the evaluator's list (i leaves its old neighbours' lists in registers, is appended to the new
+//         ones').  Any other step, and every swap, is run by the resolver on the current state exactly as the literal loop runs it;
+//       * wavefront 4 (the resolver's SIMD mate, otherwise idle) generates the random parts, 64 steps at a time.
+//     One workgroup barrier per batch.  An evaluation that raced with the resolver's stores may have read anything -- every id,
+//     count and cell index it can have read is a valid one (rows and cell vectors are zero-filled at the start, entries are
+//     stored before the counts that expose them), and whatever it computed is discarded by the marks.
 //
 // Same arithmetic, same iterator order (neighbours[i] in vector order: deleteat! keeps it, push! appends), same bits as
 // orc_mc_steps_sequential: positions, positions_at_last_update, cells[], neighbours[], accept counts, system.energy.
@@ -27,18 +33,25 @@
 #pragma once
 #include "pmc_seq.h"
 
-#define SQV_GEN 128               // random parts generated at once (threads 0 .. 127)
-#define SQV_NW 8                  // wavefronts of a chain's workgroup = steps of a batch
-#define SQV_HW 10                 // rows of up to 4 * SQV_HW ids leave a list in registers (sqv_update)
+#define SQV_GEN 128               // ring of random parts: two blocks of 64 steps
+#define SQV_NW 8                  // wavefronts of a chain's workgroup: resolver, generator, six evaluators
+#define SQV_NB 6                  // steps of a batch = evaluators
+#define SQV_HW 10                 // rows of 4 * SQV_HW ids leave a list in registers (sqv_leave_lists)
 
-const void *pmc_sqv_kernel(int d, int kind);      // pmc_verlet_inst.hip: k_sq_verlet<d, SQV_NW, kind>
 struct SqvArgs;
+const void *pmc_sqv_kernel(int d, int kind);      // pmc_verlet_inst.hip: k_sq_verlet<d, kind>
 size_t pmc_sqv_layout(int n, int d, int nspecies, int ncell, int nn, int vcap, int ccap, SqvArgs *s);   // ... the LDS layout of its workgroup
 void pmc_sqv_times(unsigned long long *out16);     // ... and the phase clock of a stamped build (-DPMC_DEBUG_TIME; zeros otherwise)
 
-// stamped builds: phase clock of chain 0's wavefront 0 (sums of s_memtime differences): 0 random parts, 1 phase A, 2 phase B,
-// 3 steps taken from their evaluation, 4 steps run alone up to the list update, 5 rebuild: leaving the neighbours' lists,
-// 6 rebuild: cell vectors + scan + appends, 7 second sums after a rebuild + decision + revert, 8 rebuilds
+// stamped builds: phase clock of chain 0's resolver (sums of s_memtime differences): 0 waiting at the batch barrier, 1 clearing
+// the marks, 2 steps taken from their evaluation, 3 rebuilds applied from an evaluator's list, 4 steps run alone up to the list
+// update, 5 rebuild: leaving the neighbours' lists, 6 rebuild: cell vectors + scan + appends, 7 rest of a step run alone,
+// 8 swaps; counters: 9 rebuilds by the resolver's own scan, 10 applied, 11 steps run alone
+#ifdef SQV_MARK
+#define SQVM(name) asm volatile("; SQVM " name)
+#else
+#define SQVM(name)
+#endif
 #ifdef PMC_DEBUG_TIME
 extern __device__ unsigned long long g_sqvt[16];
 #define SQVT(k) do { if (blockIdx.x == 0 && threadIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -50,9 +63,10 @@ extern __device__ unsigned long long g_sqvt[16];
 #endif
 
 // flags of an evaluated step (SqvSpec): SERIAL: not evaluated (a swap; a rejected step whose inexact revert would rebuild the list),
-// REBUILD: the trial position rebuilds the list (e1 stands, e2 does not), OK accepted, FINITE e1 and e2 finite (system.energy is
-// updated, src/moves.jl:13-18), CHG: the position to store differs from the current one; bits 8-10: the move
-enum { SQV_SERIAL = 1, SQV_REBUILD = 2, SQV_OK = 4, SQV_FINITE = 8, SQV_CHG = 16 };
+// REBUILD: the trial position rebuilds the list (e1 stands; e2, the decision and the new list only with LIST), REB2: the reverted
+// position rebuilds it again (the list is that of the reverted position), OK accepted, FINITE e1 and e2 finite (system.energy is
+// updated, src/moves.jl:13-18), CHG: the position to store differs from the current one, DISP: a Displacement; bits 8-10: the move
+enum { SQV_SERIAL = 1, SQV_REBUILD = 2, SQV_OK = 4, SQV_FINITE = 8, SQV_CHG = 16, SQV_LIST = 32, SQV_REB2 = 64, SQV_DISP = 128 };
 enum { SQV_ERR_ROW = 1, SQV_ERR_CELL = 2, SQV_ERR_LOAD = 4, SQV_ERR_LIST = 8 };
 
 struct SqvChain {                 // per-chain arguments (device table)
@@ -70,7 +84,8 @@ struct SqvChain {                 // per-chain arguments (device table)
     double energy;                // in: system.energy[1]; out: after the steps
     double temperature;
     unsigned long long att[8], acc[8];                   // out (added to)
-    unsigned long long n_serial, n_rebuild, n_batches;   // diagnostics (added to): steps run by wavefront 0 alone, list rebuilds, batches
+    unsigned long long n_serial, n_rebuild, n_batches;   // diagnostics (added to): steps the resolver ran alone, list rebuilds, batches
+    unsigned long long n_applied;                        // ... rebuilds applied from an evaluator's list
     int err;                      // SQV_ERR_*: the launch changed nothing
     int pad;
 };
@@ -85,25 +100,27 @@ struct SqvArgs {
     int ncell;
     int vcap, ccap;               // LDS capacities of a Verlet row (multiple of 4) and of a cell vector
     int tstride;                  // doubles of one half of a wavefront's terms buffer
-    int o_species, o_cs, o_vcnt, o_vrows, o_ccnt, o_crows, o_dirty, o_gen, o_spec, o_models, o_nbr, o_nbrcnt, o_terms, o_ctl;
+    int dstride, cdstride;        // bytes of one epoch of the particle / cell marks
+    int o_species, o_cs, o_vcnt, o_vrows, o_ccnt, o_crows, o_dirty, o_cdirty, o_gen, o_spec, o_lst, o_models, o_nbr, o_nbrcnt, o_terms, o_ctl;
 };
 
-struct __attribute__((aligned(16))) SqvSpec {       // phase A -> phase B
+struct __attribute__((aligned(16))) SqvSpec {       // evaluator -> resolver
     double e1, de;                // first sum; e2 - e1 (0 unless FINITE)
     double xw[3];                 // the position the step stores: x + d if accepted, (x + d) + (-d) otherwise
+    double xl[3];                 // LIST: positions_at_last_update after the step
     int i, flags;
-    double pad;
+    short c0, c2, c3, nl;         // the cell of i when the step was evaluated; LIST: cell of the trial position, of the reverted position (REB2), ids of the list
 };
 
 struct SqvView {
     double *pos;
     double *last;                 // positions_at_last_update: the launch's working copy in GLOBAL memory
-    unsigned char *species, *dirty;
+    unsigned char *species;
+    unsigned char *dirty, *dirty_prev;       // particle marks of this batch's resolution and of the one before (during which this batch was evaluated); a third epoch is being cleared
+    unsigned char *cdirty, *cdirty_prev;     // ... and the same for cells: a particle of the cell moved, entered, left or changed species
     unsigned short *cs, *vcnt, *vrows, *ccnt, *crows, *nbr, *nbrcnt;
     SqGen *gen;
-    SqvSpec *spec;
     const DevModel *models;
-    double *terms;
     int *ctl;                     // [0]: SQV_ERR_* of this launch
 };
 
@@ -123,52 +140,14 @@ __device__ __forceinline__ double sqv_dist2(const SqvArgs &s, const double *xi, 
     return r2;
 }
 
-// compute_energy_particle(system, i, ::VerletList) (src/atoms.jl:81-88 over src/neighbours.jl:422-424) at TWO positions at once:
-// lanes 0-31 take the row's members 32 at a time at xa with species spa, lanes 32-63 the same members at xb with species spb;
-// `other` (a swap partner, or -1) is seen with species sp_other at xb (src/moves.jl:159-167).  Each half packs its non-zero
-// terms into its half of `tb` in row order (a term that is 0 leaves a running FP64 sum as it is), then lane 0 and lane 32 run
-// the two chains of additions in ONE instruction stream.  Called by a whole wavefront; `tb` is that wavefront's own buffer.
-template <int D, int KIND>
-__device__ __forceinline__ void sqv_energy2(const SqvArgs &s, const SqvView &v, double *tb, int i, int spa, int spb, int other, int sp_other,
-                                            const double *xa, const double *xb, double &ea, double &eb)
+// the chain acc += t_k over the `cnt` terms packed at buf (cnt per LANE: lanes may walk different buffers), nmax = the largest
+// cnt of the wavefront; eight zeros lie behind every lane's terms
+__device__ __forceinline__ double sqv_chain(const double *buf, int cnt, int nmax)
 {
-    const int lane = wave_lane(), half = lane >> 5, idx = lane & 31;
-    const int n = v.vcnt[i];
-    const unsigned short *row = v.vrows + i * s.vcap;
-    const int S = s.a.S;
-    double xs[3] = {0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < D; q++) xs[q] = half ? xb[q] : xa[q];
-    const int spme = half ? spb : spa;
-    double *buf = tb + half * s.tstride;
-    int cnt = 0;
-    for (int base = 0; base < n; base += 32) {
-        const int t = base + idx;
-        double u = 0.0;
-        if (t < n) {
-            const int j = row[t];
-            double xj[3] = {0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < D; q++) xj[q] = v.pos[j * D + q];
-            int sj = (S > 1) ? (int)v.species[j] : 0;
-            if (half && j == other) sj = sp_other;
-            const DevModel &m = v.models[spme * S + sj];
-            const double r2 = sqv_dist2<D>(s, xs, xj);
-            if (!(r2 > m.rcut2)) u = (KIND == 4 ? dev_potential_dyn(r2, m) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m));
-        }
-        const unsigned long long mk = __ballot(u != 0.0);
-        const unsigned mine = half ? (unsigned)(mk >> 32) : (unsigned)mk;
-        const int rank = __popc(mine & ((1u << idx) - 1u));
-        if (u != 0.0) buf[cnt + rank] = u;
-        cnt += __popc(mine);
-    }
-    if (idx < SQ_TERMS_PAD) buf[cnt + idx] = 0.0;                 // (+0.0 leaves the sum as it is: the loop runs in blocks of 8)
-    sq_wave_sync();
-    const int nmax = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32));
     double acc = 0.0;
     {
         // the first 24 terms are requested at once (a 2-D list has 20-odd non-zero terms: one round trip, then one chain of
-        // additions); the buffer is at least that long (seq_verlet_layout), what lies behind the terms is masked
+        // additions); the buffer is at least that long (pmc_sqv_layout), what lies behind the terms is masked
         double t[3 * SQ_TERMS_PAD];
 #pragma unroll
         for (int q = 0; q < 3 * SQ_TERMS_PAD; q++) t[q] = buf[q];
@@ -189,12 +168,62 @@ __device__ __forceinline__ void sqv_energy2(const SqvArgs &s, const SqvView &v, 
 #pragma unroll
         for (int q = 0; q < SQ_TERMS_PAD; q++) acc += in ? t[q] : 0.0;
     }
-    ea = readlane_double(acc, 0);
-    eb = readlane_double(acc, 32);
-    sq_wave_sync();                                                // (the buffer is free for the wavefront's next call)
+    return acc;
 }
 
-// every member of neighbours[i], and i: their evaluations of this batch no longer describe the state
+// every lane takes the value of the lane above it (wave_shl:1; the top lane takes 0)
+__device__ __forceinline__ double sqv_shift_down(double u)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(u), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(u), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// compute_energy_particle(system, i, ::VerletList) (src/atoms.jl:81-88 over src/neighbours.jl:422-424) at TWO positions at once:
+// lanes 0-31 take the row's members 32 at a time at xa with species spa, lanes 32-63 the same members at xb with species spb;
+// `other` (a swap partner, or -1) is seen with species sp_other at xb (src/moves.jl:159-167).  The two sums are chains of
+// additions in row order held by lane 0 and lane 32: every trip of the inner loop adds the term the lane holds and shifts the
+// terms one lane down (two DPP moves), ONE instruction stream for both chains and no LDS round trip (a term that is 0 -- a
+// member beyond its pair's cutoff, a lane beyond the row -- leaves the sum as it is).  Called by a whole wavefront.
+template <int D, int KIND>
+__device__ __forceinline__ void sqv_energy2(const SqvArgs &s, const SqvView &v, int i, int spa, int spb, int other, int sp_other,
+                                            const double *xa, const double *xb, double &ea, double &eb)
+{
+    const int lane = wave_lane(), half = lane >> 5, idx = lane & 31;
+    const int n = v.vcnt[i];
+    const unsigned short *row = v.vrows + i * s.vcap;
+    const int S = s.a.S;
+    double xs[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < D; q++) xs[q] = half ? xb[q] : xa[q];
+    const int spme = half ? spb : spa;
+    double acc = 0.0;
+    for (int base = 0; base < n; base += 32) {
+        const int t = base + idx;
+        double u = 0.0;
+        if (t < n) {
+            const int j = row[t];
+            double xj[3] = {0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < D; q++) xj[q] = v.pos[j * D + q];
+            int sj = (S > 1) ? (int)v.species[j] : 0;
+            if (half && j == other) sj = sp_other;
+            const DevModel &m = v.models[spme * S + sj];
+            const double r2 = sqv_dist2<D>(s, xs, xj);
+            if (!(r2 > m.rcut2)) u = (KIND == 4 ? dev_potential_dyn(r2, m) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m));
+        }
+        // (always 32 trips, no branch between them: the lanes beyond the row hold zeros)
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            acc += u;
+            u = sqv_shift_down(u);
+        }
+    }
+    ea = readlane_double(acc, 0);
+    eb = readlane_double(acc, 32);
+}
+
+// every member of neighbours[i], and i: evaluations that read them no longer describe the state
 __device__ __forceinline__ void sqv_mark_row(const SqvArgs &s, const SqvView &v, int i)
 {
     const int lane = wave_lane();
@@ -204,35 +233,21 @@ __device__ __forceinline__ void sqv_mark_row(const SqvArgs &s, const SqvView &v,
     if (lane == 0) v.dirty[i] = 1;
 }
 
-// update_neighbour_list!(system, i, ::VerletList), src/neighbours.jl:494-543, on the LDS state; one wavefront.  Nothing unless
-// the particle is dr / 2 from its position at its last update; then i leaves every list it is in (order kept), its cell vector
-// is updated (filter! + push!), and its own list is rebuilt by scanning the neighbourhood in cell / vector order, i appended to
-// every new neighbour's list.  Returns true if the lists were rebuilt.
-// `last`: positions_at_last_update[i] (the caller has loaded it; it is x after a rebuild).
-template <int D>
-__device__ __forceinline__ bool sqv_update(const SqvArgs &s, const SqvView &v, int i, const double *x, double *last)
+// i leaves the lists of its neighbours (deleteat! in src/neighbours.jl:508-511: the order of what stays is kept); every
+// neighbour is marked.  One wavefront (the resolver).  Returns SQV_ERR_LIST if i was missing from one of them.
+__device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &v, int i)
 {
-    constexpr int NN = (D == 3) ? 27 : 9;
     const int lane = wave_lane();
-    double d2 = 0.0;
-#pragma unroll
-    for (int q = 0; q < D; q++) {
-        const double dx = x[q] - last[q];
-        d2 = (q == 0) ? dx * dx : d2 + dx * dx;
-    }
-    if (d2 < s.a.dr2o4) return false;
-    SQVT_COUNT(8);
-    const int vcap = s.vcap, ccap = s.ccap;
+    const int vcap = s.vcap;
     int err = 0;
     unsigned short *row_i = v.vrows + i * vcap;
     const int ni = v.vcnt[i];
-    // 1. i leaves the lists of its neighbours (deleteat!: the order of what stays is kept).
     if (vcap == 4 * SQV_HW) {
         // Rows of 40 ids: TWO LANES per neighbour, each with one half of that neighbour's row in registers (vcap / 4 words of
         // two ids, plus the word behind them).  A lane finds i in its half, the pair agrees on the position, every word behind it
         // takes the ids one place further on (v_alignbit; the word i sits in is merged under a mask), and the halves go back with
-        // the same few wide stores they came with.  No loop over the rows, no dependent round trip per row: the 27 rows of a 2-D
-        // list leave in ~1 300 cycles where one row per trip of a loop took 12 500 (LAB.md, round 6).
+        // the same few stores they came with.  No loop over the rows, no dependent round trip per row: the 27 rows of a 2-D
+        // list leave in ~2 000 cycles where one row per trip of a loop took 12 500 (LAB.md, round 6).
         constexpr int hw = SQV_HW;                                   // words of a half row
         for (int q0 = 0; q0 < ni; q0 += 32) {
             const int q = q0 + (lane >> 1), hf = lane & 1;
@@ -267,75 +282,97 @@ __device__ __forceinline__ bool sqv_update(const SqvArgs &s, const SqvView &v, i
             }
         }
     } else {
-    // Longer rows (3-D systems): lane q holds neighbour q and the length of its list; then one ROW per trip of the loop, the whole
-    // wavefront on it: the entries behind i move up one place
-    for (int q0 = 0; q0 < ni; q0 += PMC_WAVE) {
-        const int qn = min(PMC_WAVE, ni - q0);
-        const int jq = (lane < qn) ? (int)row_i[q0 + lane] : 0;
-        const int nq = (lane < qn) ? (int)v.vcnt[jq] : 0;
-        for (int q = 0; q < qn; q++) {
-            const int j = __builtin_amdgcn_readlane(jq, q);
-            const int n = __builtin_amdgcn_readlane(nq, q);
-            unsigned short *rj = v.vrows + j * vcap;
-            if (n <= PMC_WAVE) {
-                const int a = (lane < n) ? (int)rj[lane] : -1;
-                const int b = (lane + 1 < n) ? (int)rj[lane + 1] : 0;
-                const unsigned long long mk = __ballot(a == i);
-                if (!mk) err |= SQV_ERR_LIST;
-                const int p = mk ? (int)__builtin_ctzll(mk) : n;
-                if (lane >= p && lane + 1 < n) rj[lane] = (unsigned short)b;
-            } else {
-                int p = -1;
-                for (int base = 0; base < n && p < 0; base += PMC_WAVE) {
-                    const int k = base + lane;
-                    const unsigned long long mk = __ballot(k < n && (int)rj[k] == i);
-                    if (mk) p = base + (int)__builtin_ctzll(mk);
-                }
-                if (p < 0) { err |= SQV_ERR_LIST; p = n; }
-                for (int base = p; base < n - 1; base += PMC_WAVE) {
-                    const int k = base + lane;
-                    unsigned short t = 0;
-                    if (k < n - 1) t = rj[k + 1];
-                    sq_wave_sync();
-                    if (k < n - 1) rj[k] = t;
-                    sq_wave_sync();
+        // Other capacities (3-D systems): lane q holds neighbour q and the length of its list; then one ROW per trip of the loop,
+        // the whole wavefront on it: the entries behind i move up one place
+        for (int q0 = 0; q0 < ni; q0 += PMC_WAVE) {
+            const int qn = min(PMC_WAVE, ni - q0);
+            const int jq = (lane < qn) ? (int)row_i[q0 + lane] : 0;
+            const int nq = (lane < qn) ? (int)v.vcnt[jq] : 0;
+            for (int q = 0; q < qn; q++) {
+                const int j = __builtin_amdgcn_readlane(jq, q);
+                const int n = __builtin_amdgcn_readlane(nq, q);
+                unsigned short *rj = v.vrows + j * vcap;
+                if (n <= PMC_WAVE) {
+                    const int a = (lane < n) ? (int)rj[lane] : -1;
+                    const int b = (lane + 1 < n) ? (int)rj[lane + 1] : 0;
+                    const unsigned long long mk = __ballot(a == i);
+                    if (!mk) err |= SQV_ERR_LIST;
+                    const int p = mk ? (int)__builtin_ctzll(mk) : n;
+                    if (lane >= p && lane + 1 < n) rj[lane] = (unsigned short)b;
+                } else {
+                    int p = -1;
+                    for (int base = 0; base < n && p < 0; base += PMC_WAVE) {
+                        const int k = base + lane;
+                        const unsigned long long mk = __ballot(k < n && (int)rj[k] == i);
+                        if (mk) p = base + (int)__builtin_ctzll(mk);
+                    }
+                    if (p < 0) { err |= SQV_ERR_LIST; p = n; }
+                    for (int base = p; base < n - 1; base += PMC_WAVE) {
+                        const int k = base + lane;
+                        unsigned short t = 0;
+                        if (k < n - 1) t = rj[k + 1];
+                        sq_wave_sync();
+                        if (k < n - 1) rj[k] = t;
+                        sq_wave_sync();
+                    }
                 }
             }
-        }
-        if (lane < qn) { v.vcnt[jq] = (unsigned short)(nq - 1); v.dirty[jq] = 1; }
-    }
-    }
-    sq_wave_sync();
-    SQVT(5);
-    // 2. the cell vectors (update_cell_list!, src/neighbours.jl:468-476: filter! keeps the order, push! appends)
-    const int c = v.cs[i];
-    const int c2 = sq_cell_of_fast<D>(s.a, s.invcell, x);
-    if (c != c2) {
-        unsigned short *rc = v.crows + c * ccap;
-        const int n = v.ccnt[c];                                     // (<= ccap <= 64 checked by the host)
-        const int a = (lane < n) ? (int)rc[lane] : -1;
-        const int b = (lane + 1 < n) ? (int)rc[lane + 1] : 0;
-        const unsigned long long mk = __ballot(a == i);
-        if (!mk) err |= SQV_ERR_LIST;
-        const int p = mk ? (int)__builtin_ctzll(mk) : n;
-        if (lane >= p && lane + 1 < n) rc[lane] = (unsigned short)b;
-        const int n2 = v.ccnt[c2];
-        if (n2 >= ccap) err |= SQV_ERR_CELL;
-        if (lane == 0) {
-            v.ccnt[c] = (unsigned short)(mk ? n - 1 : n);
-            if (n2 < ccap) { v.crows[c2 * ccap + n2] = (unsigned short)i; v.ccnt[c2] = (unsigned short)(n2 + 1); }
-            v.cs[i] = (unsigned short)c2;
+            if (lane < qn) { v.vcnt[jq] = (unsigned short)(nq - 1); v.dirty[jq] = 1; }
         }
     }
     sq_wave_sync();
-    // 3. the new list: the cells around c2 in table order, every cell's vector in order.  Lane l < cnt holds neighbour cell l and
-    //    its length; candidate t of the scan finds its cell by counting the cells that end at or before t
-    const int cnt = v.nbrcnt[c2];
+    return err;
+}
+
+// update_cell_list!(i, c, c2, ::VerletList), src/neighbours.jl:468-476: filter! keeps the order of cells[c], push! appends to
+// cells[c2].  One wavefront (the resolver); both cells are marked.
+__device__ __forceinline__ int sqv_cell_move(const SqvArgs &s, const SqvView &v, int i, int c, int c2)
+{
+    const int lane = wave_lane();
+    const int ccap = s.ccap;
+    int err = 0;
+    unsigned short *rc = v.crows + c * ccap;
+    const int n = v.ccnt[c];                                         // (<= ccap <= 64)
+    const int a = (lane < n) ? (int)rc[lane] : -1;
+    const int b = (lane + 1 < n) ? (int)rc[lane + 1] : 0;
+    const unsigned long long mk = __ballot(a == i);
+    if (!mk) err |= SQV_ERR_LIST;
+    const int p = mk ? (int)__builtin_ctzll(mk) : n;
+    if (lane >= p && lane + 1 < n) rc[lane] = (unsigned short)b;
+    const int n2 = v.ccnt[c2];
+    if (n2 >= ccap) err |= SQV_ERR_CELL;
+    if (lane == 0) {
+        v.ccnt[c] = (unsigned short)(mk ? n - 1 : n);
+        if (n2 < ccap) { v.crows[c2 * ccap + n2] = (unsigned short)i; v.ccnt[c2] = (unsigned short)(n2 + 1); }
+        v.cs[i] = (unsigned short)c2;
+        v.cdirty[c] = 1;
+        v.cdirty[c2] = 1;
+    }
+    sq_wave_sync();
+    return err;
+}
+
+// The scan that re-creates neighbours[i] at x (src/neighbours.jl:523-538): the cells around c2 in table order, every cell's
+// vector in order; j is listed if it is within rcut + dr.  Lane l < cnt holds neighbour cell l and its length; candidate t of
+// the scan finds its cell by counting the cells that end at or before t.  APPLY (the resolver, on the live lists): j goes into
+// neighbours[i] and i is appended to neighbours[j].  Otherwise (an evaluator): the ids go to `lst`, and with WITH_E the pair
+// terms at x go to `tb` in scan order and their chain is returned in e -- the sum compute_energy_particle takes over the new
+// list (a listed particle beyond its pair's cutoff contributes the term 0).  Returns the length of the list.
+template <int D, int KIND, bool APPLY, bool WITH_E>
+__device__ __forceinline__ int sqv_scan(const SqvArgs &s, const SqvView &v, int i, int spi, const double *x, int c2, unsigned short *lst, double *tb,
+                                        double &e, int &err)
+{
+    constexpr int NN = (D == 3) ? 27 : 9;
+    const int lane = wave_lane();
+    const int vcap = s.vcap, ccap = s.ccap, S = s.a.S;
+    const int cnt = min((int)v.nbrcnt[c2], NN);
     const int cc = (lane < cnt) ? (int)v.nbr[c2 * NN + lane] : 0;
-    const int len = (lane < cnt) ? (int)v.ccnt[cc] : 0;
+    const int len = (lane < cnt) ? min((int)v.ccnt[cc], ccap) : 0;
     const int incl = sq_scan32(len);                                 // (inclusive; lanes >= cnt repeat the total)
     const int total = __builtin_amdgcn_readlane(incl, 31);
-    int fill = 0;
+    unsigned short *row_i = v.vrows + i * vcap;
+    const int tmax = 2 * s.tstride - SQ_TERMS_PAD;
+    int fill = 0, tcnt = 0;
     for (int base = 0; base < total; base += PMC_WAVE) {
         const int t = base + lane;
         int l = 0;
@@ -346,33 +383,83 @@ __device__ __forceinline__ bool sqv_update(const SqvArgs &s, const SqvView &v, i
         const int end_l = __shfl(incl, l, PMC_WAVE), len_l = __shfl(len, l, PMC_WAVE);
         bool in = false;
         int j = 0;
+        double u = 0.0;
         if (t < total) {
             j = v.crows[cc_l * ccap + (t - (end_l - len_l))];
             if (j != i) {
                 double xj[3] = {0, 0, 0};
 #pragma unroll
                 for (int q = 0; q < D; q++) xj[q] = v.pos[j * D + q];
-                in = sqv_dist2<D>(s, x, xj) < s.a.rcutoff2;
+                const double r2 = sqv_dist2<D>(s, x, xj);
+                in = r2 < s.a.rcutoff2;
+                if (WITH_E && in) {
+                    const DevModel &m = v.models[spi * S + ((S > 1) ? (int)v.species[j] : 0)];
+                    if (!(r2 > m.rcut2)) u = (KIND == 4 ? dev_potential_dyn(r2, m) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m));
+                }
             }
         }
         const unsigned long long mk = __ballot(in);
         if (in) {
             const int p = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-            const int nj = v.vcnt[j];
-            if (p < vcap && nj < vcap) {
-                row_i[p] = (unsigned short)j;
-                v.vrows[j * vcap + nj] = (unsigned short)i;
-                v.vcnt[j] = (unsigned short)(nj + 1);
-                v.dirty[j] = 1;
-            } else {
-                err |= SQV_ERR_ROW;
+            if (APPLY) {
+                const int nj = v.vcnt[j];
+                if (p < vcap && nj < vcap) {
+                    row_i[p] = (unsigned short)j;
+                    v.vrows[j * vcap + nj] = (unsigned short)i;
+                    v.vcnt[j] = (unsigned short)(nj + 1);
+                    v.dirty[j] = 1;
+                } else {
+                    err |= SQV_ERR_ROW;
+                }
+            } else if (p < vcap) {
+                lst[p] = (unsigned short)j;
             }
         }
         fill += __popcll(mk);
+        if (WITH_E) {
+            const unsigned long long mt = __ballot(u != 0.0);
+            const int r = tcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mt, 0u));
+            if (u != 0.0 && r < tmax) tb[r] = u;
+            tcnt = min(tcnt + __popcll(mt), tmax);
+        }
     }
+    if (WITH_E) {
+        if (lane < SQ_TERMS_PAD) tb[tcnt + lane] = 0.0;
+        sq_wave_sync();
+        e = sqv_chain(tb, tcnt, tcnt);                               // (every lane runs the same chain)
+        sq_wave_sync();
+    }
+    return fill;
+}
+
+// update_neighbour_list!(system, i, ::VerletList), src/neighbours.jl:494-543, on the LDS state; one wavefront (the resolver).
+// Nothing unless the particle is dr / 2 from its position at its last update; then i leaves every list it is in (order kept), its
+// cell vector is updated (filter! + push!), and its own list is rebuilt by scanning the neighbourhood in cell / vector order, i
+// appended to every new neighbour's list.  Returns true if the lists were rebuilt.
+// `last`: positions_at_last_update[i] (the caller has loaded it; it is x after a rebuild).
+template <int D>
+__device__ __forceinline__ bool sqv_update(const SqvArgs &s, const SqvView &v, int i, const double *x, double *last)
+{
+    const int lane = wave_lane();
+    double d2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; q++) {
+        const double dx = x[q] - last[q];
+        d2 = (q == 0) ? dx * dx : d2 + dx * dx;
+    }
+    if (d2 < s.a.dr2o4) return false;
+    SQVT_COUNT(9);
+    int err = sqv_leave_lists(s, v, i);
+    SQVT(5);
+    const int c = v.cs[i];
+    const int c2 = sq_cell_of_fast<D>(s.a, s.invcell, x);
+    if (c != c2) err |= sqv_cell_move(s, v, i, c, c2);
+    double dummy = 0.0;
+    const int fill = sqv_scan<D, 4, true, false>(s, v, i, 0, x, c2, nullptr, nullptr, dummy, err);
     if (lane == 0) {
-        v.vcnt[i] = (unsigned short)min(fill, vcap);
+        v.vcnt[i] = (unsigned short)min(fill, s.vcap);
         v.dirty[i] = 1;
+        v.cdirty[c2] = 1;
     }
     if (lane < D) v.last[i * D + lane] = sqv_sel3(x, lane);
 #pragma unroll
@@ -388,9 +475,9 @@ __device__ __forceinline__ bool sqv_update(const SqvArgs &s, const SqvView &v, i
     return true;
 }
 
-// One Displacement step of the chain on the current LDS state, by one wavefront, as the literal loop runs it (ref_disp_perform /
+// One Displacement step of the chain on the current LDS state, by the resolver, as the literal loop runs it (ref_disp_perform /
 // ref_disp_revert): e1, x += d, update_neighbour_list!, e2, accept or revert (+ update_neighbour_list! again).  Returns accepted.
-// have_e1: the step's evaluation of this batch stands as far as e1 goes (nobody has touched i or its row since) and its trial
+// have_e1: the step's evaluation stands as far as e1 goes (nobody has touched i or its row since it began) and its trial
 // position rebuilds the list: e1 is taken, e2 follows the rebuild.
 template <int D, int KIND>
 __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView &v, double *tb, int i, const SqGen &ge, double T, double &E,
@@ -408,11 +495,12 @@ __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView 
     }
     const int spi = (s.a.S > 1) ? (int)v.species[i] : 0;
     sqv_mark_row(s, v, i);
+    if (lane == 0) v.cdirty[v.cs[i]] = 1;
     double e1 = e1_in, e2 = 0.0, dummy;
     bool have_e2 = false;
     if (!have_e1) {
         // both sums over the row as it is: right unless the trial position rebuilds the list (then e2 is taken again)
-        sqv_energy2<D, KIND>(s, v, tb, i, spi, spi, -1, 0, x, xn, e1, e2);
+        sqv_energy2<D, KIND>(s, v, i, spi, spi, -1, 0, x, xn, e1, e2);
         have_e2 = true;
     }
     if (lane < D) v.pos[i * D + lane] = sqv_sel3(xn, lane);
@@ -422,7 +510,7 @@ __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView 
         nreb++;
         have_e2 = false;
     }
-    if (!have_e2) sqv_energy2<D, KIND>(s, v, tb, i, spi, spi, -1, 0, xn, xn, e2, dummy);
+    if (!have_e2) sqv_energy2<D, KIND>(s, v, i, spi, spi, -1, 0, xn, xn, e2, dummy);
     double de = 0.0;
     if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }            // src/moves.jl:13-18
     const bool ok = ge.lnu < -(e2 - e1) / T;
@@ -438,11 +526,108 @@ __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView 
     return ok;
 }
 
-template <int D, int NW, int KIND>
-__global__ __launch_bounds__(NW * 64) void k_sq_verlet(SqvArgs s)
+// An evaluator's work on one step: everything the resolver needs to take the step as it is, provided nobody touches its inputs.
+template <int D, int KIND>
+__device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v, double *tb, const SqGen &ge, double T, SqvSpec *out, unsigned short *lst)
+{
+    const RefArgs &a = s.a;
+    const int lane = wave_lane();
+    const int N = a.N, S = a.S;
+    SqvSpec sp;
+    sp.e1 = sp.de = 0.0;
+    sp.xw[0] = sp.xw[1] = sp.xw[2] = sp.xl[0] = sp.xl[1] = sp.xl[2] = 0.0;
+    sp.i = 0; sp.flags = SQV_SERIAL | (ge.m << 8);
+    sp.c0 = sp.c2 = sp.c3 = sp.nl = 0;
+    if (s.pool.kind[ge.m] == 0) {
+        const int i = (int)mulhi32(ge.r1, (uint32_t)N);
+        double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0}, xr[3] = {0, 0, 0}, last[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < D; q++) last[q] = v.last[i * D + q];     // (global: in flight behind the sums)
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            x[q] = v.pos[i * D + q];
+            xn[q] = x[q] + ge.d[q];
+            xr[q] = xn[q] + (-ge.d[q]);
+        }
+        const int spi = (S > 1) ? min((int)v.species[i], S - 1) : 0;
+        double e1, e2;
+        sqv_energy2<D, KIND>(s, v, i, spi, spi, -1, 0, x, xn, e1, e2);
+        double d2 = 0.0, d2r = 0.0, d2b = 0.0;
+        bool chg = false;
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            const double dx = xn[q] - last[q], dr_ = xr[q] - last[q], db = xr[q] - xn[q];
+            d2 = (q == 0) ? dx * dx : d2 + dx * dx;
+            d2r = (q == 0) ? dr_ * dr_ : d2r + dr_ * dr_;
+            d2b = (q == 0) ? db * db : d2b + db * db;
+            chg |= sq_bits_differ(xr[q], x[q]);
+        }
+        int fl = (ge.m << 8) | SQV_DISP;
+        sp.i = i;
+        sp.e1 = e1;
+        sp.c0 = (short)v.cs[i];
+        if (d2 < a.dr2o4) {
+            // the trial position keeps the list: e1 and e2 are sums over the same row, and the step is decided here
+            const bool fin = !(isinf(e1) || isinf(e2));
+            const bool ok = ge.lnu < -(e2 - e1) / T;
+            if (fin) { fl |= SQV_FINITE; sp.de = e2 - e1; }
+            if (ok) fl |= SQV_OK | SQV_CHG;
+            else if (chg) fl |= SQV_CHG | ((d2r < a.dr2o4) ? 0 : SQV_SERIAL);   // (an inexact revert that rebuilds the list: run alone)
+#pragma unroll
+            for (int q = 0; q < D; q++) sp.xw[q] = ok ? xn[q] : xr[q];
+        } else {
+            // the trial position rebuilds the list: the scan around its cell, e2 over the new list, the decision; a rejected step
+            // reverts, and rebuilds again if the reverted position is dr / 2 from the trial position (now the last update)
+            fl |= SQV_REBUILD;
+            int err = 0;
+            const int c2 = min(max(sq_cell_of_fast<D>(a, s.invcell, xn), 0), s.ncell - 1);   // (the clamp only ever bites on a position that raced with the resolver)
+            int nl = sqv_scan<D, KIND, false, true>(s, v, i, spi, xn, c2, lst, tb, e2, err);
+            const bool fin = !(isinf(e1) || isinf(e2));
+            const bool ok = ge.lnu < -(e2 - e1) / T;
+            if (fin) { fl |= SQV_FINITE; sp.de = e2 - e1; }
+            int c3 = c2;
+            if (ok) {
+                fl |= SQV_OK;
+            } else if (!(d2b < a.dr2o4)) {
+                fl |= SQV_REB2;
+                c3 = min(max(sq_cell_of_fast<D>(a, s.invcell, xr), 0), s.ncell - 1);
+                double dummy = 0.0;
+                nl = sqv_scan<D, KIND, false, false>(s, v, i, spi, xr, c3, lst, tb, dummy, err);
+            }
+            if (nl <= s.vcap) fl |= SQV_LIST | SQV_CHG;              // (a longer list: the resolver runs the step and reports the overflow)
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                sp.xw[q] = ok ? xn[q] : xr[q];
+                sp.xl[q] = (fl & SQV_REB2) ? xr[q] : xn[q];
+            }
+            sp.c2 = (short)c2; sp.c3 = (short)c3; sp.nl = (short)min(nl, s.vcap);
+        }
+        sp.flags = fl;
+    }
+    if (lane == 0) *out = sp;
+}
+
+// no mark, in either epoch, on any of the cells a scan around c2 reads
+template <int D>
+__device__ __forceinline__ bool sqv_cells_clean(const SqvView &v, int c2)
+{
+    constexpr int NN = (D == 3) ? 27 : 9;
+    const int lane = wave_lane();
+    const int cnt = v.nbrcnt[c2];
+    int f = 0;
+    if (lane < cnt) {
+        const int cc = v.nbr[c2 * NN + lane];
+        f = v.cdirty[cc] | v.cdirty_prev[cc];
+    }
+    return __ballot(f != 0) == 0ull;
+}
+
+template <int D, int KIND>
+__global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sqv_smem[];
     constexpr int NN = (D == 3) ? 27 : 9;
+    constexpr int NW = SQV_NW, NB = SQV_NB;
     const RefArgs &a = s.a;
     SqvChain &ch = s.chains[blockIdx.x];
     const int tid = threadIdx.x, nth = NW * 64, lane = wave_lane(), wv = tid >> 6;
@@ -451,7 +636,9 @@ __global__ __launch_bounds__(NW * 64) void k_sq_verlet(SqvArgs s)
     v.pos = reinterpret_cast<double *>(sqv_smem);
     v.last = ch.last_work;
     v.species = sqv_smem + s.o_species;
-    v.dirty = sqv_smem + s.o_dirty;
+    unsigned char *const dirty0 = sqv_smem + s.o_dirty, *const cdirty0 = sqv_smem + s.o_cdirty;
+    v.dirty = dirty0; v.dirty_prev = dirty0 + s.dstride;
+    v.cdirty = cdirty0; v.cdirty_prev = cdirty0 + s.cdstride;
     v.cs = reinterpret_cast<unsigned short *>(sqv_smem + s.o_cs);
     v.vcnt = reinterpret_cast<unsigned short *>(sqv_smem + s.o_vcnt);
     v.vrows = reinterpret_cast<unsigned short *>(sqv_smem + s.o_vrows);
@@ -460,9 +647,10 @@ __global__ __launch_bounds__(NW * 64) void k_sq_verlet(SqvArgs s)
     v.nbr = reinterpret_cast<unsigned short *>(sqv_smem + s.o_nbr);
     v.nbrcnt = reinterpret_cast<unsigned short *>(sqv_smem + s.o_nbrcnt);
     v.gen = reinterpret_cast<SqGen *>(sqv_smem + s.o_gen);
-    v.spec = reinterpret_cast<SqvSpec *>(sqv_smem + s.o_spec);
-    v.terms = reinterpret_cast<double *>(sqv_smem + s.o_terms);
     v.ctl = reinterpret_cast<int *>(sqv_smem + s.o_ctl);
+    SqvSpec *const spec0 = reinterpret_cast<SqvSpec *>(sqv_smem + s.o_spec);            // [2][NB]
+    unsigned short *const lst0 = reinterpret_cast<unsigned short *>(sqv_smem + s.o_lst);   // [2][NB][vcap]
+    double *const tb = reinterpret_cast<double *>(sqv_smem + s.o_terms) + (size_t)wv * 2 * s.tstride;
     {
         DevModel *lm = reinterpret_cast<DevModel *>(sqv_smem + s.o_models);
         const int *src = reinterpret_cast<const int *>(a.models);
@@ -470,8 +658,14 @@ __global__ __launch_bounds__(NW * 64) void k_sq_verlet(SqvArgs s)
         for (int k = tid; k < S * S * (int)(sizeof(DevModel) / sizeof(int)); k += nth) dst[k] = src[k];
         v.models = lm;
     }
-    // -- the chain's state into LDS
+    // -- the chain's state into LDS (rows, cell vectors and marks zero-filled first: whatever an evaluator reads is a valid id)
     if (tid == 0) v.ctl[0] = 0;
+    for (int k = tid; k < (N * vcap + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.vrows)[k] = 0u;
+    for (int k = tid; k < (s.ncell * ccap + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.crows)[k] = 0u;
+    for (int k = tid; k < 3 * s.dstride / 4; k += nth) reinterpret_cast<unsigned int *>(dirty0)[k] = 0u;
+    for (int k = tid; k < 3 * s.cdstride / 4; k += nth) reinterpret_cast<unsigned int *>(cdirty0)[k] = 0u;
+    for (int k = tid; k < 2 * NB * (int)(sizeof(SqvSpec) / 4); k += nth) reinterpret_cast<unsigned int *>(spec0)[k] = 0u;
+    for (int k = tid; k < NB * vcap; k += nth) reinterpret_cast<unsigned int *>(lst0)[k] = 0u;
     __syncthreads();
     int lerr = 0;
     for (int k = tid; k < s.ncell * NN; k += nth) v.nbr[k] = (unsigned short)a.nbr[(size_t)(k / NN) * a.nnmax + (k % NN)];
@@ -502,166 +696,199 @@ __global__ __launch_bounds__(NW * 64) void k_sq_verlet(SqvArgs s)
     if (ch.sp_ids_work) for (int k = tid; k < N; k += nth) { ch.sp_ids_work[k] = ch.sp_ids[k]; ch.sp_heads_work[k] = ch.sp_heads[k]; }
     __syncthreads();
     double E = ch.energy;
-    const double T = ch.temperature, T_ = T;
-    unsigned long long att[8], acc[8], nser = 0, nreb = 0, nbat = 0;
+    const double T = ch.temperature;
+    unsigned long long att[8], acc[8], nser = 0, nreb = 0, nbat = 0, napp = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) { att[q] = 0; acc[q] = 0; }
-    double *tb = v.terms + (size_t)wv * 2 * s.tstride;
-    const unsigned long long gend = ch.step0 + (unsigned long long)s.nsteps;
+    const long long nsteps = s.nsteps;
+    const long long nbatch = (nsteps + NB - 1) / NB;
+    const int ev = (wv == 0 || wv == 4) ? -1 : (wv < 4 ? wv - 1 : wv - 2);      // evaluator slot 0 .. 5
+    // the words and operations of k_ref_ops for step t of the launch, into the ring of random parts
+    auto generate = [&](long long t) {
+        const unsigned long long g = ch.step0 + (unsigned long long)t;
+        uint32_t R[4], Q[4];
+        philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, ch.key0, ch.key1, R);
+        philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ1, ch.key0, ch.key1, Q);
+        SqGen o;
+        o.m = select_move(s.pool, R[0]);
+        o.lnu = det_log(uniform53(R[2], R[3]));
+        o.r1 = R[1]; o.q0 = Q[0]; o.pad = 0;
+        o.d[0] = o.d[1] = o.d[2] = 0.0;
+        if (s.pool.kind[o.m] == 0) {
+            double z[4];
+            box_muller(Q[0], Q[1], &z[0], &z[1]);
+            box_muller(Q[2], Q[3], &z[2], &z[3]);
+            for (int q = 0; q < 3; q++) o.d[q] = s.pool.sigma[o.m] * z[q];
+        }
+        v.gen[t & (SQV_GEN - 1)] = o;
+    };
     bool dead = v.ctl[0] != 0;
-    for (unsigned long long g0 = ch.step0; g0 < gend && !dead; g0 += SQV_GEN) {
-        if (tid < SQV_GEN) {
-            // the words and operations of k_ref_ops for step g
-            const unsigned long long g = g0 + (unsigned long long)tid;
-            uint32_t R[4], Q[4];
-            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, ch.key0, ch.key1, R);
-            philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ1, ch.key0, ch.key1, Q);
-            SqGen o;
-            o.m = select_move(s.pool, R[0]);
-            o.lnu = det_log(uniform53(R[2], R[3]));
-            o.r1 = R[1]; o.q0 = Q[0]; o.pad = 0;
-            o.d[0] = o.d[1] = o.d[2] = 0.0;
-            if (s.pool.kind[o.m] == 0) {
-                double z[4];
-                box_muller(Q[0], Q[1], &z[0], &z[1]);
-                box_muller(Q[2], Q[3], &z[2], &z[3]);
-                for (int q = 0; q < 3; q++) o.d[q] = s.pool.sigma[o.m] * z[q];
+    long long gen_done = 1;                                     // blocks of 64 steps generated so far: 0 and 1, here
+    if (tid < SQV_GEN && tid < nsteps) generate(tid);
+    __syncthreads();
+    // batch 0 is evaluated before the pipeline starts
+    if (ev >= 0 && ev < nsteps && !dead) sqv_evaluate<D, KIND>(s, v, tb, v.gen[ev], T, spec0 + ev, lst0 + ev * vcap);
+    __syncthreads();
+    for (long long b = 0; b < nbatch && !dead; b++) {
+        const int cur = (int)(b & 1);
+        const int ep = (int)(b % 3), ep_prev = (ep + 2) % 3, ep_next = (ep + 1) % 3;   // marks: this batch's, the one before's, the next one's (being cleared)
+        if (wv == 0) {
+            // ---- the resolver: batch b in step order
+            SQVT(0);
+            v.dirty = dirty0 + ep * s.dstride; v.dirty_prev = dirty0 + ep_prev * s.dstride;
+            v.cdirty = cdirty0 + ep * s.cdstride; v.cdirty_prev = cdirty0 + ep_prev * s.cdstride;
+            nbat++;
+            const int nb = (int)min((long long)NB, nsteps - b * NB);
+            SqvSpec spn = spec0[cur * NB];
+            for (int k = 0; k < nb; k++) {
+                SQVM("step_begin");
+                const SqvSpec sp = spn;
+                if (k + 1 < nb) spn = spec0[cur * NB + k + 1];       // (nothing in this loop writes the evaluators' records: in flight behind this step)
+                const unsigned short *lst = lst0 + (cur * NB + k) * vcap;
+                const long long t = b * NB + k;
+                const int m = (sp.flags >> 8) & 7;
+                bool ok = false;
+                if (sp.flags & SQV_DISP) {
+                    const int i = sp.i;
+                    // (one round trip: the marks of i, and its row in case the step stores a position)
+                    const int di = v.dirty[i] | v.dirty_prev[i];
+                    const int ni_ = v.vcnt[i];
+                    const int rj_ = (lane < vcap) ? (int)v.vrows[i * vcap + lane] : 0;
+                    const bool clean = !di;
+                    if (clean && !(sp.flags & (SQV_SERIAL | SQV_REBUILD))) {
+                        // nobody has touched i or its row since the evaluation began: the evaluation is the step
+                        ok = (sp.flags & SQV_OK) != 0;
+                        if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }     // src/moves.jl:17,79
+                        if (sp.flags & SQV_CHG) {
+                            // (the stored position is within dr / 2 of the last update: update_neighbour_list! returns at once)
+                            if (lane < D) v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
+                            if (lane < ni_) v.dirty[rj_] = 1;
+                            for (int q = PMC_WAVE + lane; q < ni_; q += PMC_WAVE) v.dirty[v.vrows[i * vcap + q]] = 1;
+                            if (lane == 0) { v.dirty[i] = 1; v.cdirty[sp.c0] = 1; }
+                        }
+                        SQVM("clean_end");
+                        SQVT(2);
+                    } else if (clean && (sp.flags & SQV_LIST) && sqv_cells_clean<D>(v, sp.c2) && (!(sp.flags & SQV_REB2) || sqv_cells_clean<D>(v, sp.c3))) {
+                        // ... and nobody has touched the cells its scan read: the rebuild is applied from the evaluator's list.
+                        // Net effect of update_neighbour_list! at the trial position (and again at the reverted one, REB2): i has
+                        // left its old neighbours' lists and is appended to those of the final list; the cell vectors took
+                        // every move in turn
+                        ok = (sp.flags & SQV_OK) != 0;
+                        if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }
+                        int err = sqv_leave_lists(s, v, i);
+                        const int c = v.cs[i];
+                        if (c != sp.c2) err |= sqv_cell_move(s, v, i, c, sp.c2);
+                        if (sp.c3 != sp.c2) err |= sqv_cell_move(s, v, i, sp.c2, sp.c3);
+                        unsigned short *row_i = v.vrows + i * vcap;
+                        const int nl = sp.nl;
+                        for (int q = lane; q < nl; q += PMC_WAVE) {
+                            const int j = lst[q];
+                            const int nj = v.vcnt[j];
+                            if (nj < vcap) {
+                                v.vrows[j * vcap + nj] = (unsigned short)i;
+                                v.vcnt[j] = (unsigned short)(nj + 1);
+                                v.dirty[j] = 1;
+                            } else {
+                                err |= SQV_ERR_ROW;
+                            }
+                            row_i[q] = (unsigned short)j;
+                        }
+                        if (lane == 0) {
+                            v.vcnt[i] = (unsigned short)nl;
+                            v.dirty[i] = 1;
+                            v.cdirty[c] = 1;
+                            v.cdirty[sp.c3] = 1;
+                        }
+                        if (lane < D) {
+                            v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
+                            v.last[i * D + lane] = sqv_sel3(sp.xl, lane);
+                        }
+                        if (__ballot(err != 0)) {
+                            int e = err;
+#pragma unroll
+                            for (int sft = 32; sft >= 1; sft >>= 1) e |= __shfl_xor(e, sft, PMC_WAVE);
+                            if (lane == 0) v.ctl[0] |= e;
+                        }
+                        nreb += (sp.flags & SQV_REB2) ? 2 : 1;
+                        napp++;
+                        sq_wave_sync();
+                        SQVT_COUNT(10);
+                        SQVT(3);
+                    } else {
+                        nser++;
+                        SQVT_COUNT(11);
+                        const SqGen ge = v.gen[t & (SQV_GEN - 1)];
+                        ok = sqv_disp_serial<D, KIND>(s, v, tb, i, ge, T, E, nreb, clean && (sp.flags & SQV_REBUILD), sp.e1);
+                    }
+                } else {
+                    // DiscreteSwap (src/moves.jl:137-207): four sums, species exchange, SpeciesList fix-up; the SpeciesList
+                    // stays in global memory (the launch's working copy: this wavefront is its only reader and writer)
+                    nser++;
+                    const SqGen ge = v.gen[t & (SQV_GEN - 1)];
+                    const int sa = s.pool.sp0[m], sb = s.pool.sp1[m];
+                    const int oa = ch.sp_off[sa], ob = ch.sp_off[sb];
+                    const int na = ch.sp_off[sa + 1] - oa, nbb = ch.sp_off[sb + 1] - ob;
+                    if (na > 0 && nbb > 0) {
+                        const int i = ch.sp_ids_work[oa + mulhi32(ge.r1, (uint32_t)na)];
+                        const int j = ch.sp_ids_work[ob + mulhi32(ge.q0, (uint32_t)nbb)];
+                        double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
+#pragma unroll
+                        for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
+                        const int spi = v.species[i], spj = v.species[j];
+                        double e1i, e2i, e1j, e2j;
+                        sqv_energy2<D, KIND>(s, v, i, spi, spj, j, spi, xi, xi, e1i, e2i);
+                        sqv_energy2<D, KIND>(s, v, j, spj, spi, i, spj, xj, xj, e1j, e2j);
+                        const double e1 = e1i + e1j, e2 = e2i + e2j;
+                        double de = 0.0;
+                        if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
+                        ok = ge.lnu < -(e2 - e1) / T;
+                        if (ok) {
+                            sqv_mark_row(s, v, i);
+                            sqv_mark_row(s, v, j);
+                            if (lane == 0) {
+                                v.species[i] = (unsigned char)spj;
+                                v.species[j] = (unsigned char)spi;
+                                v.cdirty[v.cs[i]] = 1;
+                                v.cdirty[v.cs[j]] = 1;
+                                // update_species_list!, src/moves.jl:175-179
+                                const int hi_ = ch.sp_heads_work[i], hj_ = ch.sp_heads_work[j];
+                                ch.sp_ids_work[oa + hi_] = j;
+                                ch.sp_ids_work[ob + hj_] = i;
+                                ch.sp_heads_work[i] = hj_;
+                                ch.sp_heads_work[j] = hi_;
+                            }
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_wave_barrier();
+                        } else {
+                            E -= de;                                             // src/moves.jl:206
+                        }
+                    }
+                    SQVT(8);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    att[q] += (q == m);
+                    acc[q] += (q == m && ok);
+                }
             }
-            v.gen[tid] = o;
+        } else if (wv == 4) {
+            // ---- the generator: the marks of the next batch's resolution cleared, and the random parts the evaluators read in the
+            // NEXT trip of this loop (batch b + 2)
+            for (int k = lane; k < s.dstride / 4; k += PMC_WAVE) reinterpret_cast<unsigned int *>(dirty0 + ep_next * s.dstride)[k] = 0u;
+            for (int k = lane; k < s.cdstride / 4; k += PMC_WAVE) reinterpret_cast<unsigned int *>(cdirty0 + ep_next * s.cdstride)[k] = 0u;
+            const long long need = min((long long)NB * (b + 3) - 1, nsteps - 1) >> 6;
+            if (need > gen_done) {
+                const long long t = (need << 6) + lane;
+                if (t < nsteps) generate(t);
+                gen_done = need;
+            }
+        } else {
+            // ---- an evaluator: one step of batch b + 1
+            const long long t = (long long)NB * (b + 1) + ev;
+            if (t < nsteps) sqv_evaluate<D, KIND>(s, v, tb, v.gen[t & (SQV_GEN - 1)], T, spec0 + (cur ^ 1) * NB + ev, lst0 + ((cur ^ 1) * NB + ev) * vcap);
         }
         __syncthreads();
-        SQVT(0);
-        const int ng = (int)min((unsigned long long)SQV_GEN, gend - g0);
-        for (int b0 = 0; b0 < ng && !dead; b0 += NW) {
-            const int nb = min(NW, ng - b0);
-            // ---- phase A: wavefront w evaluates step b0 + w against the state as it is now
-            for (int k = tid; k < (N + 3) / 4; k += nth) reinterpret_cast<unsigned int *>(v.dirty)[k] = 0u;
-            if (wv < nb) {
-                const SqGen ge = v.gen[b0 + wv];
-                SqvSpec sp;
-                sp.e1 = sp.de = sp.pad = 0.0; sp.xw[0] = sp.xw[1] = sp.xw[2] = 0.0; sp.i = 0; sp.flags = SQV_SERIAL | (ge.m << 8);
-                if (s.pool.kind[ge.m] == 0) {
-                    const int i = (int)mulhi32(ge.r1, (uint32_t)N);
-                    double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0}, xr[3] = {0, 0, 0}, last[3] = {0, 0, 0};
-#pragma unroll
-                    for (int q = 0; q < D; q++) last[q] = v.last[i * D + q];     // (global: in flight behind the sums)
-#pragma unroll
-                    for (int q = 0; q < D; q++) {
-                        x[q] = v.pos[i * D + q];
-                        xn[q] = x[q] + ge.d[q];
-                        xr[q] = xn[q] + (-ge.d[q]);
-                    }
-                    const int spi = (S > 1) ? (int)v.species[i] : 0;
-                    double e1, e2;
-                    sqv_energy2<D, KIND>(s, v, tb, i, spi, spi, -1, 0, x, xn, e1, e2);
-                    double d2 = 0.0, d2r = 0.0;
-                    bool chg = false;
-#pragma unroll
-                    for (int q = 0; q < D; q++) {
-                        const double dx = xn[q] - last[q], dr_ = xr[q] - last[q];
-                        d2 = (q == 0) ? dx * dx : d2 + dx * dx;
-                        d2r = (q == 0) ? dr_ * dr_ : d2r + dr_ * dr_;
-                        chg |= sq_bits_differ(xr[q], x[q]);
-                    }
-                    int fl = ge.m << 8;
-                    sp.i = i;
-                    sp.e1 = e1;
-                    if (d2 < a.dr2o4) {
-                        // the trial position keeps the list: e1 and e2 are sums over the same row, and the step is decided here
-                        const bool fin = !(isinf(e1) || isinf(e2));
-                        const bool ok = ge.lnu < -(e2 - e1) / T_;
-                        if (fin) { fl |= SQV_FINITE; sp.de = e2 - e1; }
-                        if (ok) fl |= SQV_OK | SQV_CHG;
-                        else if (chg) fl |= SQV_CHG | ((d2r < a.dr2o4) ? 0 : SQV_SERIAL);   // (an inexact revert that rebuilds the list: run alone)
-#pragma unroll
-                        for (int q = 0; q < D; q++) sp.xw[q] = ok ? xn[q] : xr[q];
-                    } else {
-                        fl |= SQV_REBUILD;
-                    }
-                    sp.flags = fl;
-                }
-                if (lane == 0) v.spec[wv] = sp;
-            }
-            __syncthreads();
-            SQVT(1);
-            // ---- phase B: wavefront 0 takes the steps in order
-            if (wv == 0) {
-                nbat++;
-                for (int k = 0; k < nb; k++) {
-                    const SqvSpec sp = v.spec[k];
-                    const int m = (sp.flags >> 8) & 7;
-                    bool ok = false;
-                    if (s.pool.kind[m] == 0) {
-                        const int i = sp.i;
-                        const bool clean = !v.dirty[i];
-                        if (clean && !(sp.flags & (SQV_SERIAL | SQV_REBUILD))) {
-                            // nobody has touched i or its row since the batch started: the evaluation is the step
-                            ok = (sp.flags & SQV_OK) != 0;
-                            if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }     // src/moves.jl:17,79
-                            if (sp.flags & SQV_CHG) {
-                                // (the stored position is within dr / 2 of the last update: update_neighbour_list! returns at once)
-                                if (lane < D) v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
-                                sqv_mark_row(s, v, i);
-                            }
-                            SQVT(3);
-                        } else {
-                            nser++;
-                            const SqGen ge = v.gen[b0 + k];
-                            ok = sqv_disp_serial<D, KIND>(s, v, tb, i, ge, T, E, nreb, clean && (sp.flags & SQV_REBUILD), sp.e1);
-                        }
-                    } else {
-                        // DiscreteSwap (src/moves.jl:137-207): four sums, species exchange, SpeciesList fix-up; the SpeciesList
-                        // stays in global memory (the launch's working copy: this wavefront is its only reader and writer)
-                        nser++;
-                        const SqGen ge = v.gen[b0 + k];
-                        const int sa = s.pool.sp0[m], sb = s.pool.sp1[m];
-                        const int oa = ch.sp_off[sa], ob = ch.sp_off[sb];
-                        const int na = ch.sp_off[sa + 1] - oa, nbb = ch.sp_off[sb + 1] - ob;
-                        if (na > 0 && nbb > 0) {
-                            const int i = ch.sp_ids_work[oa + mulhi32(ge.r1, (uint32_t)na)];
-                            const int j = ch.sp_ids_work[ob + mulhi32(ge.q0, (uint32_t)nbb)];
-                            double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
-#pragma unroll
-                            for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
-                            const int spi = v.species[i], spj = v.species[j];
-                            double e1i, e2i, e1j, e2j;
-                            sqv_energy2<D, KIND>(s, v, tb, i, spi, spj, j, spi, xi, xi, e1i, e2i);
-                            sqv_energy2<D, KIND>(s, v, tb, j, spj, spi, i, spj, xj, xj, e1j, e2j);
-                            const double e1 = e1i + e1j, e2 = e2i + e2j;
-                            double de = 0.0;
-                            if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
-                            ok = ge.lnu < -(e2 - e1) / T;
-                            if (ok) {
-                                sqv_mark_row(s, v, i);
-                                sqv_mark_row(s, v, j);
-                                if (lane == 0) {
-                                    v.species[i] = (unsigned char)spj;
-                                    v.species[j] = (unsigned char)spi;
-                                    // update_species_list!, src/moves.jl:175-179
-                                    const int hi_ = ch.sp_heads_work[i], hj_ = ch.sp_heads_work[j];
-                                    ch.sp_ids_work[oa + hi_] = j;
-                                    ch.sp_ids_work[ob + hj_] = i;
-                                    ch.sp_heads_work[i] = hj_;
-                                    ch.sp_heads_work[j] = hi_;
-                                }
-                                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                                __builtin_amdgcn_wave_barrier();
-                            } else {
-                                E -= de;                                             // src/moves.jl:206
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        att[q] += (q == m);
-                        acc[q] += (q == m && ok);
-                    }
-                }
-            }
-            __syncthreads();
-            SQVT(2);
-            dead = v.ctl[0] != 0;
-        }
+        dead = v.ctl[0] != 0;
     }
     __syncthreads();
     if (dead) {
@@ -689,8 +916,8 @@ __global__ __launch_bounds__(NW * 64) void k_sq_verlet(SqvArgs s)
     }
     if (tid == 0) {
         ch.energy = E;
-        ch.step0 = gend;
+        ch.step0 += (unsigned long long)nsteps;
         for (int q = 0; q < 8; q++) { ch.att[q] += att[q]; ch.acc[q] += acc[q]; }
-        ch.n_serial += nser; ch.n_rebuild += nreb; ch.n_batches += nbat;
+        ch.n_serial += nser; ch.n_rebuild += nreb; ch.n_batches += nbat; ch.n_applied += napp;
     }
 }
