@@ -995,8 +995,8 @@ static int sweep_sequential_verlet(pmc_system **hs, int n, const pmc_move *pool,
     if (getenv("PMC_SQV_TIMES")) {                          // stamped builds (-DPMC_DEBUG_TIME on pmc_verlet_inst.hip): chain 0's phase clock
         unsigned long long t[16];
         pmc_sqv_times(t);
-        fprintf(stderr, "sqv phase clock (resolver, s_memtime ticks): barrier %llu  clear %llu | taken %llu  applied %llu  alone-to-update %llu  leave-lists %llu  scan %llu  rest %llu  swaps %llu | own rebuilds %llu  applied %llu  alone %llu  (%.2f ms; chain 0: %llu batches, %llu alone, %llu rebuilds, %llu applied)\n",
-                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], ms, tab[0].n_batches, tab[0].n_serial, tab[0].n_rebuild, tab[0].n_applied);
+        fprintf(stderr, "sqv phase clock (resolver, s_memtime ticks): wait %llu  step-overhead %llu | taken %llu  applied %llu  alone-to-update %llu  leave-lists %llu  scan %llu  rest %llu  swaps %llu | own rebuilds %llu  applied %llu  alone %llu | evaluator 0 plain %llu; spins %llu in %llu steps that waited  (%.2f ms; chain 0: %llu batches, %llu alone, %llu rebuilds, %llu applied)\n",
+                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], ms, tab[0].n_batches, tab[0].n_serial, tab[0].n_rebuild, tab[0].n_applied);
     }
     for (int r = 0; r < n; r++) {
         pmc_system *h = hs[r];
@@ -1020,7 +1020,14 @@ static int sweep_sequential_verlet(pmc_system **hs, int n, const pmc_move *pool,
             o.sweep_kernel_launches = launches;
             o.energy = h->energy;
         }
-        if (c.err & SQV_ERR_LIST) return fail(h, PMC_ERR_STATE, "sequential engine 4: a particle was missing from a neighbour's list or from its cell vector");
+        // (a list that overflowed leaves the step half-applied: a particle missing further on in the SAME step -- the second cell move of a
+        // step whose first found the cell full -- is part of that overflow, not an inconsistency of the lists)
+        if ((c.err & SQV_ERR_LIST) && !(c.err & (SQV_ERR_ROW | SQV_ERR_CELL | SQV_ERR_LOAD))) {
+            static char msg[256];
+            snprintf(msg, sizeof msg, "sequential engine 4: a particle was missing from a neighbour's list or from its cell vector (site %d: particle %d, %s %d of %d ids)",
+                     c.dbg[0], c.dbg[1], c.dbg[0] == 3 ? "cell" : "neighbour", c.dbg[2], c.dbg[3]);
+            return fail(h, PMC_ERR_STATE, msg);
+        }
     }
     return PMC_OK;
 }

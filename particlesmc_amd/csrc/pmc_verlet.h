@@ -34,8 +34,11 @@
 #include "pmc_seq.h"
 
 #define SQV_GEN 128               // ring of random parts: two blocks of 64 steps
-#define SQV_NW 8                  // wavefronts of a chain's workgroup: resolver, generator, six evaluators
-#define SQV_NB 6                  // steps of a batch = evaluators
+#define SQV_NW 16                 // wavefronts of a chain's workgroup: wavefront 0 resolves, 4 generates, 8 and 12 (the resolver's other SIMD mates) idle
+#define SQV_NB 12                 // evaluators (wavefronts 1-3, 5-7, 9-11, 13-15): evaluator e takes the steps t = e (mod SQV_NB)
+#ifndef SQV_LOOK
+#define SQV_LOOK 7                // an evaluator begins step t once the resolver has finished step t - SQV_LOOK - 1 (< SQV_NB: its record is free by then)
+#endif
 #define SQV_HW 10                 // rows of 4 * SQV_HW ids leave a list in registers (sqv_leave_lists)
 
 struct SqvArgs;
@@ -84,10 +87,11 @@ struct SqvChain {                 // per-chain arguments (device table)
     double energy;                // in: system.energy[1]; out: after the steps
     double temperature;
     unsigned long long att[8], acc[8];                   // out (added to)
-    unsigned long long n_serial, n_rebuild, n_batches;   // diagnostics (added to): steps the resolver ran alone, list rebuilds, batches
+    unsigned long long n_serial, n_rebuild, n_batches;   // diagnostics (added to): steps the resolver ran alone, list rebuilds, polls of the resolver for a record that was not ready
     unsigned long long n_applied;                        // ... rebuilds applied from an evaluator's list
     int err;                      // SQV_ERR_*: the launch changed nothing
     int pad;
+    int dbg[4];                   // SQV_ERR_LIST: where (1, 2 a neighbour's list, 3 a cell vector), i, the neighbour or cell, its length
 };
 
 struct SqvArgs {
@@ -100,8 +104,7 @@ struct SqvArgs {
     int ncell;
     int vcap, ccap;               // LDS capacities of a Verlet row (multiple of 4) and of a cell vector
     int tstride;                  // doubles of one half of a wavefront's terms buffer
-    int dstride, cdstride;        // bytes of one epoch of the particle / cell marks
-    int o_species, o_cs, o_vcnt, o_vrows, o_ccnt, o_crows, o_dirty, o_cdirty, o_gen, o_spec, o_lst, o_models, o_nbr, o_nbrcnt, o_terms, o_ctl;
+    int o_species, o_cs, o_vcnt, o_vrows, o_ccnt, o_crows, o_touch, o_ctouch, o_gen, o_spec, o_lst, o_models, o_nbr, o_nbrcnt, o_terms, o_ctl;
 };
 
 struct __attribute__((aligned(16))) SqvSpec {       // evaluator -> resolver
@@ -110,19 +113,60 @@ struct __attribute__((aligned(16))) SqvSpec {       // evaluator -> resolver
     double xl[3];                 // LIST: positions_at_last_update after the step
     int i, flags;
     short c0, c2, c3, nl;         // the cell of i when the step was evaluated; LIST: cell of the trial position, of the reverted position (REB2), ids of the list
+    int s0;                       // the steps the resolver had finished when the evaluation began: a mark by any later step voids it
+    int seq;                      // step + 1 once the record is complete (stored last, read first)
+    int pad0, pad1;
 };
 
 struct SqvView {
     double *pos;
     double *last;                 // positions_at_last_update: the launch's working copy in GLOBAL memory
     unsigned char *species;
-    unsigned char *dirty, *dirty_prev;       // particle marks of this batch's resolution and of the one before (during which this batch was evaluated); a third epoch is being cleared
-    unsigned char *cdirty, *cdirty_prev;     // ... and the same for cells: a particle of the cell moved, entered, left or changed species
+    unsigned short *touch;        // per particle: the step (its number in the launch + 1, low 16 bits) that last moved, re-listed or re-labelled it or a member of its list
+    unsigned short *ctouch;       // per cell: ... that last moved a particle of the cell, put one in, took one out or re-labelled one
+    unsigned short stamp;         // the resolver's current step, as the marks store it
     unsigned short *cs, *vcnt, *vrows, *ccnt, *crows, *nbr, *nbrcnt;
     SqGen *gen;
     const DevModel *models;
     int *ctl;                     // [0]: SQV_ERR_* of this launch
 };
+
+// LDS words the wavefronts of the pipeline talk through (workgroup scope; LDS operations of one wavefront execute in order)
+__device__ __forceinline__ int sqv_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void sqv_st(int *p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int sqv_ld_relaxed(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void sqv_st_relaxed(int *p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// An evaluator's record as the resolver takes it.  What every step needs -- the 16 bytes with the sequence number FIRST (the LDS
+// takes a wavefront's operations in order; the evaluator stores that number last), then i / flags / cells, e1 / de and the
+// position to store -- is requested while the resolver is busy with the step before, and used only when that step is over.
+// `zero` is a 0 the compiler cannot see through: the address looks lane-dependent, so the values stay in vector registers
+// (no v_readfirstlane, hence no wait, right behind the request) until sqv_rec_decode asks for them.
+typedef unsigned int sqv_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sqv_u2 __attribute__((ext_vector_type(2)));
+struct SqvRaw { sqv_u2 q5; sqv_u4 q4, q0, q1; };
+__device__ __forceinline__ void sqv_rec_request(const SqvSpec *rec, int zero, SqvRaw &r)
+{
+    const sqv_u4 *p = reinterpret_cast<const sqv_u4 *>(reinterpret_cast<const unsigned char *>(rec) + zero);
+    r.q5 = *reinterpret_cast<const sqv_u2 *>(p + 5);            // (s0, seq: no more than is used -- a register of a pending request that is reused elsewhere makes the compiler wait for the request)
+    asm volatile("" ::: "memory");
+    r.q4 = p[4];
+    r.q0 = p[0];
+    r.q1 = p[1];
+}
+__device__ __forceinline__ double sqv_dbl(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ void sqv_rec_decode(const SqvRaw &r, SqvSpec &sp)
+{
+    sp.e1 = sqv_dbl(r.q0.x, r.q0.y); sp.de = sqv_dbl(r.q0.z, r.q0.w);
+    sp.xw[0] = sqv_dbl(r.q1.x, r.q1.y); sp.xw[1] = sqv_dbl(r.q1.z, r.q1.w);
+    sp.i = __builtin_amdgcn_readfirstlane((int)r.q4.x);
+    sp.flags = __builtin_amdgcn_readfirstlane((int)r.q4.y);
+    const int cz = __builtin_amdgcn_readfirstlane((int)r.q4.z), cw = __builtin_amdgcn_readfirstlane((int)r.q4.w);
+    sp.c0 = (short)(cz & 0xffff); sp.c2 = (short)(cz >> 16); sp.c3 = (short)(cw & 0xffff); sp.nl = (short)(cw >> 16);
+    sp.s0 = __builtin_amdgcn_readfirstlane((int)r.q5.x);
+    sp.seq = __builtin_amdgcn_readfirstlane((int)r.q5.y);
+    sp.pad0 = sp.pad1 = 0;
+}
 
 // a[lane] for lane < 3 without indexing registers by a lane number
 __device__ __forceinline__ double sqv_sel3(const double *a, int lane) { return lane == 0 ? a[0] : (lane == 1 ? a[1] : a[2]); }
@@ -229,8 +273,8 @@ __device__ __forceinline__ void sqv_mark_row(const SqvArgs &s, const SqvView &v,
     const int lane = wave_lane();
     const int n = v.vcnt[i];
     const unsigned short *row = v.vrows + i * s.vcap;
-    for (int q = lane; q < n; q += PMC_WAVE) v.dirty[row[q]] = 1;
-    if (lane == 0) v.dirty[i] = 1;
+    for (int q = lane; q < n; q += PMC_WAVE) v.touch[row[q]] = v.stamp;
+    if (lane == 0) v.touch[i] = v.stamp;
 }
 
 // i leaves the lists of its neighbours (deleteat! in src/neighbours.jl:508-511: the order of what stays is kept); every
@@ -278,7 +322,7 @@ __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &
                 }
 #pragma unroll
                 for (int k = 0; k < SQV_HW; k++) rw[k] = w[k];
-                if (hf == 0) { v.vcnt[j] = (unsigned short)(n - 1); v.dirty[j] = 1; }
+                if (hf == 0) { v.vcnt[j] = (unsigned short)(n - 1); v.touch[j] = v.stamp; }
             }
         }
     } else {
@@ -296,7 +340,7 @@ __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &
                     const int a = (lane < n) ? (int)rj[lane] : -1;
                     const int b = (lane + 1 < n) ? (int)rj[lane + 1] : 0;
                     const unsigned long long mk = __ballot(a == i);
-                    if (!mk) err |= SQV_ERR_LIST;
+                    if (!mk) { err |= SQV_ERR_LIST; if (lane == 0) { v.ctl[20] = 1; v.ctl[21] = i; v.ctl[22] = j; v.ctl[23] = n; } }
                     const int p = mk ? (int)__builtin_ctzll(mk) : n;
                     if (lane >= p && lane + 1 < n) rj[lane] = (unsigned short)b;
                 } else {
@@ -306,7 +350,7 @@ __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &
                         const unsigned long long mk = __ballot(k < n && (int)rj[k] == i);
                         if (mk) p = base + (int)__builtin_ctzll(mk);
                     }
-                    if (p < 0) { err |= SQV_ERR_LIST; p = n; }
+                    if (p < 0) { err |= SQV_ERR_LIST; p = n; if (lane == 0) { v.ctl[20] = 2; v.ctl[21] = i; v.ctl[22] = j; v.ctl[23] = n; } }
                     for (int base = p; base < n - 1; base += PMC_WAVE) {
                         const int k = base + lane;
                         unsigned short t = 0;
@@ -317,7 +361,7 @@ __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &
                     }
                 }
             }
-            if (lane < qn) { v.vcnt[jq] = (unsigned short)(nq - 1); v.dirty[jq] = 1; }
+            if (lane < qn) { v.vcnt[jq] = (unsigned short)(nq - 1); v.touch[jq] = v.stamp; }
         }
     }
     sq_wave_sync();
@@ -336,7 +380,7 @@ __device__ __forceinline__ int sqv_cell_move(const SqvArgs &s, const SqvView &v,
     const int a = (lane < n) ? (int)rc[lane] : -1;
     const int b = (lane + 1 < n) ? (int)rc[lane + 1] : 0;
     const unsigned long long mk = __ballot(a == i);
-    if (!mk) err |= SQV_ERR_LIST;
+    if (!mk) { err |= SQV_ERR_LIST; if (lane == 0) { v.ctl[20] = 3; v.ctl[21] = i; v.ctl[22] = c; v.ctl[23] = n; } }
     const int p = mk ? (int)__builtin_ctzll(mk) : n;
     if (lane >= p && lane + 1 < n) rc[lane] = (unsigned short)b;
     const int n2 = v.ccnt[c2];
@@ -345,8 +389,8 @@ __device__ __forceinline__ int sqv_cell_move(const SqvArgs &s, const SqvView &v,
         v.ccnt[c] = (unsigned short)(mk ? n - 1 : n);
         if (n2 < ccap) { v.crows[c2 * ccap + n2] = (unsigned short)i; v.ccnt[c2] = (unsigned short)(n2 + 1); }
         v.cs[i] = (unsigned short)c2;
-        v.cdirty[c] = 1;
-        v.cdirty[c2] = 1;
+        v.ctouch[c] = v.stamp;
+        v.ctouch[c2] = v.stamp;
     }
     sq_wave_sync();
     return err;
@@ -407,7 +451,7 @@ __device__ __forceinline__ int sqv_scan(const SqvArgs &s, const SqvView &v, int 
                     row_i[p] = (unsigned short)j;
                     v.vrows[j * vcap + nj] = (unsigned short)i;
                     v.vcnt[j] = (unsigned short)(nj + 1);
-                    v.dirty[j] = 1;
+                    v.touch[j] = v.stamp;
                 } else {
                     err |= SQV_ERR_ROW;
                 }
@@ -458,8 +502,8 @@ __device__ __forceinline__ bool sqv_update(const SqvArgs &s, const SqvView &v, i
     const int fill = sqv_scan<D, 4, true, false>(s, v, i, 0, x, c2, nullptr, nullptr, dummy, err);
     if (lane == 0) {
         v.vcnt[i] = (unsigned short)min(fill, s.vcap);
-        v.dirty[i] = 1;
-        v.cdirty[c2] = 1;
+        v.touch[i] = v.stamp;
+        v.ctouch[c2] = v.stamp;
     }
     if (lane < D) v.last[i * D + lane] = sqv_sel3(x, lane);
 #pragma unroll
@@ -485,6 +529,7 @@ __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView 
 {
     const int lane = wave_lane();
     double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0}, xr[3] = {0, 0, 0}, last[3] = {0, 0, 0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the resolver's own earlier stores to positions_at_last_update)
 #pragma unroll
     for (int q = 0; q < D; q++) last[q] = v.last[i * D + q];            // (global: in flight behind the sums below)
 #pragma unroll
@@ -495,7 +540,7 @@ __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView 
     }
     const int spi = (s.a.S > 1) ? (int)v.species[i] : 0;
     sqv_mark_row(s, v, i);
-    if (lane == 0) v.cdirty[v.cs[i]] = 1;
+    if (lane == 0) v.ctouch[v.cs[i]] = v.stamp;
     double e1 = e1_in, e2 = 0.0, dummy;
     bool have_e2 = false;
     if (!have_e1) {
@@ -528,7 +573,8 @@ __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView 
 
 // An evaluator's work on one step: everything the resolver needs to take the step as it is, provided nobody touches its inputs.
 template <int D, int KIND>
-__device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v, double *tb, const SqGen &ge, double T, SqvSpec *out, unsigned short *lst)
+__device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v, double *tb, const SqGen &ge, double T, SqvSpec *out, unsigned short *lst,
+                                             int s0, int seq)
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
@@ -538,11 +584,12 @@ __device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v,
     sp.xw[0] = sp.xw[1] = sp.xw[2] = sp.xl[0] = sp.xl[1] = sp.xl[2] = 0.0;
     sp.i = 0; sp.flags = SQV_SERIAL | (ge.m << 8);
     sp.c0 = sp.c2 = sp.c3 = sp.nl = 0;
+    sp.s0 = s0; sp.seq = 0; sp.pad0 = sp.pad1 = 0;
     if (s.pool.kind[ge.m] == 0) {
         const int i = (int)mulhi32(ge.r1, (uint32_t)N);
         double x[3] = {0, 0, 0}, xn[3] = {0, 0, 0}, xr[3] = {0, 0, 0}, last[3] = {0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < D; q++) last[q] = v.last[i * D + q];     // (global: in flight behind the sums)
+        for (int q = 0; q < D; q++) last[q] = __hip_atomic_load(&v.last[i * D + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (global, past the L1: in flight behind the sums)
 #pragma unroll
         for (int q = 0; q < D; q++) {
             x[q] = v.pos[i * D + q];
@@ -604,22 +651,25 @@ __device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v,
         }
         sp.flags = fl;
     }
+    // the record, then (everything of it and of the list having landed) its sequence number
     if (lane == 0) *out = sp;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) sqv_st(&out->seq, seq);
 }
 
-// no mark, in either epoch, on any of the cells a scan around c2 reads
+// a mark older than `window` steps (the step number + 1 is `now`): set before the evaluation in question began
+__device__ __forceinline__ bool sqv_fresh(int tv, int now, int window) { return ((now - tv) & 0xffff) > window; }
+
+// no mark since the evaluation began on any of the cells a scan around c2 reads
 template <int D>
-__device__ __forceinline__ bool sqv_cells_clean(const SqvView &v, int c2)
+__device__ __forceinline__ bool sqv_cells_clean(const SqvView &v, int c2, int now, int window)
 {
     constexpr int NN = (D == 3) ? 27 : 9;
     const int lane = wave_lane();
     const int cnt = v.nbrcnt[c2];
-    int f = 0;
-    if (lane < cnt) {
-        const int cc = v.nbr[c2 * NN + lane];
-        f = v.cdirty[cc] | v.cdirty_prev[cc];
-    }
-    return __ballot(f != 0) == 0ull;
+    bool bad = false;
+    if (lane < cnt) bad = !sqv_fresh(v.ctouch[v.nbr[c2 * NN + lane]], now, window);
+    return __ballot(bad) == 0ull;
 }
 
 template <int D, int KIND>
@@ -636,9 +686,9 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
     v.pos = reinterpret_cast<double *>(sqv_smem);
     v.last = ch.last_work;
     v.species = sqv_smem + s.o_species;
-    unsigned char *const dirty0 = sqv_smem + s.o_dirty, *const cdirty0 = sqv_smem + s.o_cdirty;
-    v.dirty = dirty0; v.dirty_prev = dirty0 + s.dstride;
-    v.cdirty = cdirty0; v.cdirty_prev = cdirty0 + s.cdstride;
+    v.touch = reinterpret_cast<unsigned short *>(sqv_smem + s.o_touch);
+    v.ctouch = reinterpret_cast<unsigned short *>(sqv_smem + s.o_ctouch);
+    v.stamp = 0;
     v.cs = reinterpret_cast<unsigned short *>(sqv_smem + s.o_cs);
     v.vcnt = reinterpret_cast<unsigned short *>(sqv_smem + s.o_vcnt);
     v.vrows = reinterpret_cast<unsigned short *>(sqv_smem + s.o_vrows);
@@ -648,9 +698,11 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
     v.nbrcnt = reinterpret_cast<unsigned short *>(sqv_smem + s.o_nbrcnt);
     v.gen = reinterpret_cast<SqGen *>(sqv_smem + s.o_gen);
     v.ctl = reinterpret_cast<int *>(sqv_smem + s.o_ctl);
-    SqvSpec *const spec0 = reinterpret_cast<SqvSpec *>(sqv_smem + s.o_spec);            // [2][NB]
-    unsigned short *const lst0 = reinterpret_cast<unsigned short *>(sqv_smem + s.o_lst);   // [2][NB][vcap]
-    double *const tb = reinterpret_cast<double *>(sqv_smem + s.o_terms) + (size_t)wv * 2 * s.tstride;
+    int *const p_err = v.ctl, *const p_done = v.ctl + 1, *const p_gen = v.ctl + 2, *const p_cnt = v.ctl + 4;   // [4 .. 19]: attempted, accepted per move
+    SqvSpec *const spec0 = reinterpret_cast<SqvSpec *>(sqv_smem + s.o_spec);            // [NB]: evaluator e's record
+    unsigned short *const lst0 = reinterpret_cast<unsigned short *>(sqv_smem + s.o_lst);   // [NB][vcap]: ... and its list
+    const int ev = (wv & 3) ? (wv & 3) - 1 + 3 * (wv >> 2) : -1;          // evaluator 0 .. NB - 1, or none
+    double *const tb = reinterpret_cast<double *>(sqv_smem + s.o_terms) + (size_t)max(ev, 0) * 2 * s.tstride;   // (an evaluator's terms of the sum over a rebuilt list)
     {
         DevModel *lm = reinterpret_cast<DevModel *>(sqv_smem + s.o_models);
         const int *src = reinterpret_cast<const int *>(a.models);
@@ -659,13 +711,13 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         v.models = lm;
     }
     // -- the chain's state into LDS (rows, cell vectors and marks zero-filled first: whatever an evaluator reads is a valid id)
-    if (tid == 0) v.ctl[0] = 0;
+    if (tid < 24) v.ctl[tid] = 0;
     for (int k = tid; k < (N * vcap + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.vrows)[k] = 0u;
     for (int k = tid; k < (s.ncell * ccap + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.crows)[k] = 0u;
-    for (int k = tid; k < 3 * s.dstride / 4; k += nth) reinterpret_cast<unsigned int *>(dirty0)[k] = 0u;
-    for (int k = tid; k < 3 * s.cdstride / 4; k += nth) reinterpret_cast<unsigned int *>(cdirty0)[k] = 0u;
-    for (int k = tid; k < 2 * NB * (int)(sizeof(SqvSpec) / 4); k += nth) reinterpret_cast<unsigned int *>(spec0)[k] = 0u;
-    for (int k = tid; k < NB * vcap; k += nth) reinterpret_cast<unsigned int *>(lst0)[k] = 0u;
+    for (int k = tid; k < (N + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.touch)[k] = 0u;
+    for (int k = tid; k < (s.ncell + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.ctouch)[k] = 0u;
+    for (int k = tid; k < NB * (int)(sizeof(SqvSpec) / 4); k += nth) reinterpret_cast<unsigned int *>(spec0)[k] = 0u;
+    for (int k = tid; k < NB * vcap / 2; k += nth) reinterpret_cast<unsigned int *>(lst0)[k] = 0u;
     __syncthreads();
     int lerr = 0;
     for (int k = tid; k < s.ncell * NN; k += nth) v.nbr[k] = (unsigned short)a.nbr[(size_t)(k / NN) * a.nnmax + (k % NN)];
@@ -692,19 +744,11 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         const int i = k / vcap, q = k - i * vcap;
         if (q < (int)v.vcnt[i]) v.vrows[k] = (unsigned short)ch.vl_nb[(size_t)i * a.vl_cap + q];
     }
-    if (lerr) atomicOr(v.ctl, lerr);
+    if (lerr) atomicOr(p_err, lerr);
     if (ch.sp_ids_work) for (int k = tid; k < N; k += nth) { ch.sp_ids_work[k] = ch.sp_ids[k]; ch.sp_heads_work[k] = ch.sp_heads[k]; }
-    __syncthreads();
-    double E = ch.energy;
-    const double T = ch.temperature;
-    unsigned long long att[8], acc[8], nser = 0, nreb = 0, nbat = 0, napp = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) { att[q] = 0; acc[q] = 0; }
-    const long long nsteps = s.nsteps;
-    const long long nbatch = (nsteps + NB - 1) / NB;
-    const int ev = (wv == 0 || wv == 4) ? -1 : (wv < 4 ? wv - 1 : wv - 2);      // evaluator slot 0 .. 5
+    const int nsteps = (int)s.nsteps;                            // (a launch has at most 2^20 steps: the counters above are ints)
     // the words and operations of k_ref_ops for step t of the launch, into the ring of random parts
-    auto generate = [&](long long t) {
+    auto generate = [&](int t) {
         const unsigned long long g = ch.step0 + (unsigned long long)t;
         uint32_t R[4], Q[4];
         philox4x32((uint32_t)g, (uint32_t)(g >> 32), 0, TAG_SEQ0, ch.key0, ch.key1, R);
@@ -722,179 +766,242 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         }
         v.gen[t & (SQV_GEN - 1)] = o;
     };
-    bool dead = v.ctl[0] != 0;
-    long long gen_done = 1;                                     // blocks of 64 steps generated so far: 0 and 1, here
-    if (tid < SQV_GEN && tid < nsteps) generate(tid);
+    if (tid < SQV_GEN && tid < nsteps) generate(tid);           // blocks 0 and 1 of the random parts
+    if (tid == 0) *p_gen = 2;
     __syncthreads();
-    // batch 0 is evaluated before the pipeline starts
-    if (ev >= 0 && ev < nsteps && !dead) sqv_evaluate<D, KIND>(s, v, tb, v.gen[ev], T, spec0 + ev, lst0 + ev * vcap);
-    __syncthreads();
-    for (long long b = 0; b < nbatch && !dead; b++) {
-        const int cur = (int)(b & 1);
-        const int ep = (int)(b % 3), ep_prev = (ep + 2) % 3, ep_next = (ep + 1) % 3;   // marks: this batch's, the one before's, the next one's (being cleared)
-        if (wv == 0) {
-            // ---- the resolver: batch b in step order
+    const double T = ch.temperature;
+    double E = ch.energy;
+    unsigned long long nser = 0, nreb = 0, napp = 0, nwait = 0;
+    const bool dead0 = *p_err != 0;
+    if (dead0) {
+        // (a row longer than the LDS holds: nothing runs)
+    } else if (wv == 0) {
+        // ---- the RESOLVER: the steps in order
+        // (the loop bound as a value the compiler cannot re-load from the kernel arguments: under register pressure it then keeps
+        // it in a lane of a vector register, where a scalar load and its wait -- for every LDS operation in flight too -- stood
+        // at the end of every step)
+        int nsteps_r = nsteps;
+        asm volatile("" : "+s"(nsteps_r));
+        int slot = 0;
+        // The record of a step in one round trip, requested while the step before is resolved (the evaluators are SQV_LOOK steps
+        // ahead: it is nearly always there, and is asked for again if it is not): sqv_rec_request
+        SqvRaw raw;
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        sqv_rec_request(spec0, zero, raw);
+        for (int t = 0; t < nsteps_r; t++, slot = (slot + 1 == NB) ? 0 : slot + 1) {
+            SQVM("step_begin");
+            const SqvSpec *rec = spec0 + slot;
+            SqvSpec sp;
+            sqv_rec_decode(raw, sp);
+            bool stop = false;
+            SQVM("rec_ready");
+            SQVT(1);
+            if (sp.seq != t + 1) SQVT_COUNT(14);
+            while (sp.seq != t + 1) {
+                nwait++;
+                SQVT_COUNT(13);
+                if (sqv_ld(p_err)) { stop = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                sqv_rec_request(rec, zero, raw);
+                sqv_rec_decode(raw, sp);
+            }
+            if (!stop) sqv_rec_request(spec0 + ((slot + 1 == NB) ? 0 : slot + 1), zero, raw);     // the next step's, in flight behind this step
+            if (stop) break;
             SQVT(0);
-            v.dirty = dirty0 + ep * s.dstride; v.dirty_prev = dirty0 + ep_prev * s.dstride;
-            v.cdirty = cdirty0 + ep * s.cdstride; v.cdirty_prev = cdirty0 + ep_prev * s.cdstride;
-            nbat++;
-            const int nb = (int)min((long long)NB, nsteps - b * NB);
-            SqvSpec spn = spec0[cur * NB];
-            for (int k = 0; k < nb; k++) {
-                SQVM("step_begin");
-                const SqvSpec sp = spn;
-                if (k + 1 < nb) spn = spec0[cur * NB + k + 1];       // (nothing in this loop writes the evaluators' records: in flight behind this step)
-                const unsigned short *lst = lst0 + (cur * NB + k) * vcap;
-                const long long t = b * NB + k;
-                const int m = (sp.flags >> 8) & 7;
-                bool ok = false;
-                if (sp.flags & SQV_DISP) {
-                    const int i = sp.i;
-                    // (one round trip: the marks of i, and its row in case the step stores a position)
-                    const int di = v.dirty[i] | v.dirty_prev[i];
-                    const int ni_ = v.vcnt[i];
-                    const int rj_ = (lane < vcap) ? (int)v.vrows[i * vcap + lane] : 0;
-                    const bool clean = !di;
-                    if (clean && !(sp.flags & (SQV_SERIAL | SQV_REBUILD))) {
-                        // nobody has touched i or its row since the evaluation began: the evaluation is the step
-                        ok = (sp.flags & SQV_OK) != 0;
-                        if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }     // src/moves.jl:17,79
-                        if (sp.flags & SQV_CHG) {
-                            // (the stored position is within dr / 2 of the last update: update_neighbour_list! returns at once)
-                            if (lane < D) v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
-                            if (lane < ni_) v.dirty[rj_] = 1;
-                            for (int q = PMC_WAVE + lane; q < ni_; q += PMC_WAVE) v.dirty[v.vrows[i * vcap + q]] = 1;
-                            if (lane == 0) { v.dirty[i] = 1; v.cdirty[sp.c0] = 1; }
-                        }
-                        SQVM("clean_end");
-                        SQVT(2);
-                    } else if (clean && (sp.flags & SQV_LIST) && sqv_cells_clean<D>(v, sp.c2) && (!(sp.flags & SQV_REB2) || sqv_cells_clean<D>(v, sp.c3))) {
-                        // ... and nobody has touched the cells its scan read: the rebuild is applied from the evaluator's list.
-                        // Net effect of update_neighbour_list! at the trial position (and again at the reverted one, REB2): i has
-                        // left its old neighbours' lists and is appended to those of the final list; the cell vectors took
-                        // every move in turn
-                        ok = (sp.flags & SQV_OK) != 0;
-                        if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }
-                        int err = sqv_leave_lists(s, v, i);
-                        const int c = v.cs[i];
-                        if (c != sp.c2) err |= sqv_cell_move(s, v, i, c, sp.c2);
-                        if (sp.c3 != sp.c2) err |= sqv_cell_move(s, v, i, sp.c2, sp.c3);
-                        unsigned short *row_i = v.vrows + i * vcap;
-                        const int nl = sp.nl;
-                        for (int q = lane; q < nl; q += PMC_WAVE) {
-                            const int j = lst[q];
-                            const int nj = v.vcnt[j];
-                            if (nj < vcap) {
-                                v.vrows[j * vcap + nj] = (unsigned short)i;
-                                v.vcnt[j] = (unsigned short)(nj + 1);
-                                v.dirty[j] = 1;
-                            } else {
-                                err |= SQV_ERR_ROW;
-                            }
-                            row_i[q] = (unsigned short)j;
-                        }
-                        if (lane == 0) {
-                            v.vcnt[i] = (unsigned short)nl;
-                            v.dirty[i] = 1;
-                            v.cdirty[c] = 1;
-                            v.cdirty[sp.c3] = 1;
-                        }
-                        if (lane < D) {
-                            v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
-                            v.last[i * D + lane] = sqv_sel3(sp.xl, lane);
-                        }
-                        if (__ballot(err != 0)) {
-                            int e = err;
-#pragma unroll
-                            for (int sft = 32; sft >= 1; sft >>= 1) e |= __shfl_xor(e, sft, PMC_WAVE);
-                            if (lane == 0) v.ctl[0] |= e;
-                        }
-                        nreb += (sp.flags & SQV_REB2) ? 2 : 1;
-                        napp++;
-                        sq_wave_sync();
-                        SQVT_COUNT(10);
-                        SQVT(3);
-                    } else {
-                        nser++;
-                        SQVT_COUNT(11);
-                        const SqGen ge = v.gen[t & (SQV_GEN - 1)];
-                        ok = sqv_disp_serial<D, KIND>(s, v, tb, i, ge, T, E, nreb, clean && (sp.flags & SQV_REBUILD), sp.e1);
+            const unsigned short *lst = lst0 + slot * vcap;
+            const int now = t + 1, window = t - sp.s0;
+            v.stamp = (unsigned short)now;
+            const int m = (sp.flags >> 8) & 7;
+            bool ok = false, clean_step = false;
+            if (sp.flags & SQV_DISP) {
+                const int i = sp.i;
+                // (one round trip: the mark of i, and its row in case the step stores a position)
+                const int rj_ = (lane < vcap) ? (int)v.vrows[i * vcap + lane] : 0;
+                asm volatile("" ::: "memory");
+                const int ti = v.touch[i];
+                const int ni_ = v.vcnt[i];
+                const bool clean = sqv_fresh(ti, now, window);
+                clean_step = clean;
+                if (clean && !(sp.flags & (SQV_SERIAL | SQV_REBUILD))) {
+                    // nobody has touched i or its row since the evaluation began: the evaluation is the step
+                    ok = (sp.flags & SQV_OK) != 0;
+                    if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }     // src/moves.jl:17,79
+                    if (sp.flags & SQV_CHG) {
+                        // (the stored position is within dr / 2 of the last update: update_neighbour_list! returns at once)
+                        if (D == 3) sp.xw[2] = rec->xw[2];
+                        if (lane < D) v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
+                        if (lane < ni_) v.touch[rj_] = v.stamp;
+                        for (int q = PMC_WAVE + lane; q < ni_; q += PMC_WAVE) v.touch[v.vrows[i * vcap + q]] = v.stamp;
+                        if (lane == 0) { v.touch[i] = v.stamp; v.ctouch[sp.c0] = v.stamp; }
                     }
-                } else {
-                    // DiscreteSwap (src/moves.jl:137-207): four sums, species exchange, SpeciesList fix-up; the SpeciesList
-                    // stays in global memory (the launch's working copy: this wavefront is its only reader and writer)
-                    nser++;
-                    const SqGen ge = v.gen[t & (SQV_GEN - 1)];
-                    const int sa = s.pool.sp0[m], sb = s.pool.sp1[m];
-                    const int oa = ch.sp_off[sa], ob = ch.sp_off[sb];
-                    const int na = ch.sp_off[sa + 1] - oa, nbb = ch.sp_off[sb + 1] - ob;
-                    if (na > 0 && nbb > 0) {
-                        const int i = ch.sp_ids_work[oa + mulhi32(ge.r1, (uint32_t)na)];
-                        const int j = ch.sp_ids_work[ob + mulhi32(ge.q0, (uint32_t)nbb)];
-                        double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
-#pragma unroll
-                        for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
-                        const int spi = v.species[i], spj = v.species[j];
-                        double e1i, e2i, e1j, e2j;
-                        sqv_energy2<D, KIND>(s, v, i, spi, spj, j, spi, xi, xi, e1i, e2i);
-                        sqv_energy2<D, KIND>(s, v, j, spj, spi, i, spj, xj, xj, e1j, e2j);
-                        const double e1 = e1i + e1j, e2 = e2i + e2j;
-                        double de = 0.0;
-                        if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
-                        ok = ge.lnu < -(e2 - e1) / T;
-                        if (ok) {
-                            sqv_mark_row(s, v, i);
-                            sqv_mark_row(s, v, j);
-                            if (lane == 0) {
-                                v.species[i] = (unsigned char)spj;
-                                v.species[j] = (unsigned char)spi;
-                                v.cdirty[v.cs[i]] = 1;
-                                v.cdirty[v.cs[j]] = 1;
-                                // update_species_list!, src/moves.jl:175-179
-                                const int hi_ = ch.sp_heads_work[i], hj_ = ch.sp_heads_work[j];
-                                ch.sp_ids_work[oa + hi_] = j;
-                                ch.sp_ids_work[ob + hj_] = i;
-                                ch.sp_heads_work[i] = hj_;
-                                ch.sp_heads_work[j] = hi_;
-                            }
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_wave_barrier();
+                    SQVM("clean_end");
+                    SQVT(2);
+                } else if (clean && (sp.flags & SQV_LIST) && sqv_cells_clean<D>(v, sp.c2, now, window) &&
+                           (!(sp.flags & SQV_REB2) || sqv_cells_clean<D>(v, sp.c3, now, window))) {
+                    // ... and nobody has touched the cells its scan read: the rebuild is applied from the evaluator's list.
+                    // Net effect of update_neighbour_list! at the trial position (and again at the reverted one, REB2): i has
+                    // left its old neighbours' lists and is appended to those of the final list; the cell vectors took
+                    // every move in turn
+                    ok = (sp.flags & SQV_OK) != 0;
+                    if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }
+                    sp.xw[2] = rec->xw[2]; sp.xl[0] = rec->xl[0]; sp.xl[1] = rec->xl[1]; sp.xl[2] = rec->xl[2];      // (the rest of the record: the evaluator leaves it alone until this step is over)
+                    int err = sqv_leave_lists(s, v, i);
+                    const int c = v.cs[i];
+                    if (c != sp.c2) err |= sqv_cell_move(s, v, i, c, sp.c2);
+                    if (sp.c3 != sp.c2) err |= sqv_cell_move(s, v, i, sp.c2, sp.c3);
+                    unsigned short *row_i = v.vrows + i * vcap;
+                    const int nl = sp.nl;
+                    for (int q = lane; q < nl; q += PMC_WAVE) {
+                        const int j = lst[q];
+                        const int nj = v.vcnt[j];
+                        if (nj < vcap) {
+                            v.vrows[j * vcap + nj] = (unsigned short)i;
+                            v.vcnt[j] = (unsigned short)(nj + 1);
+                            v.touch[j] = v.stamp;
                         } else {
-                            E -= de;                                             // src/moves.jl:206
+                            err |= SQV_ERR_ROW;
                         }
+                        row_i[q] = (unsigned short)j;
                     }
-                    SQVT(8);
-                }
+                    if (lane == 0) {
+                        v.vcnt[i] = (unsigned short)nl;
+                        v.touch[i] = v.stamp;
+                        v.ctouch[c] = v.stamp;
+                        v.ctouch[sp.c3] = v.stamp;
+                    }
+                    if (lane < D) {
+                        v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
+                        v.last[i * D + lane] = sqv_sel3(sp.xl, lane);
+                    }
+                    if (__ballot(err != 0)) {
+                        int e = err;
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    att[q] += (q == m);
-                    acc[q] += (q == m && ok);
+                        for (int sft = 32; sft >= 1; sft >>= 1) e |= __shfl_xor(e, sft, PMC_WAVE);
+                        if (lane == 0) atomicOr(p_err, e);
+                    }
+                    nreb += (sp.flags & SQV_REB2) ? 2 : 1;
+                    napp++;
+                    SQVT_COUNT(10);
+                    SQVT(3);
+                } else {
+                    nser++;
+                    SQVT_COUNT(11);
+                    const SqGen ge = v.gen[t & (SQV_GEN - 1)];
+                    ok = sqv_disp_serial<D, KIND>(s, v, tb, i, ge, T, E, nreb, clean && (sp.flags & SQV_REBUILD), sp.e1);
                 }
+            } else {
+                // DiscreteSwap (src/moves.jl:137-207): four sums, species exchange, SpeciesList fix-up; the SpeciesList
+                // stays in global memory (the launch's working copy: this wavefront is its only reader and writer)
+                nser++;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the resolver's own earlier stores to the SpeciesList)
+                const SqGen ge = v.gen[t & (SQV_GEN - 1)];
+                const int sa = s.pool.sp0[m], sb = s.pool.sp1[m];
+                const int oa = ch.sp_off[sa], ob = ch.sp_off[sb];
+                const int na = ch.sp_off[sa + 1] - oa, nbb = ch.sp_off[sb + 1] - ob;
+                if (na > 0 && nbb > 0) {
+                    const int i = ch.sp_ids_work[oa + mulhi32(ge.r1, (uint32_t)na)];
+                    const int j = ch.sp_ids_work[ob + mulhi32(ge.q0, (uint32_t)nbb)];
+                    double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < D; q++) { xi[q] = v.pos[i * D + q]; xj[q] = v.pos[j * D + q]; }
+                    const int spi = v.species[i], spj = v.species[j];
+                    double e1i, e2i, e1j, e2j;
+                    sqv_energy2<D, KIND>(s, v, i, spi, spj, j, spi, xi, xi, e1i, e2i);
+                    sqv_energy2<D, KIND>(s, v, j, spj, spi, i, spj, xj, xj, e1j, e2j);
+                    const double e1 = e1i + e1j, e2 = e2i + e2j;
+                    double de = 0.0;
+                    if (!(isinf(e1) || isinf(e2))) { de = e2 - e1; E += de; }
+                    ok = ge.lnu < -(e2 - e1) / T;
+                    if (ok) {
+                        sqv_mark_row(s, v, i);
+                        sqv_mark_row(s, v, j);
+                        if (lane == 0) {
+                            v.species[i] = (unsigned char)spj;
+                            v.species[j] = (unsigned char)spi;
+                            v.ctouch[v.cs[i]] = v.stamp;
+                            v.ctouch[v.cs[j]] = v.stamp;
+                            // update_species_list!, src/moves.jl:175-179
+                            const int hi_ = ch.sp_heads_work[i], hj_ = ch.sp_heads_work[j];
+                            ch.sp_ids_work[oa + hi_] = j;
+                            ch.sp_ids_work[ob + hj_] = i;
+                            ch.sp_heads_work[i] = hj_;
+                            ch.sp_heads_work[j] = hi_;
+                        }
+                    } else {
+                        E -= de;                                             // src/moves.jl:206
+                    }
+                }
+                SQVT(8);
             }
-        } else if (wv == 4) {
-            // ---- the generator: the marks of the next batch's resolution cleared, and the random parts the evaluators read in the
-            // NEXT trip of this loop (batch b + 2)
-            for (int k = lane; k < s.dstride / 4; k += PMC_WAVE) reinterpret_cast<unsigned int *>(dirty0 + ep_next * s.dstride)[k] = 0u;
-            for (int k = lane; k < s.cdstride / 4; k += PMC_WAVE) reinterpret_cast<unsigned int *>(cdirty0 + ep_next * s.cdstride)[k] = 0u;
-            const long long need = min((long long)NB * (b + 3) - 1, nsteps - 1) >> 6;
-            if (need > gen_done) {
-                const long long t = (need << 6) + lane;
-                if (t < nsteps) generate(t);
-                gen_done = need;
+            // (a row or cell vector that overflowed in this step -- only the paths that edit lists can tell -- ends the launch here:
+            // the state is no longer the chain's, and nothing of it is written back)
+            if (!(sp.flags & SQV_DISP) || (sp.flags & (SQV_SERIAL | SQV_REBUILD)) || !clean_step) {
+                if (sqv_ld(p_err)) break;
             }
-        } else {
-            // ---- an evaluator: one step of batch b + 1
-            const long long t = (long long)NB * (b + 1) + ev;
-            if (t < nsteps) sqv_evaluate<D, KIND>(s, v, tb, v.gen[t & (SQV_GEN - 1)], T, spec0 + (cur ^ 1) * NB + ev, lst0 + ((cur ^ 1) * NB + ev) * vcap);
+            SQVM("step_end");
+            if (lane == 0) {
+                (void)__hip_atomic_fetch_add(p_cnt + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ok) (void)__hip_atomic_fetch_add(p_cnt + 8 + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // the evaluators are told that the step is over: the LDS takes this store behind everything the step stored there.
+            // (What it stored in global memory -- positions_at_last_update, the SpeciesList -- may still be on its way: an
+            // evaluator that reads a stale positions_at_last_update[i] reads it for a particle this step has marked.)
+            asm volatile("" ::: "memory");
+            if (lane == 0) sqv_st_relaxed(p_done, now);
         }
-        __syncthreads();
-        dead = v.ctl[0] != 0;
+    } else if (wv == 4) {
+        // ---- the GENERATOR: block B of the random parts takes the place of block B - 2 once the resolver is through with it
+        for (int B = 2; (B << 6) < nsteps; B++) {
+            bool stop = false;
+            while (true) {
+                const sqv_u4 c = *reinterpret_cast<const volatile sqv_u4 *>(v.ctl);
+                if (c.x) { stop = true; break; }
+                if ((int)c.y >= ((B - 1) << 6)) break;
+                __builtin_amdgcn_s_sleep(60);
+            }
+            if (stop) break;
+            const int t = (B << 6) + lane;
+            if (t < nsteps) generate(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) sqv_st(p_gen, B + 1);
+        }
+    } else if (ev >= 0) {
+        // ---- an EVALUATOR: every NB-th step, begun once the resolver is within SQV_LOOK steps of it
+        // (An evaluator is idle nine tenths of the time.  Twelve of them polling the control words every hundred cycles kept the
+        // LDS busy enough to double the cost of every step of the resolver: one 16-byte request per poll, and a sleep that
+        // follows the distance to go.)
+        bool stop = false;
+        for (int t = ev; t < nsteps && !stop; t += NB) {
+            int s0 = 0;
+            while (true) {
+                const sqv_u4 c = *reinterpret_cast<const volatile sqv_u4 *>(v.ctl);      // err, done, random parts, -
+                if (c.x) { stop = true; break; }
+                s0 = (int)c.y;
+                if (s0 >= t - SQV_LOOK && (int)c.z > (t >> 6)) break;
+                if (t - SQV_LOOK - s0 > 2) __builtin_amdgcn_s_sleep(24); else __builtin_amdgcn_s_sleep(3);
+            }
+            if (stop) break;
+            asm volatile("" ::: "memory");
+#ifdef PMC_DEBUG_TIME
+            const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
+            sqv_evaluate<D, KIND>(s, v, tb, v.gen[t & (SQV_GEN - 1)], T, spec0 + ev, lst0 + ev * vcap, s0, t + 1);
+#ifdef PMC_DEBUG_TIME
+            if (blockIdx.x == 0 && ev == 0 && lane == 0) {       // evaluator 0's clock: 12 plain evaluations, 13 with a rebuilt list, 14 the latter's number
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+                const bool rb = (spec0[ev].flags & SQV_REBUILD) != 0;
+                g_sqvt[12] += rb ? 0 : te1 - te0;
+            }
+#endif
+        }
     }
     __syncthreads();
-    if (dead) {
+    if (*p_err != 0) {
         // a row or cell vector outgrew the LDS (or the lists were inconsistent): nothing is written back -- the swaps of this launch
         // edited only the working copy of the SpeciesList -- and the host runs these steps on the literal loop
-        if (tid == 0) ch.err = v.ctl[0];
+        if (tid == 0) { ch.err = *p_err; for (int q = 0; q < 4; q++) ch.dbg[q] = v.ctl[20 + q]; }
         return;
     }
     // -- back to global memory
@@ -917,7 +1024,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
     if (tid == 0) {
         ch.energy = E;
         ch.step0 += (unsigned long long)nsteps;
-        for (int q = 0; q < 8; q++) { ch.att[q] += att[q]; ch.acc[q] += acc[q]; }
-        ch.n_serial += nser; ch.n_rebuild += nreb; ch.n_batches += nbat; ch.n_applied += napp;
+        for (int q = 0; q < 8; q++) { ch.att[q] += (unsigned long long)p_cnt[q]; ch.acc[q] += (unsigned long long)p_cnt[8 + q]; }
+        ch.n_serial += nser; ch.n_rebuild += nreb; ch.n_batches += nwait; ch.n_applied += napp;
     }
 }

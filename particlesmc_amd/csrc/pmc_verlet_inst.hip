@@ -10,10 +10,9 @@ static size_t sqv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // LDS bytes of k_sq_verlet for a system of this shape with rows of `vcap` ids and cell vectors of `ccap` (and the offsets of its arrays)
 size_t pmc_sqv_layout(int n_, int d, int nspecies, int ncell, int nn_, int vcap, int ccap, SqvArgs *s)
 {
-    const size_t N = (size_t)n_, nc = (size_t)ncell, nn = (size_t)nn_, nw = SQV_NW, nb = SQV_NB;
+    const size_t N = (size_t)n_, nc = (size_t)ncell, nn = (size_t)nn_, nb = SQV_NB;
     const size_t t0 = (size_t)((vcap + 7) / 8 * 8 + SQ_TERMS_PAD), t1 = 3 * SQ_TERMS_PAD;      // (the sums request their first 24 terms at once)
     const size_t tstride = t0 > t1 ? t0 : t1;
-    const size_t dstride = sqv_align(N + 4, 16), cdstride = sqv_align(nc + 4, 16);
     size_t o = sqv_align(N * d * sizeof(double), 16);
     const size_t o_vrows = o;     o = sqv_align(o + N * vcap * 2 + 8, 16);       // (+ the word a half row reads behind the last row)
     const size_t o_crows = o;     o = sqv_align(o + nc * ccap * 2, 16);
@@ -23,19 +22,19 @@ size_t pmc_sqv_layout(int n_, int d, int nspecies, int ncell, int nn_, int vcap,
     const size_t o_nbr = o;       o = sqv_align(o + nc * nn * 2, 16);
     const size_t o_nbrcnt = o;    o = sqv_align(o + nc * 2, 16);
     const size_t o_species = o;   o = sqv_align(o + N, 16);
-    const size_t o_dirty = o;     o = o + 3 * dstride;       // (three epochs: this batch's marks, the one before's, the next one's being cleared)
-    const size_t o_cdirty = o;    o = o + 3 * cdstride;
+    const size_t o_touch = o;     o = sqv_align(o + N * 2 + 4, 16);
+    const size_t o_ctouch = o;    o = sqv_align(o + nc * 2 + 4, 16);
     const size_t o_gen = o;       o = sqv_align(o + SQV_GEN * sizeof(SqGen), 16);
-    const size_t o_spec = o;      o = sqv_align(o + 2 * nb * sizeof(SqvSpec), 16);
-    const size_t o_lst = o;       o = sqv_align(o + 2 * nb * (size_t)vcap * 2, 16);
+    const size_t o_spec = o;      o = sqv_align(o + nb * sizeof(SqvSpec), 16);
+    const size_t o_lst = o;       o = sqv_align(o + nb * (size_t)vcap * 2, 16);
     const size_t o_models = o;    o = sqv_align(o + (size_t)nspecies * nspecies * sizeof(DevModel), 16);
-    const size_t o_terms = o;     o = sqv_align(o + nw * 2 * tstride * sizeof(double), 16);
-    const size_t o_ctl = o;       o = sqv_align(o + 16, 16);
+    const size_t o_terms = o;     o = sqv_align(o + nb * 2 * tstride * sizeof(double), 16);      // (the evaluators' only)
+    const size_t o_ctl = o;       o = sqv_align(o + 24 * sizeof(int), 16);
     if (s) {
-        s->vcap = vcap; s->ccap = ccap; s->tstride = (int)tstride; s->dstride = (int)dstride; s->cdstride = (int)cdstride;
+        s->vcap = vcap; s->ccap = ccap; s->tstride = (int)tstride;
         s->o_vrows = (int)o_vrows; s->o_crows = (int)o_crows; s->o_cs = (int)o_cs; s->o_vcnt = (int)o_vcnt;
-        s->o_ccnt = (int)o_ccnt; s->o_nbr = (int)o_nbr; s->o_nbrcnt = (int)o_nbrcnt; s->o_species = (int)o_species; s->o_dirty = (int)o_dirty;
-        s->o_cdirty = (int)o_cdirty; s->o_gen = (int)o_gen; s->o_spec = (int)o_spec; s->o_lst = (int)o_lst; s->o_models = (int)o_models;
+        s->o_ccnt = (int)o_ccnt; s->o_nbr = (int)o_nbr; s->o_nbrcnt = (int)o_nbrcnt; s->o_species = (int)o_species; s->o_touch = (int)o_touch;
+        s->o_ctouch = (int)o_ctouch; s->o_gen = (int)o_gen; s->o_spec = (int)o_spec; s->o_lst = (int)o_lst; s->o_models = (int)o_models;
         s->o_terms = (int)o_terms; s->o_ctl = (int)o_ctl;
     }
     return o;
