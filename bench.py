@@ -616,7 +616,8 @@ def other_configs(pmc, budget_cpu_s=1.2):
     except Exception as exc:
         rows.append({"config": "published mixture as published (N=1000)", "error": repr(exc)})
     # -- the reference's CI system (test/runtests.jl:22-91: config_0, N = 1290 2-D ternary JBB, T = 0.231) with a VerletList dr = 0.2 on
-    #    the reference's own chain: the literal loop (engine 1), one chain and 256 chains of a parallel = true run in one launch
+    #    the reference's own chain: engine 4 (round 6: the state in LDS, one wavefront resolving the steps while twelve evaluate the
+    #    ones behind them), one chain and 256 chains of a parallel = true run in one launch; and the literal loop (engine 1) beside it
     try:
         from particlesmc_amd.io import load_configuration
         cfg = load_configuration(os.path.join(ROOT, "tests", "golden", "config_0.xyz"))
@@ -625,22 +626,35 @@ def other_configs(pmc, budget_cpu_s=1.2):
         crho = len(cpos) / float(np.prod(cbox))
         vpool = [disp()]
 
-        def verlet_chain(k):
-            return pmc.System(cpos, csp, crho, 0.231, pmc.JBB(), list_type=pmc.VerletList, list_parameters={"dr": 0.2}, seed=10, chain=k)
+        def verlet_chain(k, engine=0):
+            g = pmc.System(cpos, csp, crho, 0.231, pmc.JBB(), list_type=pmc.VerletList, list_parameters={"dr": 0.2}, seed=10, chain=k)
+            if engine:
+                g.set_sequential_engine(engine, 0)
+            return g
         one = verlet_chain(0)
-        pmc.mc_sweep(one, vpool, nsweeps=1, mode="sequential")
+        pmc.mc_sweep(one, vpool, nsweeps=2, mode="sequential")
         t0 = time.perf_counter()
-        st1 = pmc.mc_sweep(one, vpool, nsweeps=4, mode="sequential")
+        st1 = pmc.mc_sweep(one, vpool, nsweeps=100, mode="sequential")
         dt1 = time.perf_counter() - t0
+        vinfo = one.verlet_info()
+        lit = verlet_chain(0, engine=1)
+        pmc.mc_sweep(lit, vpool, nsweeps=1, mode="sequential")
+        t0 = time.perf_counter()
+        pmc.mc_sweep(lit, vpool, nsweeps=4, mode="sequential")
+        dtl = time.perf_counter() - t0
         chains = [verlet_chain(k) for k in range(256)]
         pmc.mc_sweep_many(chains, vpool, nsweeps=1, mode="sequential")
         t0 = time.perf_counter()
-        pmc.mc_sweep_many(chains, vpool, nsweeps=2, mode="sequential")
+        pmc.mc_sweep_many(chains, vpool, nsweeps=20, mode="sequential")
         dtn = time.perf_counter() - t0
         rows.append({"config": "the reference's CI system (test/runtests.jl:22-91): config_0, N=1290 2-D ternary JBB, T=0.231, VerletList dr=0.2, Displacement sigma=0.05; "
-                               "the reference's sequential chain on the literal loop (engine 1)",
-                     "reference_order_chain": {"moves_per_s_one_chain": 4 * one.N / dt1, "us_per_step_one_chain": 1e6 * dt1 / (4 * one.N),
-                                               "moves_per_s_256_chains_one_launch": 256 * 2 * one.N / dtn,
+                               "the reference's sequential chain on engine 4 (state in LDS, one resolver and twelve evaluators per chain)",
+                     "reference_order_chain": {"moves_per_s_one_chain": 100 * one.N / dt1, "us_per_step_one_chain": 1e6 * dt1 / (100 * one.N),
+                                               "kernel_moves_per_s_one_chain": 100 * one.N / (st1.sweep_kernel_ms * 1e-3),
+                                               "moves_per_s_256_chains_one_launch": 256 * 20 * one.N / dtn,
+                                               "moves_per_s_one_chain_literal_loop_engine_1": 4 * one.N / dtl,
+                                               "steps_the_resolver_ran_alone": vinfo[1] / float(max(1, vinfo[3])),
+                                               "list_rebuilds_per_step": vinfo[2] / float(max(1, vinfo[3])),
                                                "acceptance": [float(st1.accepted[0]) / max(1, st1.attempted[0])]},
                      "cpu_oracle_moves_per_s": _oracle_rate(lambda: O.System(cpos, csp, crho, 0.231, O.jbb(), O.VERLETLIST, 0.2),
                                                             O.make_pool([{"kind": "Displacement", "sigma": SIGMA_MOVE}]), 10, budget_cpu_s)})
