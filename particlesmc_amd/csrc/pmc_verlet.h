@@ -789,54 +789,80 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         int zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
         sqv_rec_request(spec0, zero, raw);
-        for (int t = 0; t < nsteps_r; t++, slot = (slot + 1 == NB) ? 0 : slot + 1) {
-            SQVM("step_begin");
-            const SqvSpec *rec = spec0 + slot;
+        // The loop is two loops: the inner one takes the steps that ARE their evaluation (seven in ten) and nothing else -- a
+        // record, one round trip for the stamp of i and its row, the stores -- and leaves at the first step that needs a list
+        // edit or a re-evaluation; that step is handled behind it, and the inner loop starts again.
+        int t = 0;
+        bool stop = false, fin = false;
+        while (!stop && !fin) {
+            const SqvSpec *rec = spec0;
             SqvSpec sp;
-            sqv_rec_decode(raw, sp);
-            bool stop = false;
-            SQVM("rec_ready");
-            SQVT(1);
-            if (sp.seq != t + 1) SQVT_COUNT(14);
-            while (sp.seq != t + 1) {
-                nwait++;
-                SQVT_COUNT(13);
-                if (sqv_ld(p_err)) { stop = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-                sqv_rec_request(rec, zero, raw);
+            int now = 0, window = 0, m = 0, i = 0;
+            bool clean = false, clean_known = false;
+            while (true) {
+                SQVM("step_begin");
+                rec = spec0 + slot;
                 sqv_rec_decode(raw, sp);
-            }
-            if (!stop) sqv_rec_request(spec0 + ((slot + 1 == NB) ? 0 : slot + 1), zero, raw);     // the next step's, in flight behind this step
-            if (stop) break;
-            SQVT(0);
-            const unsigned short *lst = lst0 + slot * vcap;
-            const int now = t + 1, window = t - sp.s0;
-            v.stamp = (unsigned short)now;
-            const int m = (sp.flags >> 8) & 7;
-            bool ok = false, clean_step = false;
-            if (sp.flags & SQV_DISP) {
-                const int i = sp.i;
+                SQVM("rec_ready");
+                SQVT(1);
+                if (sp.seq != t + 1) SQVT_COUNT(14);
+                while (sp.seq != t + 1) {
+                    nwait++;
+                    SQVT_COUNT(13);
+                    if (sqv_ld(p_err)) { stop = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    sqv_rec_request(rec, zero, raw);
+                    sqv_rec_decode(raw, sp);
+                }
+                if (stop) break;
+                sqv_rec_request(spec0 + ((slot + 1 == NB) ? 0 : slot + 1), zero, raw);     // the next step's, in flight behind this step
+                SQVT(0);
+                now = t + 1; window = t - sp.s0;
+                v.stamp = (unsigned short)now;
+                m = (sp.flags >> 8) & 7;
+                clean_known = false;
+                if ((sp.flags & (SQV_DISP | SQV_SERIAL | SQV_REBUILD)) != SQV_DISP) break;
+                i = sp.i;
                 // (one round trip: the mark of i, and its row in case the step stores a position)
-                const int rj_ = (lane < vcap) ? (int)v.vrows[i * vcap + lane] : 0;
+                const int rj_ = (int)v.vrows[i * vcap + min(lane, vcap - 1)];      // (every lane: a read under a lane mask is scheduled behind the wait for the two below)
                 asm volatile("" ::: "memory");
                 const int ti = v.touch[i];
                 const int ni_ = v.vcnt[i];
-                const bool clean = sqv_fresh(ti, now, window);
-                clean_step = clean;
-                if (clean && !(sp.flags & (SQV_SERIAL | SQV_REBUILD))) {
-                    // nobody has touched i or its row since the evaluation began: the evaluation is the step
-                    ok = (sp.flags & SQV_OK) != 0;
-                    if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }     // src/moves.jl:17,79
-                    if (sp.flags & SQV_CHG) {
-                        // (the stored position is within dr / 2 of the last update: update_neighbour_list! returns at once)
-                        if (D == 3) sp.xw[2] = rec->xw[2];
-                        if (lane < D) v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
-                        if (lane < ni_) v.touch[rj_] = v.stamp;
-                        for (int q = PMC_WAVE + lane; q < ni_; q += PMC_WAVE) v.touch[v.vrows[i * vcap + q]] = v.stamp;
-                        if (lane == 0) { v.touch[i] = v.stamp; v.ctouch[sp.c0] = v.stamp; }
-                    }
-                    SQVM("clean_end");
-                    SQVT(2);
+                clean = sqv_fresh(ti, now, window);
+                clean_known = true;
+                if (!clean) break;
+                // nobody has touched i or its row since the evaluation began: the evaluation is the step
+                const bool ok = (sp.flags & SQV_OK) != 0;
+                if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }     // src/moves.jl:17,79
+                if (sp.flags & SQV_CHG) {
+                    // (the stored position is within dr / 2 of the last update: update_neighbour_list! returns at once)
+                    if (D == 3) sp.xw[2] = rec->xw[2];
+                    if (lane < D) v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
+                    if (lane < ni_) v.touch[rj_] = v.stamp;
+                    for (int q = PMC_WAVE + lane; q < ni_; q += PMC_WAVE) v.touch[v.vrows[i * vcap + q]] = v.stamp;
+                    if (lane == 0) { v.touch[i] = v.stamp; v.ctouch[sp.c0] = v.stamp; }
+                }
+                SQVM("clean_end");
+                SQVT(2);
+                if (lane == 0) {
+                    (void)__hip_atomic_fetch_add(p_cnt + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ok) (void)__hip_atomic_fetch_add(p_cnt + 8 + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // the evaluators are told that the step is over: the LDS takes this store behind everything the step stored there
+                asm volatile("" ::: "memory");
+                if (lane == 0) sqv_st_relaxed(p_done, now);
+                t++;
+                slot = (slot + 1 == NB) ? 0 : slot + 1;
+                if (t >= nsteps_r) { fin = true; break; }
+            }
+            if (stop || fin) break;
+            // ---- step t needs a list edit or a re-evaluation
+            const unsigned short *lst = lst0 + slot * vcap;
+            bool ok = false;
+            if (sp.flags & SQV_DISP) {
+                i = sp.i;
+                if (!clean_known) clean = sqv_fresh(v.touch[i], now, window);
+                if (false) {
                 } else if (clean && (sp.flags & SQV_LIST) && sqv_cells_clean<D>(v, sp.c2, now, window) &&
                            (!(sp.flags & SQV_REB2) || sqv_cells_clean<D>(v, sp.c3, now, window))) {
                     // ... and nobody has touched the cells its scan read: the rebuild is applied from the evaluator's list.
@@ -888,7 +914,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                     nser++;
                     SQVT_COUNT(11);
                     const SqGen ge = v.gen[t & (SQV_GEN - 1)];
-                    ok = sqv_disp_serial<D, KIND>(s, v, tb, i, ge, T, E, nreb, clean && (sp.flags & SQV_REBUILD), sp.e1);
+                    ok = sqv_disp_serial<D, KIND>(s, v, tb, i, ge, T, E, nreb, clean && (sp.flags & SQV_REBUILD) != 0, sp.e1);
                 }
             } else {
                 // DiscreteSwap (src/moves.jl:137-207): four sums, species exchange, SpeciesList fix-up; the SpeciesList
@@ -934,11 +960,9 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                 }
                 SQVT(8);
             }
-            // (a row or cell vector that overflowed in this step -- only the paths that edit lists can tell -- ends the launch here:
-            // the state is no longer the chain's, and nothing of it is written back)
-            if (!(sp.flags & SQV_DISP) || (sp.flags & (SQV_SERIAL | SQV_REBUILD)) || !clean_step) {
-                if (sqv_ld(p_err)) break;
-            }
+            // (a row or cell vector that overflowed in this step ends the launch here: the state is no longer the chain's, and
+            // nothing of it is written back)
+            if (sqv_ld(p_err)) break;
             SQVM("step_end");
             if (lane == 0) {
                 (void)__hip_atomic_fetch_add(p_cnt + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -949,6 +973,9 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
             // evaluator that reads a stale positions_at_last_update[i] reads it for a particle this step has marked.)
             asm volatile("" ::: "memory");
             if (lane == 0) sqv_st_relaxed(p_done, now);
+            t++;
+            slot = (slot + 1 == NB) ? 0 : slot + 1;
+            if (t >= nsteps_r) fin = true;
         }
     } else if (wv == 4) {
         // ---- the GENERATOR: block B of the random parts takes the place of block B - 2 once the resolver is through with it

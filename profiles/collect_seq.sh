@@ -38,7 +38,14 @@ for w in big single; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $P/${w}_trace -- python3 profiles/mix_run.py $a > $P/${w}_run.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/${w}_sq -- python3 profiles/mix_run.py $a > /dev/null 2>&1
 done
+# round 6: engine 4 (VerletList chains in LDS, k_sq_verlet) on the reference's CI system: one chain of 100 sweeps, 256 chains of 20
+rm -rf $P/verlet_trace $P/verlet_many_trace $P/verlet_sq
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/verlet_trace -- python3 examples/verlet_rate.py 100 1 > $P/verlet.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/verlet_many_trace -- python3 examples/verlet_rate.py 20 256 > $P/verlet_many.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/verlet_sq -- python3 examples/verlet_rate.py 100 1 > /dev/null 2>&1
+python3 examples/verlet_rate.py 100 1 16 64 256 1024 > gpurun_out/verlet_rate_table.jsonl 2>&1
+SWAPS=1 python3 examples/verlet_rate.py 100 1 256 >> gpurun_out/verlet_rate_table.jsonl 2>&1
 mkdir -p gpurun_out/seq_summary
-PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py ${ROUND:-r05} --seq-only
-rm -rf $P/seq_small_trace $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace $P/big_sq $P/big_trace $P/single_sq $P/single_trace
+PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py ${ROUND:-r06} --seq-only
+rm -rf $P/seq_small_trace $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace $P/big_sq $P/big_trace $P/single_sq $P/single_trace $P/verlet_trace $P/verlet_many_trace $P/verlet_sq
 ls gpurun_out/seq_summary

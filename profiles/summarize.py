@@ -181,6 +181,30 @@ def _seq_summary():
             if "SQ_INSTS_VALU" in rec:
                 rec["valu_wave_instructions_per_move"] = rec["SQ_INSTS_VALU"]["mean_per_launch"] / nmoves
             json.dump(rec, open(os.path.join(OUT, f"{tag}_pmc_{w}.json"), "w"), indent=1)
+    # round 6: engine 4 (VerletList chains in LDS, k_sq_verlet) on the reference's CI system: one chain, and 256 chains in one launch
+    ver = {}
+    for sub, name in (("verlet_trace", "one_chain"), ("verlet_many_trace", "256_chains")):
+        st = sorted(glob.glob(os.path.join(SRC, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+        if not st:
+            continue
+        shutil.copy(st[-1], os.path.join(OUT, f"{tag}_verlet_{name}_kernel_stats.csv"))
+        rows = [r for r in csv.DictReader(open(st[-1])) if "k_sq_verlet" in r["Name"] or "k_ref" in r["Name"]]
+        ver[name] = {"kernels": {r["Name"].split("(")[0]: {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                                             "total_ms": float(r["TotalDurationNs"]) / 1e6} for r in rows}}
+        log = os.path.join(SRC, sub.replace("_trace", ".log"))
+        if os.path.exists(log):
+            ver[name]["run"] = [json.loads(l) for l in open(log) if l.startswith("{")]
+    for k, v in counters("verlet_sq").items():
+        if "k_sq_verlet" in k:
+            ver.setdefault("pmc_one_chain", {})["kernel"] = k
+            for c, vals in v.items():
+                ver["pmc_one_chain"][c] = {"mean_per_launch": sum(vals) / max(1, len(vals)), "launches": len(vals)}
+    if ver:
+        json.dump(ver, open(os.path.join(OUT, f"{tag}_verlet.json"), "w"), indent=1)
+        print(f"wrote profiles/{tag}_verlet.json")
+    src = os.path.join(ROOT, "gpurun_out", "verlet_rate_table.jsonl")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(OUT, f"{tag}_verlet_rate_table.jsonl"))
     if out:
         json.dump(out, open(os.path.join(OUT, f"{tag}_seq.json"), "w"), indent=1)
         print(f"wrote profiles/{tag}_seq.json")
