@@ -793,6 +793,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         // record, one round trip for the stamp of i and its row, the stores -- and leaves at the first step that needs a list
         // edit or a re-evaluation; that step is handled behind it, and the inner loop starts again.
         int t = 0;
+        unsigned int cntv = 0;                                   // per-move counters of the launch, one per lane (a launch has < 2^32 steps)
         bool stop = false, fin = false;
         while (!stop && !fin) {
             const SqvSpec *rec = spec0;
@@ -828,6 +829,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                 asm volatile("" ::: "memory");
                 const int ti = v.touch[i];
                 const int ni_ = v.vcnt[i];
+                asm volatile("" : : "v"(rj_), "v"(ti), "v"(ni_));      // (all three requested before the first is waited for)
                 clean = sqv_fresh(ti, now, window);
                 clean_known = true;
                 if (!clean) break;
@@ -844,10 +846,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                 }
                 SQVM("clean_end");
                 SQVT(2);
-                if (lane == 0) {
-                    (void)__hip_atomic_fetch_add(p_cnt + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (ok) (void)__hip_atomic_fetch_add(p_cnt + 8 + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                cntv += (lane == m || (ok && lane == 8 + m)) ? 1u : 0u;     // lane q: attempts of move q; lane 8 + q: its accepted steps
                 // the evaluators are told that the step is over: the LDS takes this store behind everything the step stored there
                 asm volatile("" ::: "memory");
                 if (lane == 0) sqv_st_relaxed(p_done, now);
@@ -964,10 +963,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
             // nothing of it is written back)
             if (sqv_ld(p_err)) break;
             SQVM("step_end");
-            if (lane == 0) {
-                (void)__hip_atomic_fetch_add(p_cnt + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (ok) (void)__hip_atomic_fetch_add(p_cnt + 8 + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            cntv += (lane == m || (ok && lane == 8 + m)) ? 1u : 0u;
             // the evaluators are told that the step is over: the LDS takes this store behind everything the step stored there.
             // (What it stored in global memory -- positions_at_last_update, the SpeciesList -- may still be on its way: an
             // evaluator that reads a stale positions_at_last_update[i] reads it for a particle this step has marked.)
@@ -977,6 +973,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
             slot = (slot + 1 == NB) ? 0 : slot + 1;
             if (t >= nsteps_r) fin = true;
         }
+        if (lane < 16) p_cnt[lane] = (int)cntv;
     } else if (wv == 4) {
         // ---- the GENERATOR: block B of the random parts takes the place of block B - 2 once the resolver is through with it
         for (int B = 2; (B << 6) < nsteps; B++) {
