@@ -888,7 +888,7 @@ static bool seq_verlet_caps(const pmc_system *h, int *vcap_out, int *ccap_out)
     const double sphere = (h->D == 3) ? 4.18879020478639 * r * r * r : 3.14159265358979 * r * r;
     const double mean_v = sphere * (double)h->N / vol;
     int vcap = std::min(h->vl_cap / 4 * 4, 1024);
-    while (vcap >= 4 && seq_verlet_layout(h, vcap, ccap, SQV_NW, nullptr) > SQ_LDS_MAX) vcap -= 4;
+    while (vcap >= 4 && seq_verlet_layout(h, vcap, ccap, 0, nullptr) > SQ_LDS_MAX) vcap -= 4;
     if (vcap < 4 || (double)vcap < 1.15 * mean_v + 3.0) return false;
     // rows of up to 4 * SQV_HW ids leave a list in registers (sqv_update): no more than that unless the expected list needs it
     if (vcap > 4 * SQV_HW && 1.5 * mean_v + 4.0 <= 4.0 * SQV_HW) vcap = 4 * SQV_HW;
@@ -938,7 +938,7 @@ static int sweep_sequential_verlet(pmc_system **hs, int n, const pmc_move *pool,
     memset(&s, 0, sizeof s);
     int vcap = 0, ccap = 0;
     if (!seq_verlet_caps(m, &vcap, &ccap)) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 4: not a VerletList system whose state fits the LDS");
-    const size_t lds = seq_verlet_layout(m, vcap, ccap, SQV_NW, &s);
+    const size_t lds = seq_verlet_layout(m, vcap, ccap, 0, &s);
     s.a = ref_args(m);
     for (int q = 0; q < 3; q++) { s.invbox[q] = 1.0 / s.a.box[q]; s.invcell[q] = (q < m->D) ? 1.0 / s.a.cell[q] : 1.0; }
     s.pool = make_pool(pool, npool);
@@ -983,7 +983,7 @@ static int sweep_sequential_verlet(pmc_system **hs, int n, const pmc_move *pool,
     for (long long done = 0; done < total; done += chunk) {
         s.nsteps = std::min(chunk, total - done);
         void *kargs[1] = {(void *)&s};
-        HIPCHK(m, hipLaunchKernel(kfn, dim3(n), dim3(SQV_NW * 64), kargs, lds, m->stream));
+        HIPCHK(m, hipLaunchKernel(kfn, dim3(n), dim3(pmc_sqv_threads()), kargs, lds, m->stream));
         HIPCHK(m, hipGetLastError());
         launches++;
     }

@@ -34,8 +34,10 @@
 #include "pmc_seq.h"
 
 #define SQV_GEN 128               // ring of random parts: two blocks of 64 steps
+#ifndef SQV_NW
 #define SQV_NW 16                 // wavefronts of a chain's workgroup: wavefront 0 resolves, 4 generates, 8 and 12 (the resolver's other SIMD mates) idle
-#define SQV_NB 12                 // evaluators (wavefronts 1-3, 5-7, 9-11, 13-15): evaluator e takes the steps t = e (mod SQV_NB)
+#endif
+#define SQV_NB (3 * SQV_NW / 4)   // evaluators (wavefronts 1-3, 5-7, 9-11, 13-15): evaluator e takes the steps t = e (mod SQV_NB)
 #ifndef SQV_LOOK
 #define SQV_LOOK 7                // an evaluator begins step t once the resolver has finished step t - SQV_LOOK - 1 (< SQV_NB: its record is free by then)
 #endif
@@ -44,6 +46,7 @@
 struct SqvArgs;
 const void *pmc_sqv_kernel(int d, int kind);      // pmc_verlet_inst.hip: k_sq_verlet<d, kind>
 size_t pmc_sqv_layout(int n, int d, int nspecies, int ncell, int nn, int vcap, int ccap, SqvArgs *s);   // ... the LDS layout of its workgroup
+int pmc_sqv_threads();                              // ... the threads of that workgroup
 void pmc_sqv_times(unsigned long long *out16);     // ... and the phase clock of a stamped build (-DPMC_DEBUG_TIME; zeros otherwise)
 
 // stamped builds: phase clock of chain 0's resolver (sums of s_memtime differences): 0 waiting at the batch barrier, 1 clearing

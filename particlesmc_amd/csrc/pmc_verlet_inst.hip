@@ -40,6 +40,8 @@ size_t pmc_sqv_layout(int n_, int d, int nspecies, int ncell, int nn_, int vcap,
     return o;
 }
 
+int pmc_sqv_threads() { return SQV_NW * 64; }
+
 const void *pmc_sqv_kernel(int d, int kind)
 {
 #define SQV_PICK(DD) (kind == 0 ? (const void *)k_sq_verlet<DD, 0> : kind == 1 ? (const void *)k_sq_verlet<DD, 1> : \
