@@ -239,8 +239,11 @@ int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
  * to ~17 000 particles (beyond 4096 in 3-D their positions stay in global memory, everything else in LDS), else 2 for
  * LinkedList / CellList; 4 for VerletList systems (src/neighbours.jl:387-543; the reference's CI system, test/runtests.jl:41-91)
  * whose positions, positions_at_last_update, cell vectors and neighbour lists fit the LDS: one workgroup per chain, the next
- * eight steps evaluated at once against the current state and resolved in step order; 1 for larger VerletList systems, for
- * still larger EmptyList systems and for swap moves between a species and itself.  window: pending steps per round of engine 2
+ * twelve steps behind the one being resolved evaluated by other wavefronts; 5 for EmptyList systems of a few hundred particles
+ * under pools of Displacements only (the reference's published benchmark, benchmark/particles_benchmarks.jl:10-28): as 4, and an
+ * evaluation that earlier steps have overtaken is repaired -- the pair terms of the particles stored in between replaced in its
+ * packed list, the ordered sums run again -- instead of discarded; 1 for larger VerletList systems, for still larger EmptyList
+ * systems and for swap moves between a species and itself.  window: pending steps per round of engine 2
  * (0: chosen from the cell count; at most 4096). */
 int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window);
 /* diagnostics of the last PMC_SEQUENTIAL call that ran engine 2: out[0] rounds, out[1] step evaluations, out[2] window,
@@ -249,7 +252,9 @@ int pmc_sequential_info(pmc_system *h, int64_t *out);
 /* diagnostics of the last PMC_SEQUENTIAL call that ran engine 4 (VerletList state in LDS): out[0] batches, out[1] steps that
  * wavefront 0 ran alone on the current state (list rebuilds of update_neighbour_list!, src/neighbours.jl:494-543, swaps, steps
  * whose inputs an earlier step of the batch had touched), out[2] list rebuilds, out[3] steps of the call the engine ran (the
- * rest, if a list outgrew its LDS row, ran on engine 1) */
+ * rest, if a list outgrew its LDS row, ran on engine 1).  After a call that ran engine 5: out[0] polls of the resolver for a record that
+ * was not ready, out[1] steps evaluated again from scratch (their own particle had been stored in between), out[2] steps whose
+ * evaluation was repaired, out[3] steps */
 int pmc_verlet_info(pmc_system *h, int64_t *out);
 
 /* Fault injection for the library's own tests (no reference counterpart; never needed by a host).  what =

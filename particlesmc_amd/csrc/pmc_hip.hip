@@ -1907,13 +1907,16 @@ extern "C" int pmc_delta_e(pmc_system *h, int64_t n, const int64_t *i, const dou
 }
 
 #include "pmc_verlet.h"
+#include "pmc_empty.h"
 #include "pmc_seq_host.h"
 
 extern "C" int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window)
 {
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: null handle");
-    if (engine < 0 || engine > 4 || window < 0 || window > SQ_KMAX)
-        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront), 2 (speculative windows), 3 (state in LDS) or 4 (VerletList state in LDS); window 0..4096");
+    if (engine < 0 || engine > 5 || window < 0 || window > SQ_KMAX)
+        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront), 2 (speculative windows), 3 (state in LDS), 4 (VerletList state in LDS) or 5 (small EmptyList systems, evaluations repaired); window 0..4096");
+    if (engine == 5 && !seq_empty_fits(h))
+        return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 5 needs an EmptyList system whose packed pair terms fit 160 KB of LDS (a few hundred particles)");
     if (engine == 4 && !seq_verlet_fits(h))
         return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 4 needs a VerletList system whose positions, cell vectors and neighbour lists fit 160 KB of LDS");
     if (engine == 3 && !seq_lds_fits(h, SQ_LDS_MAX))
@@ -1986,6 +1989,13 @@ static int sweep_literal_steps(pmc_system *h, const pmc_move *pool, int npool, l
 
 static int sweep_sequential(pmc_system *h, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
 {
+    if (nsweeps > 0 && h->list_type == 0 && (h->seq_engine == 0 || h->seq_engine == 5) && seq_empty_pool_ok(pool, npool) && seq_empty_fits(h)) {
+        // a small EmptyList system and Displacements only (the reference's published benchmark): state in LDS, the steps evaluated
+        // ahead and repaired term by term (pmc_empty.h, engine 5)
+        pmc_system *one[1] = {h};
+        return sweep_sequential_empty(one, 1, pool, npool, nsweeps, out);
+    }
+    if (h->seq_engine == 5) return fail(h, PMC_ERR_UNSUPPORTED, "sequential engine 5: an EmptyList system of a few hundred particles and a pool of Displacements only");
     if (nsweeps > 0 && seq_pool_ok(pool, npool) && h->seq_engine != 1 && h->seq_engine != 2 && h->seq_engine != 4 &&
         (h->seq_engine == 3 || (h->ncell_ref <= 343 && seq_lds_fits(h, SQ_LDS_AUTO)))) {
         // few cells per side: every step interacts with every other, and the whole state fits the LDS (pmc_seq.h, engine 3)
@@ -2480,6 +2490,13 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         if (int rc = validate_pool(hs[r], pool, npool, nsweeps)) return rc;
     }
     if (out) memset(out, 0, (size_t)n * sizeof *out);
+    if (mode == PMC_SEQUENTIAL && n > 1 && n <= 256 && nsweeps > 0 && hs[0]->list_type == 0 && seq_empty_pool_ok(pool, npool) && seq_lds_compatible(hs, n)) {
+        // small EmptyList chains of one shape and Displacements only, up to a chain per CU: engine 5 (pmc_empty.h), one workgroup
+        // per chain in one launch (more chains than CUs: engine 3 below, a wavefront or four per chain)
+        bool eok = seq_empty_fits(hs[0]);
+        for (int r = 0; r < n && eok; r++) if (hs[r]->seq_engine != 0 && hs[r]->seq_engine != 5) eok = false;
+        if (eok) return sweep_sequential_empty(hs, n, pool, npool, nsweeps, out);
+    }
     if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0 && seq_pool_ok(pool, npool) && seq_lds_compatible(hs, n)) {
         // the chains of a `parallel = true` run on the reference's own chain (src/moves.jl:57-81): small systems of one shape
         // run one wavefront per chain with their state in LDS, all chains in one launch (pmc_seq.h, engine 3)

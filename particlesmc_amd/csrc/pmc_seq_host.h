@@ -1031,3 +1031,103 @@ static int sweep_sequential_verlet(pmc_system **hs, int n, const pmc_move *pool,
     }
     return PMC_OK;
 }
+
+// ---- engine 5: small EmptyList chains in LDS, evaluations repaired term by term (pmc_empty.h) ------------------------------------
+
+static bool seq_empty_pool_ok(const pmc_move *pool, int npool)
+{
+    for (int m = 0; m < npool; m++) if (pool[m].kind != PMC_MOVE_DISPLACEMENT) return false;     // (a swap re-labels two particles: engine 3)
+    return npool > 0;
+}
+
+static bool seq_empty_fits(const pmc_system *h)
+{
+    if (h->list_type != 0 || h->N > 65000 || h->N < 2 || h->S > 8) return false;
+    return pmc_sqe_layout(h->N, h->D, h->S, nullptr) <= SQ_LDS_MAX;
+}
+
+// n EmptyList chains of one shape, nsweeps sweeps each of the reference's sequential chain, in shared launches of k_sq_empty (one
+// workgroup per chain)
+static int sweep_sequential_empty(pmc_system **hs, int n, const pmc_move *pool, int npool, int64_t nsweeps, pmc_stats *out)
+{
+    pmc_system *m = hs[0];
+    int rc = set_device(m);
+    if (rc) return rc;
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        if (!h->cells_built) { rc = pmc_build_cells(h); if (rc) return rc; }
+        if (int rs = refresh_stale_energy(h)) return rs;
+    }
+    SqeArgs s;
+    memset(&s, 0, sizeof s);
+    const size_t lds = pmc_sqe_layout(m->N, m->D, m->S, &s);
+    if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 5: the chain's packed terms do not fit the LDS");
+    s.a = ref_args(m);
+    for (int q = 0; q < 3; q++) s.invbox[q] = 1.0 / s.a.box[q];
+    s.pool = make_pool(pool, npool);
+    int ukind = m->models.empty() ? 4 : (int)m->models[0].kind;
+    for (const pmc_pair_model &pm : m->models) if ((int)pm.kind != ukind) ukind = 4;
+    if (ukind > 3 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
+    const void *kfn = pmc_sqe_kernel(m->D, ukind);
+    HIPCHK(m, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<SqeChain> tab((size_t)n);
+    DevTmp dtab;
+    StreamDrain drain(m->stream);
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        SqeChain &c = tab[r];
+        memset(&c, 0, sizeof c);
+        c.pos = h->d_pos; c.species = h->d_species;
+        c.key0 = h->key[0]; c.key1 = h->key[1];
+        c.step0 = h->step_ctr;
+        c.energy = h->energy;
+        c.temperature = h->p.temperature;
+    }
+    HIPCHK(m, dtab.alloc((size_t)n * sizeof(SqeChain)));
+    s.chains = dtab.as<SqeChain>();
+    HIPCHK(m, hipMemcpyAsync(s.chains, tab.data(), (size_t)n * sizeof(SqeChain), hipMemcpyHostToDevice, m->stream));
+    for (int r = 1; r < n; r++) HIPCHK(hs[r], hipStreamSynchronize(hs[r]->stream));   // earlier work on the chains' own streams
+    HIPCHK(m, hipEventRecord(m->ev[0], m->stream));
+    const long long total = nsweeps * (int64_t)m->N;          // sweepstep = N, src/ParticlesMC.jl:246
+    const long long chunk = 1 << 20;
+    long long launches = 0;
+    for (long long done = 0; done < total; done += chunk) {
+        s.nsteps = std::min(chunk, total - done);
+        void *kargs[1] = {(void *)&s};
+        HIPCHK(m, hipLaunchKernel(kfn, dim3(n), dim3(pmc_sqv_threads()), kargs, lds, m->stream));
+        HIPCHK(m, hipGetLastError());
+        launches++;
+    }
+    HIPCHK(m, hipEventRecord(m->ev[1], m->stream));
+    HIPCHK(m, hipMemcpyAsync(tab.data(), s.chains, (size_t)n * sizeof(SqeChain), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, m->ev[0], m->ev[1]);
+    if (getenv("PMC_SQV_TIMES")) {                          // stamped builds: chain 0's resolver
+        unsigned long long t[16];
+        pmc_sqv_times(t);
+        fprintf(stderr, "sqe phase clock (resolver, s_memtime ticks): record %llu  log %llu  pair terms %llu  inserts %llu  chains %llu  rest %llu  (%.2f ms; chain 0: %llu patched, %llu again, %llu inserted, %llu polls)\n",
+                t[0], t[1], t[2], t[3], t[4], t[5], ms, tab[0].n_patched, tab[0].n_again, tab[0].n_inserted, tab[0].n_polls);
+    }
+    for (int r = 0; r < n; r++) {
+        pmc_system *h = hs[r];
+        const SqeChain &c = tab[r];
+        h->mc_binned = false;
+        h->e_fix_valid = false;
+        h->img_valid = false;
+        h->energy = c.energy;
+        h->step_ctr += (uint64_t)total;
+        h->sweep_ctr += (uint64_t)nsweeps;
+        h->sqv_last[0] = (long long)c.n_polls; h->sqv_last[1] = (long long)c.n_again; h->sqv_last[2] = (long long)c.n_patched; h->sqv_last[3] = total;
+        if (out) {
+            pmc_stats &o = out[r];
+            memset(&o, 0, sizeof o);
+            for (int q = 0; q < PMC_MAX_MOVES; q++) { o.attempted[q] = (int64_t)c.att[q]; o.accepted[q] = (int64_t)c.acc[q]; }
+            o.kernel_ms = ms;
+            o.sweep_kernel_ms = ms;
+            o.sweep_kernel_launches = launches;
+            o.energy = h->energy;
+        }
+    }
+    return PMC_OK;
+}

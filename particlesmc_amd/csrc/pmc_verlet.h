@@ -191,29 +191,21 @@ __device__ __forceinline__ double sqv_dist2(const SqvArgs &s, const double *xi, 
 // cnt of the wavefront; eight zeros lie behind every lane's terms
 __device__ __forceinline__ double sqv_chain(const double *buf, int cnt, int nmax)
 {
+    // blocks of eight terms, the next block requested before this one is added (one round trip in flight behind every eight
+    // additions); the buffer reaches sixteen entries past the longest list (pmc_sqv_layout, pmc_sqe_layout), what lies behind a
+    // lane's terms is masked
     double acc = 0.0;
-    {
-        // the first 24 terms are requested at once (a 2-D list has 20-odd non-zero terms: one round trip, then one chain of
-        // additions); the buffer is at least that long (pmc_sqv_layout), what lies behind the terms is masked
-        double t[3 * SQ_TERMS_PAD];
+    double cur[SQ_TERMS_PAD], nxt[SQ_TERMS_PAD];
 #pragma unroll
-        for (int q = 0; q < 3 * SQ_TERMS_PAD; q++) t[q] = buf[q];
+    for (int q = 0; q < SQ_TERMS_PAD; q++) cur[q] = buf[q];
+    for (int k = 0; k < nmax; k += SQ_TERMS_PAD) {
 #pragma unroll
-        for (int b = 0; b < 3; b++) {
-            if (b * SQ_TERMS_PAD < nmax) {
-                const bool in = b * SQ_TERMS_PAD < cnt;             // (a block that starts inside the terms ends inside their zero padding)
+        for (int q = 0; q < SQ_TERMS_PAD; q++) nxt[q] = buf[k + SQ_TERMS_PAD + q];
+        const bool in = k < cnt;                                   // (a block that starts inside the terms ends inside their zero padding)
 #pragma unroll
-                for (int q = 0; q < SQ_TERMS_PAD; q++) acc += in ? t[b * SQ_TERMS_PAD + q] : 0.0;
-            }
-        }
-    }
-    for (int k = 3 * SQ_TERMS_PAD; k < nmax; k += SQ_TERMS_PAD) {
-        double t[SQ_TERMS_PAD];
+        for (int q = 0; q < SQ_TERMS_PAD; q++) acc += in ? cur[q] : 0.0;
 #pragma unroll
-        for (int q = 0; q < SQ_TERMS_PAD; q++) t[q] = buf[k + q];
-        const bool in = k < cnt;
-#pragma unroll
-        for (int q = 0; q < SQ_TERMS_PAD; q++) acc += in ? t[q] : 0.0;
+        for (int q = 0; q < SQ_TERMS_PAD; q++) cur[q] = nxt[q];
     }
     return acc;
 }
@@ -418,7 +410,7 @@ __device__ __forceinline__ int sqv_scan(const SqvArgs &s, const SqvView &v, int 
     const int incl = sq_scan32(len);                                 // (inclusive; lanes >= cnt repeat the total)
     const int total = __builtin_amdgcn_readlane(incl, 31);
     unsigned short *row_i = v.vrows + i * vcap;
-    const int tmax = 2 * s.tstride - SQ_TERMS_PAD;
+    const int tmax = 2 * s.tstride - 2 * SQ_TERMS_PAD;
     int fill = 0, tcnt = 0;
     for (int base = 0; base < total; base += PMC_WAVE) {
         const int t = base + lane;

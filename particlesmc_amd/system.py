@@ -274,7 +274,8 @@ class Atoms(Particles):
     # --- how PMC_SEQUENTIAL sweeps run (same chain bit for bit; include/pmc.h) --------------------
     def set_sequential_engine(self, engine=0, window=0):
         """engine 0 auto, 1 the one-wavefront literal loop, 2 speculative windows, 3 the chain's state in LDS (small systems;
-        any number of chains per launch through mc_sweep_many), 4 a VerletList system's state in LDS with batches of steps;
+        any number of chains per launch through mc_sweep_many), 4 a VerletList system's state in LDS (one wavefront resolves, twelve
+        evaluate ahead), 5 the same for small EmptyList systems under Displacement-only pools (evaluations repaired term by term);
         window: pending steps per round of engine 2 (0 auto)."""
         _lib.check(_lib.lib().pmc_set_sequential_engine(self._h, int(engine), int(window)), self._h)
 

@@ -10,7 +10,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = [os.path.join(ROOT, "particlesmc_amd", "csrc", f) for f in ("pmc_kernels.h", "pmc_ref.h", "pmc_device.h", "pmc_hip.hip", "pmc_seq.h", "pmc_verlet.h")]
+SOURCES = [os.path.join(ROOT, "particlesmc_amd", "csrc", f) for f in ("pmc_kernels.h", "pmc_ref.h", "pmc_device.h", "pmc_hip.hip", "pmc_seq.h", "pmc_verlet.h", "pmc_empty.h")]
 CROSS = re.compile(r"readlane|__shfl|update_dpp|dpp_add|mov_dpp|ds_bpermute|ds_swizzle|wave_sum_exact|wave_sum\b")
 # branches that switch lanes off by their index: `if (lane == 0)`, `if (tid == 0 ...`, `if (lane < n ...`, `if (... && lane == i)`
 LANE_BRANCH = re.compile(r"\bif\s*\((?:[^()]|\([^()]*\))*\b(?:lane|tid|threadIdx\.x)\s*(?:==|<|<=|>|>=|!=)(?:[^()]|\([^()]*\))*\)")
