@@ -750,6 +750,19 @@ def other_configs(pmc, budget_cpu_s=1.2):
     t0 = time.perf_counter()
     stb = pmc.mc_sweep(one, poolb, nsweeps=1000, mode="sequential")
     dt1 = time.perf_counter() - t0
+    vinfo5 = one.verlet_info()
+    eng3 = pmc.System(posb, spb, 0.5342, 0.2, pmc.BHHP(), list_type=pmc.EmptyList, seed=42)
+    eng3.set_sequential_engine(3, 0)
+    pmc.mc_sweep(eng3, poolb, nsweeps=20, mode="sequential")
+    t0 = time.perf_counter()
+    pmc.mc_sweep(eng3, poolb, nsweeps=200, mode="sequential")
+    dt3 = time.perf_counter() - t0
+    c256 = [pmc.System(posb, spb, 0.5342, 0.2, pmc.BHHP(), list_type=pmc.EmptyList, seed=42, chain=k) for k in range(256)]
+    pmc.mc_sweep_many(c256, poolb, nsweeps=5, mode="sequential")
+    t0 = time.perf_counter()
+    pmc.mc_sweep_many(c256, poolb, nsweeps=200, mode="sequential")
+    dt256 = time.perf_counter() - t0
+    del c256
     chains = [pmc.System(posb, spb, 0.5342, 0.2, pmc.BHHP(), list_type=pmc.EmptyList, seed=42, chain=k) for k in range(1000)]
     pmc.mc_sweep_many(chains, poolb, nsweeps=5, mode="sequential")
     t0 = time.perf_counter()
@@ -758,9 +771,14 @@ def other_configs(pmc, budget_cpu_s=1.2):
     mob = O.model_matrix(lambda e, sg: O.soft_spheres(e, sg, 12), ((1.0, 1.0), (1.0, 1.0)), ((1.0, 1.2), (1.2, 1.4)))
     cpu = _oracle_rate(lambda: O.System(posb, spb, 0.5342, 0.2, mob, O.EMPTYLIST), O.make_pool([{"kind": "Displacement", "sigma": 0.1}]), 42, budget_cpu_s)
     rows.append({"config": "the reference's published benchmark as published (benchmark/particles_benchmarks.jl:10-28): N=216 3D 50:50 BHHP soft spheres n=12, "
-                           "rho=0.5342, T=0.2, sigma_move=0.1, EmptyList; the reference's sequential chain, state in LDS",
+                           "rho=0.5342, T=0.2, sigma_move=0.1, EmptyList; the reference's sequential chain on engine 5 (state in LDS, one resolver and six "
+                           "evaluators per chain, evaluations repaired term by term): one chain, 256 and 1000 chains in one launch; engine 3 (state in LDS, one step "
+                           "after the other) beside it",
                  "reference_order_chain": {"us_per_step_one_chain": 1e6 * dt1 / (216 * 1000), "moves_per_s_one_chain": 216 * 1000 / dt1,
+                                           "us_per_step_one_chain_engine_3": 1e6 * dt3 / (216 * 200),
+                                           "moves_per_s_256_chains": 256 * 216 * 200 / dt256,
                                            "moves_per_s_1000_chains": 1000 * 216 * 100 / dtn,
+                                           "steps_repaired": vinfo5[2] / float(max(1, vinfo5[3])), "steps_evaluated_again": vinfo5[1] / float(max(1, vinfo5[3])),
                                            "acceptance": [float(stb.accepted[0]) / max(1.0, float(stb.attempted[0]))]},
                  "cpu_oracle_moves_per_s": cpu, "cpu_oracle_us_per_step": 1e6 / cpu,
                  "reference_published": {"us_per_mc_step": 5.114, "us_per_step_in_mc_sweep": 1737.0 / 216, "hardware": "not stated (source comment)",

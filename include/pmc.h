@@ -240,11 +240,12 @@ int pmc_sweep(pmc_system *h, int32_t mode, const pmc_move *pool, int32_t npool,
  * LinkedList / CellList; 4 for VerletList systems (src/neighbours.jl:387-543; the reference's CI system, test/runtests.jl:41-91)
  * whose positions, positions_at_last_update, cell vectors and neighbour lists fit the LDS: one workgroup per chain, the next
  * twelve steps behind the one being resolved evaluated by other wavefronts; 5 for EmptyList systems of a few hundred particles
- * under pools of Displacements only (the reference's published benchmark, benchmark/particles_benchmarks.jl:10-28): as 4, and an
+ * under pools of Displacements only (the reference's published benchmark, benchmark/particles_benchmarks.jl:10-28): as 4 with six or twelve evaluators, and an
  * evaluation that earlier steps have overtaken is repaired -- the pair terms of the particles stored in between replaced in its
  * packed list, the ordered sums run again -- instead of discarded; 1 for larger VerletList systems, for still larger EmptyList
  * systems and for swap moves between a species and itself.  window: pending steps per round of engine 2
- * (0: chosen from the cell count; at most 4096). */
+ * (0: chosen from the cell count; at most 4096); with engine 5 the wavefronts per chain, 8 or 16 (0: sixteen while every chain
+ * of the call has a CU to itself, eight -- two chains to a CU -- beyond). */
 int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t window);
 /* diagnostics of the last PMC_SEQUENTIAL call that ran engine 2: out[0] rounds, out[1] step evaluations, out[2] window,
  * out[3] steps of that call folded into system.energy (= nsweeps * N when it ended well) */

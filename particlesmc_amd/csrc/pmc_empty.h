@@ -1,7 +1,7 @@
 // pmc_empty.h -- engine 5 of the reference-order chain: small EmptyList systems (src/neighbours.jl:13-44: every particle is a
 // neighbour of every other, summed in id order -- the list type of the reference's published benchmark,
 // benchmark/particles_benchmarks.jl:10-28: N = 216 BHHP soft spheres) with their state in LDS, one wavefront RESOLVING the steps
-// in order while twelve others EVALUATE the steps behind them, as engine 4 (pmc_verlet.h) does for VerletList systems.
+// in order while six or twelve others EVALUATE the steps behind them, as engine 4 (pmc_verlet.h) does for VerletList systems.
 //
 // What is different from engine 4: in an EmptyList system every step reads every particle, so a step that stores a position
 // touches the inputs of EVERY evaluation in flight -- an evaluation could hardly ever be taken as it is.  But it can be
@@ -20,13 +20,17 @@
 #include "pmc_verlet.h"
 
 #ifndef SQE_LOOK
-#define SQE_LOOK 5                // an evaluator begins step t once the resolver has finished step t - SQE_LOOK - 1 (< SQV_NB)
+#define SQE_LOOK 5                // an evaluator begins step t once the resolver has finished step t - SQE_LOOK - 1 (SQE_LOOK < 6 evaluators)
 #endif
-#define SQE_LOG 64                // the resolver's log of stores: a ring (an evaluation is at most SQV_NB steps old)
+// Sixteen wavefronts (the resolver, the generator, twelve evaluators) or eight (six evaluators).  The resolver bounds the rate and
+// SQE_LOOK the evaluations in flight, so six evaluators serve a chain nearly as well as twelve (1.30 against 1.26 us per step of
+// the reference's benchmark system) -- and two such chains share a CU (four wavefronts per SIMD at 128 VGPRs, their blocks in half
+// the LDS each): 3.1e8 moves/s from 512 chains on, against 2.0e8 with one chain per CU.  The host picks (seq_empty_waves).
+#define SQE_LOG 64                // the resolver's log of stores: a ring (an evaluation is at most 3 NW / 4 steps old)
 
 struct SqeArgs;
-const void *pmc_sqe_kernel(int d, int kind);      // pmc_verlet_inst.hip: k_sq_empty<d, kind>
-size_t pmc_sqe_layout(int n, int d, int nspecies, SqeArgs *s);   // ... the LDS layout of its workgroup (0: does not fit)
+const void *pmc_sqe_kernel(int d, int kind, int nw);      // pmc_verlet_inst.hip: k_sq_empty<d, kind, nw> (nw: 8 or 16 wavefronts)
+size_t pmc_sqe_layout(int n, int d, int nspecies, int nw, SqeArgs *s);   // ... the LDS layout of its workgroup
 
 struct SqeChain {                 // per-chain arguments (device table)
     double *pos;
@@ -236,11 +240,12 @@ __device__ __forceinline__ int sqe_insert(double *t, unsigned short *id, unsigne
     return cnt + 1;
 }
 
-template <int D, int KIND>
-__global__ __launch_bounds__(SQV_NW * 64) void k_sq_empty(SqeArgs s)
+template <int D, int KIND, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sq_empty(SqeArgs s)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sqe_smem[];
-    constexpr int NW = SQV_NW, NB = SQV_NB;
+    constexpr int NB = 3 * NW / 4;
+    static_assert(NB > SQE_LOOK && 2 * NB <= 64, "evaluators");
     const RefArgs &a = s.a;
     SqeChain &ch = s.chains[blockIdx.x];
     const int tid = threadIdx.x, nth = NW * 64, lane = wave_lane(), wv = tid >> 6;
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_empty(SqeArgs s)
                     int c1 = sp.c1, c2 = sp.c2;
                     // the first place either list changes at: the chains start at its block
                     int k1 = (lq >= 0 && !which && kk != 0xffff) ? kk : 0x7fff, k2 = (lq >= 0 && which && kk != 0xffff) ? kk : 0x7fff;
-                    k1 = sqe_min32(k1);                                   // (the entries of the log sit in lanes 0 .. 2 SQV_NB - 1)
+                    k1 = sqe_min32(k1);                                   // (the entries of the log sit in lanes 0 .. 2 NB - 1)
                     k2 = sqe_min32(k2);
                     // particles that have come inside a cutoff: a place in id order, one at a time (rare)
                     unsigned long long ins = __ballot(lq >= 0 && kk == 0xffff && u != 0.0);

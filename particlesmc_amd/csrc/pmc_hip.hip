@@ -1915,6 +1915,8 @@ extern "C" int pmc_set_sequential_engine(pmc_system *h, int32_t engine, int32_t 
     if (!h) return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: null handle");
     if (engine < 0 || engine > 5 || window < 0 || window > SQ_KMAX)
         return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 0 (auto), 1 (one wavefront), 2 (speculative windows), 3 (state in LDS), 4 (VerletList state in LDS) or 5 (small EmptyList systems, evaluations repaired); window 0..4096");
+    if (engine == 5 && window != 0 && window != 8 && window != 16)
+        return fail(h, PMC_ERR_BADARG, "pmc_set_sequential_engine: engine 5 takes window 0 (the library's choice), 8 or 16 (wavefronts per chain)");
     if (engine == 5 && !seq_empty_fits(h))
         return fail(h, PMC_ERR_UNSUPPORTED, "pmc_set_sequential_engine: engine 5 needs an EmptyList system whose packed pair terms fit 160 KB of LDS (a few hundred particles)");
     if (engine == 4 && !seq_verlet_fits(h))
@@ -2490,9 +2492,10 @@ extern "C" int pmc_sweep_many(pmc_system **hs, int32_t n, int32_t mode, const pm
         if (int rc = validate_pool(hs[r], pool, npool, nsweeps)) return rc;
     }
     if (out) memset(out, 0, (size_t)n * sizeof *out);
-    if (mode == PMC_SEQUENTIAL && n > 1 && n <= 256 && nsweeps > 0 && hs[0]->list_type == 0 && seq_empty_pool_ok(pool, npool) && seq_lds_compatible(hs, n)) {
-        // small EmptyList chains of one shape and Displacements only, up to a chain per CU: engine 5 (pmc_empty.h), one workgroup
-        // per chain in one launch (more chains than CUs: engine 3 below, a wavefront or four per chain)
+    if (mode == PMC_SEQUENTIAL && n > 1 && nsweeps > 0 && hs[0]->list_type == 0 && seq_empty_pool_ok(pool, npool) && seq_lds_compatible(hs, n)) {
+        // small EmptyList chains of one shape and Displacements only: engine 5 (pmc_empty.h), one workgroup (a CU) per chain in one
+        // launch -- 2.0e8 moves/s from 256 chains of the reference's benchmark system on, where engine 3 (a wavefront or four per
+        // chain, below) reaches 1.3e8 with a thousand
         bool eok = seq_empty_fits(hs[0]);
         for (int r = 0; r < n && eok; r++) if (hs[r]->seq_engine != 0 && hs[r]->seq_engine != 5) eok = false;
         if (eok) return sweep_sequential_empty(hs, n, pool, npool, nsweeps, out);

@@ -1043,7 +1043,19 @@ static bool seq_empty_pool_ok(const pmc_move *pool, int npool)
 static bool seq_empty_fits(const pmc_system *h)
 {
     if (h->list_type != 0 || h->N > 65000 || h->N < 2 || h->S > 8) return false;
-    return pmc_sqe_layout(h->N, h->D, h->S, nullptr) <= SQ_LDS_MAX;
+    return pmc_sqe_layout(h->N, h->D, h->S, 8, nullptr) <= SQ_LDS_MAX;
+}
+
+// wavefronts per chain of engine 5: sixteen (twelve evaluators) while every chain has a CU to itself, eight (two chains to a CU)
+// for more chains than that and for systems whose blocks only fit six times; pmc_set_sequential_engine(h, 5, 8 or 16) says which
+static int seq_empty_waves(const pmc_system *h, int n)
+{
+    const bool fits16 = pmc_sqe_layout(h->N, h->D, h->S, 16, nullptr) <= SQ_LDS_MAX;
+    if (h->seq_engine == 5 && h->seq_window == 8) return 8;
+    if (h->seq_engine == 5 && h->seq_window == 16) return fits16 ? 16 : 8;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->p.device) != hipSuccess || cus <= 0) cus = 256;
+    return fits16 && n <= cus ? 16 : 8;
 }
 
 // n EmptyList chains of one shape, nsweeps sweeps each of the reference's sequential chain, in shared launches of k_sq_empty (one
@@ -1060,7 +1072,8 @@ static int sweep_sequential_empty(pmc_system **hs, int n, const pmc_move *pool, 
     }
     SqeArgs s;
     memset(&s, 0, sizeof s);
-    const size_t lds = pmc_sqe_layout(m->N, m->D, m->S, &s);
+    const int nw = seq_empty_waves(m, n);
+    const size_t lds = pmc_sqe_layout(m->N, m->D, m->S, nw, &s);
     if (lds > SQ_LDS_MAX) return fail(m, PMC_ERR_UNSUPPORTED, "sequential engine 5: the chain's packed terms do not fit the LDS");
     s.a = ref_args(m);
     for (int q = 0; q < 3; q++) s.invbox[q] = 1.0 / s.a.box[q];
@@ -1068,7 +1081,7 @@ static int sweep_sequential_empty(pmc_system **hs, int n, const pmc_move *pool, 
     int ukind = m->models.empty() ? 4 : (int)m->models[0].kind;
     for (const pmc_pair_model &pm : m->models) if ((int)pm.kind != ukind) ukind = 4;
     if (ukind > 3 || getenv("PMC_SEQ_ANYKIND")) ukind = 4;
-    const void *kfn = pmc_sqe_kernel(m->D, ukind);
+    const void *kfn = pmc_sqe_kernel(m->D, ukind, nw);
     HIPCHK(m, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<SqeChain> tab((size_t)n);
     DevTmp dtab;
@@ -1094,7 +1107,7 @@ static int sweep_sequential_empty(pmc_system **hs, int n, const pmc_move *pool, 
     for (long long done = 0; done < total; done += chunk) {
         s.nsteps = std::min(chunk, total - done);
         void *kargs[1] = {(void *)&s};
-        HIPCHK(m, hipLaunchKernel(kfn, dim3(n), dim3(pmc_sqv_threads()), kargs, lds, m->stream));
+        HIPCHK(m, hipLaunchKernel(kfn, dim3(n), dim3(nw * 64), kargs, lds, m->stream));
         HIPCHK(m, hipGetLastError());
         launches++;
     }

@@ -52,9 +52,9 @@ const void *pmc_sqv_kernel(int d, int kind)
 }
 
 // LDS bytes of k_sq_empty for a system of this shape (and the offsets of its arrays)
-size_t pmc_sqe_layout(int n_, int d, int nspecies, SqeArgs *s)
+size_t pmc_sqe_layout(int n_, int d, int nspecies, int nw, SqeArgs *s)
 {
-    const size_t N = (size_t)n_, nb = SQV_NB;
+    const size_t N = (size_t)n_, nb = (size_t)(3 * nw / 4);
     const size_t k8 = (N + 7) / 8 * 8 + 2 * SQ_TERMS_PAD, kc = k8 > 32 ? k8 : 32;      // (eight zeros behind the terms, and the block a chain requests behind the one it adds)
     size_t o = sqv_align(N * d * sizeof(double), 16);
     const size_t o_species = o;   o = sqv_align(o + N, 16);
@@ -73,11 +73,12 @@ size_t pmc_sqe_layout(int n_, int d, int nspecies, SqeArgs *s)
     return o;
 }
 
-const void *pmc_sqe_kernel(int d, int kind)
+const void *pmc_sqe_kernel(int d, int kind, int nw)
 {
-#define SQE_PICK(DD) (kind == 0 ? (const void *)k_sq_empty<DD, 0> : kind == 1 ? (const void *)k_sq_empty<DD, 1> : \
-                      kind == 2 ? (const void *)k_sq_empty<DD, 2> : kind == 3 ? (const void *)k_sq_empty<DD, 3> : (const void *)k_sq_empty<DD, 4>)
-    return d == 3 ? SQE_PICK(3) : SQE_PICK(2);
+#define SQE_PICK(DD, WW) (kind == 0 ? (const void *)k_sq_empty<DD, 0, WW> : kind == 1 ? (const void *)k_sq_empty<DD, 1, WW> : \
+                          kind == 2 ? (const void *)k_sq_empty<DD, 2, WW> : kind == 3 ? (const void *)k_sq_empty<DD, 3, WW> : (const void *)k_sq_empty<DD, 4, WW>)
+    if (nw == 8) return d == 3 ? SQE_PICK(3, 8) : SQE_PICK(2, 8);
+    return d == 3 ? SQE_PICK(3, 16) : SQE_PICK(2, 16);
 #undef SQE_PICK
 }
 

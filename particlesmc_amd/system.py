@@ -276,7 +276,7 @@ class Atoms(Particles):
         """engine 0 auto, 1 the one-wavefront literal loop, 2 speculative windows, 3 the chain's state in LDS (small systems;
         any number of chains per launch through mc_sweep_many), 4 a VerletList system's state in LDS (one wavefront resolves, twelve
         evaluate ahead), 5 the same for small EmptyList systems under Displacement-only pools (evaluations repaired term by term);
-        window: pending steps per round of engine 2 (0 auto)."""
+        window: pending steps per round of engine 2 (0 auto); with engine 5 the wavefronts per chain, 8 or 16 (0 auto)."""
         _lib.check(_lib.lib().pmc_set_sequential_engine(self._h, int(engine), int(window)), self._h)
 
     def debug_inject(self, what=1):

@@ -45,7 +45,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $P/verlet_many_trace -- 
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/verlet_sq -- python3 examples/verlet_rate.py 100 1 > /dev/null 2>&1
 python3 examples/verlet_rate.py 100 1 16 64 256 1024 > gpurun_out/verlet_rate_table.jsonl 2>&1
 SWAPS=1 python3 examples/verlet_rate.py 100 1 256 >> gpurun_out/verlet_rate_table.jsonl 2>&1
+# round 6: engine 5 (small EmptyList chains in LDS, k_sq_empty) on the reference's published benchmark system: one chain, 256 chains
+rm -rf $P/empty_trace $P/empty_many_trace $P/empty_sq
+ENGINES=5 rocprofv3 --kernel-trace --stats --output-format csv -d $P/empty_trace -- python3 examples/empty_rate.py 1000 1 > $P/empty.log 2>&1
+ENGINES=5 rocprofv3 --kernel-trace --stats --output-format csv -d $P/empty_many_trace -- python3 examples/empty_rate.py 200 256 > $P/empty_many.log 2>&1
+ENGINES=5 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $P/empty_sq -- python3 examples/empty_rate.py 1000 1 > /dev/null 2>&1
+python3 examples/empty_rate.py 1000 1 16 256 1000 > gpurun_out/empty_rate_table.jsonl 2>&1
 mkdir -p gpurun_out/seq_summary
 PMC_PROFILES_OUT=gpurun_out/seq_summary python3 profiles/summarize.py ${ROUND:-r06} --seq-only
-rm -rf $P/seq_small_trace $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace $P/big_sq $P/big_trace $P/single_sq $P/single_trace $P/verlet_trace $P/verlet_many_trace $P/verlet_sq
+rm -rf $P/seq_small_trace $P/seq_trace $P/seq_many_trace $P/seq_sq $P/seq_many_sq $P/seq_fetch $P/seq_write $P/teams_sq $P/teams_trace $P/big_sq $P/big_trace $P/single_sq $P/single_trace $P/verlet_trace $P/verlet_many_trace $P/verlet_sq $P/empty_trace $P/empty_many_trace $P/empty_sq
 ls gpurun_out/seq_summary

@@ -205,6 +205,30 @@ def _seq_summary():
     src = os.path.join(ROOT, "gpurun_out", "verlet_rate_table.jsonl")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(OUT, f"{tag}_verlet_rate_table.jsonl"))
+    # round 6: engine 5 (small EmptyList chains in LDS, k_sq_empty) on the reference's published benchmark system
+    emp = {}
+    for sub, name in (("empty_trace", "one_chain"), ("empty_many_trace", "256_chains")):
+        st = sorted(glob.glob(os.path.join(SRC, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+        if not st:
+            continue
+        shutil.copy(st[-1], os.path.join(OUT, f"{tag}_empty_{name}_kernel_stats.csv"))
+        rows = [r for r in csv.DictReader(open(st[-1])) if "k_sq_empty" in r["Name"]]
+        emp[name] = {"kernels": {r["Name"].split("(")[0]: {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                                             "total_ms": float(r["TotalDurationNs"]) / 1e6} for r in rows}}
+        log = os.path.join(SRC, sub.replace("_trace", ".log"))
+        if os.path.exists(log):
+            emp[name]["run"] = [json.loads(l) for l in open(log) if l.startswith("{")]
+    for k, v in counters("empty_sq").items():
+        if "k_sq_empty" in k:
+            emp.setdefault("pmc_one_chain", {})["kernel"] = k
+            for c, vals in v.items():
+                emp["pmc_one_chain"][c] = {"mean_per_launch": sum(vals) / max(1, len(vals)), "launches": len(vals)}
+    if emp:
+        json.dump(emp, open(os.path.join(OUT, f"{tag}_empty.json"), "w"), indent=1)
+        print(f"wrote profiles/{tag}_empty.json")
+    src = os.path.join(ROOT, "gpurun_out", "empty_rate_table.jsonl")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(OUT, f"{tag}_empty_rate_table.jsonl"))
     if out:
         json.dump(out, open(os.path.join(OUT, f"{tag}_seq.json"), "w"), indent=1)
         print(f"wrote profiles/{tag}_seq.json")

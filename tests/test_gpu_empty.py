@@ -1,5 +1,5 @@
 """-m gpu: engine 5 of the reference-order chain -- small EmptyList systems (src/neighbours.jl:13-44) with their state in LDS, one
-wavefront resolving the steps in order while twelve others evaluate the steps behind them, and an evaluation that earlier steps
+wavefront resolving the steps in order while six or twelve others evaluate the steps behind them, and an evaluation that earlier steps
 have overtaken REPAIRED (the pair terms of the particles stored in between replaced in its packed list, the ordered sums run
 again) instead of discarded (csrc/pmc_empty.h) -- against the oracle's restatement of the reference's sequential chain, bit for
 bit: positions, system.energy, accept counts.
@@ -30,16 +30,18 @@ def _benchmark_system():
     return binary_lattice(216, frac_b=0.5, rho=0.5342, jitter=0.05, seed=42)
 
 
-def test_engine5_runs_the_reference_benchmark_system(gpu):
-    """benchmark/particles_benchmarks.jl:10-28 as published, on engine 5, three calls: after each the chain is the oracle's; most
-    steps are repaired evaluations, a few (their own particle had been stored since) are evaluated again."""
+@pytest.mark.parametrize("waves", [0, 8, 16])
+def test_engine5_runs_the_reference_benchmark_system(gpu, waves):
+    """benchmark/particles_benchmarks.jl:10-28 as published, on engine 5 (sixteen wavefronts per chain, eight, the library's
+    choice), three calls: after each the chain is the oracle's; most steps are repaired evaluations, a few (their own particle had
+    been stored since) are evaluated again."""
     from oracle import oracle as O
     pmc = gpu
     pos, sp, rho = _benchmark_system()
     N = len(pos)
     g = pmc.System(pos, sp, rho, 0.2, pmc.BHHP(), list_type=pmc.EmptyList, seed=42)
     o = O.System(pos, sp, rho, 0.2, O.bhhp(), O.EMPTYLIST)
-    g.set_sequential_engine(5, 0)
+    g.set_sequential_engine(5, waves)
     pm = [_disp(pmc, 0.1)]
     po = O.make_pool([{"kind": "Displacement", "sigma": 0.1}])
     done = 0
@@ -104,11 +106,11 @@ def test_engine5_pools_with_swaps_run_on_engine_3(gpu):
     assert ei.value.code == _lib.PMC_ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("nchains,n", [(9, 216), (100, 8), (300, 8)])
+@pytest.mark.parametrize("nchains,n", [(9, 216), (100, 8), (300, 8), (520, 216)])
 def test_engine5_chains_of_a_parallel_run(gpu, nchains, n):
-    """pmc_sweep_many on EmptyList chains of one shape: up to 256 chains run one workgroup each in ONE launch of k_sq_empty; more
-    chains than that run on engine 3 (a wavefront per chain) -- the reference's published benchmark system, and test/ss142d.jl's
-    chains of N = 8 (2-D soft spheres).  Every chain against the oracle's."""
+    """pmc_sweep_many on EmptyList chains of one shape: one workgroup per chain in ONE launch of k_sq_empty, more chains than the
+    chip has CUs (eight wavefronts per chain then, two chains to a CU) included -- the reference's published benchmark system, and test/ss142d.jl's chains of N = 8 (2-D soft spheres).
+    Every chain against the oracle's."""
     from oracle import oracle as O
     pmc = gpu
     rng = np.random.default_rng(nchains)
@@ -131,15 +133,14 @@ def test_engine5_chains_of_a_parallel_run(gpu, nchains, n):
         att, acc = o.mc_steps(po, 42, k, 0, nsw * N)
         assert sts[k].accepted[0] == acc[0], (k, sts[k].accepted, acc)
         assert np.array_equal(gs[k].position, o.positions()) and gs[k].energy[0] == o.energy, k
-    if nchains <= 256:
-        assert gs[0].verlet_info()[3] == nsw * N           # engine 5 ran the call
+    assert gs[0].verlet_info()[3] == nsw * N               # engine 5 ran the call
 
 
 def _draw(pmc, O, case):
     for attempt in range(50):
         rng = np.random.default_rng(515000 + case + 100000 * attempt)
         d = int(rng.choice([2, 3]))
-        n = int(rng.integers(2, 18)) if d == 2 else int(rng.integers(2, 7))
+        n = int(rng.integers(2, 27)) if d == 2 else int(rng.integers(2, 9))
         rho = float(np.exp(rng.uniform(np.log(0.05), np.log(1.3))))
         S = int(rng.choice([1, 2, 3]))
         pos, sp, _ = lj_lattice(n, jitter=0.08 * rho ** (-1.0 / d), seed=case, rho=rho, d=d)
@@ -164,9 +165,9 @@ def _draw(pmc, O, case):
 
 @pytest.mark.parametrize("case", range(FIRST, FIRST + NCASES))
 def test_random_empty_list_chain(gpu, case):
-    """Seeded random EmptyList chains under Displacement pools (one or two widths, up to a good part of the box): 4 to 289
+    """Seeded random EmptyList chains under Displacement pools (one or two widths, up to a good part of the box): 4 to 676
     particles, 2-D and 3-D, dilute to dense, frozen to hot, 1-3 species with random model matrices.  One to three calls, the
-    engine drawn per call (5, the default, 3, and 1 for the smallest)."""
+    engine drawn per call (5 with eight, sixteen or the library's choice of wavefronts; the default; 3; and 1 for the smallest)."""
     from oracle import oracle as O
     pmc = gpu
     rng, d, S, pos, sp, rho, T, seed, chain, mm, mo = _draw(pmc, O, case)
@@ -188,7 +189,7 @@ def test_random_empty_list_chain(gpu, case):
         nsw = int(rng.integers(1, 12))
         if engine == 1 and N * nsw > 1500:
             engine = 0
-        g.set_sequential_engine(engine, 0)
+        g.set_sequential_engine(engine, int(rng.choice([0, 8, 16])) if engine == 5 else 0)
         st = pmc.mc_sweep(g, pm, nsweeps=nsw, mode="sequential")
         att, acc = o.mc_steps(pool_o, seed, chain, done, nsw * N)
         done += nsw * N
