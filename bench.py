@@ -771,7 +771,7 @@ def other_configs(pmc, budget_cpu_s=1.2):
     mob = O.model_matrix(lambda e, sg: O.soft_spheres(e, sg, 12), ((1.0, 1.0), (1.0, 1.0)), ((1.0, 1.2), (1.2, 1.4)))
     cpu = _oracle_rate(lambda: O.System(posb, spb, 0.5342, 0.2, mob, O.EMPTYLIST), O.make_pool([{"kind": "Displacement", "sigma": 0.1}]), 42, budget_cpu_s)
     rows.append({"config": "the reference's published benchmark as published (benchmark/particles_benchmarks.jl:10-28): N=216 3D 50:50 BHHP soft spheres n=12, "
-                           "rho=0.5342, T=0.2, sigma_move=0.1, EmptyList; the reference's sequential chain on engine 5 (state in LDS, one resolver and six "
+                           "rho=0.5342, T=0.2, sigma_move=0.1, EmptyList; the reference's sequential chain on engine 5 (state in LDS, one resolver and six or twelve "
                            "evaluators per chain, evaluations repaired term by term): one chain, 256 and 1000 chains in one launch; engine 3 (state in LDS, one step "
                            "after the other) beside it",
                  "reference_order_chain": {"us_per_step_one_chain": 1e6 * dt1 / (216 * 1000), "moves_per_s_one_chain": 216 * 1000 / dt1,
