@@ -273,7 +273,9 @@ __device__ __forceinline__ void sqv_mark_row(const SqvArgs &s, const SqvView &v,
 }
 
 // i leaves the lists of its neighbours (deleteat! in src/neighbours.jl:508-511: the order of what stays is kept); every
-// neighbour is marked.  One wavefront (the resolver).  Returns SQV_ERR_LIST if i was missing from one of them.
+// neighbour is marked (MARK; the applier's rows were marked by the resolver when it handed the rebuild over).  One wavefront.
+// Returns SQV_ERR_LIST if i was missing from one of them.
+template <bool MARK = true>
 __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &v, int i)
 {
     const int lane = wave_lane();
@@ -317,7 +319,7 @@ __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &
                 }
 #pragma unroll
                 for (int k = 0; k < SQV_HW; k++) rw[k] = w[k];
-                if (hf == 0) { v.vcnt[j] = (unsigned short)(n - 1); v.touch[j] = v.stamp; }
+                if (hf == 0) { v.vcnt[j] = (unsigned short)(n - 1); if (MARK) v.touch[j] = v.stamp; }
             }
         }
     } else {
@@ -356,7 +358,7 @@ __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &
                     }
                 }
             }
-            if (lane < qn) { v.vcnt[jq] = (unsigned short)(nq - 1); v.touch[jq] = v.stamp; }
+            if (lane < qn) { v.vcnt[jq] = (unsigned short)(nq - 1); if (MARK) v.touch[jq] = v.stamp; }
         }
     }
     sq_wave_sync();
@@ -364,7 +366,8 @@ __device__ __forceinline__ int sqv_leave_lists(const SqvArgs &s, const SqvView &
 }
 
 // update_cell_list!(i, c, c2, ::VerletList), src/neighbours.jl:468-476: filter! keeps the order of cells[c], push! appends to
-// cells[c2].  One wavefront (the resolver); both cells are marked.
+// cells[c2].  One wavefront; both cells are marked (MARK: see sqv_leave_lists).
+template <bool MARK = true>
 __device__ __forceinline__ int sqv_cell_move(const SqvArgs &s, const SqvView &v, int i, int c, int c2)
 {
     const int lane = wave_lane();
@@ -384,8 +387,7 @@ __device__ __forceinline__ int sqv_cell_move(const SqvArgs &s, const SqvView &v,
         v.ccnt[c] = (unsigned short)(mk ? n - 1 : n);
         if (n2 < ccap) { v.crows[c2 * ccap + n2] = (unsigned short)i; v.ccnt[c2] = (unsigned short)(n2 + 1); }
         v.cs[i] = (unsigned short)c2;
-        v.ctouch[c] = v.stamp;
-        v.ctouch[c2] = v.stamp;
+        if (MARK) { v.ctouch[c] = v.stamp; v.ctouch[c2] = v.stamp; }
     }
     sq_wave_sync();
     return err;
@@ -694,10 +696,24 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
     v.gen = reinterpret_cast<SqGen *>(sqv_smem + s.o_gen);
     v.ctl = reinterpret_cast<int *>(sqv_smem + s.o_ctl);
     int *const p_err = v.ctl, *const p_done = v.ctl + 1, *const p_gen = v.ctl + 2, *const p_cnt = v.ctl + 4;   // [4 .. 19]: attempted, accepted per move
+    // The APPLIER (wavefront 8): the list edits of a rebuild the resolver takes from an evaluator's list -- i leaves its old
+    // neighbours' rows, joins those of the new list, moves between cell vectors -- are handed over as a JOB and applied behind
+    // the resolver's back, in the order they were handed over.  The resolver marks everything the job will edit when it hands
+    // it over (so every evaluation that has read or will read a row in the making is void, as if the edit had been made on the
+    // spot), and waits for the applier only before a step it has to run itself on the lists.  [3]: jobs applied; [24]: jobs
+    // handed over; [25]: the resolver is through; [28 .. 31]: the step (+ 1) of job k mod 4; [32 ..]: the jobs, six words each
+    constexpr int SQV_JQ = 4;
+    int *const p_applied = v.ctl + 3, *const p_posted = v.ctl + 24, *const p_fin = v.ctl + 25, *const p_jstep = v.ctl + 28, *const p_job = v.ctl + 32;
+    // The SECOND OPINION (wavefront 12): a step whose evaluation does not stand is evaluated again on the state as it is, by a
+    // wavefront that has nothing else to do (and none of the resolver's registers to keep alive); [26]: the step (+ 1) the
+    // resolver asks for, [27]: the step (+ 1) whose record is ready
+    int *const p_ask = v.ctl + 26, *const p_told = v.ctl + 27;
+    static_assert(NW > 12, "wavefront 8 applies the rebuilds, wavefront 12 evaluates again");
     SqvSpec *const spec0 = reinterpret_cast<SqvSpec *>(sqv_smem + s.o_spec);            // [NB]: evaluator e's record
     unsigned short *const lst0 = reinterpret_cast<unsigned short *>(sqv_smem + s.o_lst);   // [NB][vcap]: ... and its list
     const int ev = (wv & 3) ? (wv & 3) - 1 + 3 * (wv >> 2) : -1;          // evaluator 0 .. NB - 1, or none
     double *const tb = reinterpret_cast<double *>(sqv_smem + s.o_terms) + (size_t)max(ev, 0) * 2 * s.tstride;   // (an evaluator's terms of the sum over a rebuilt list)
+    double *const tbr = reinterpret_cast<double *>(sqv_smem + s.o_terms);
     {
         DevModel *lm = reinterpret_cast<DevModel *>(sqv_smem + s.o_models);
         const int *src = reinterpret_cast<const int *>(a.models);
@@ -706,7 +722,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         v.models = lm;
     }
     // -- the chain's state into LDS (rows, cell vectors and marks zero-filled first: whatever an evaluator reads is a valid id)
-    if (tid < 24) v.ctl[tid] = 0;
+    if (tid < 64) v.ctl[tid] = 0;
     for (int k = tid; k < (N * vcap + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.vrows)[k] = 0u;
     for (int k = tid; k < (s.ncell * ccap + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.crows)[k] = 0u;
     for (int k = tid; k < (N + 1) / 2; k += nth) reinterpret_cast<unsigned int *>(v.touch)[k] = 0u;
@@ -790,6 +806,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         int t = 0;
         unsigned int cntv = 0;                                   // per-move counters of the launch, one per lane (a launch has < 2^32 steps)
         bool stop = false, fin = false;
+        int posted = 0;                                          // jobs handed to the applier
         while (!stop && !fin) {
             const SqvSpec *rec = spec0;
             SqvSpec sp;
@@ -853,67 +870,128 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
             // ---- step t needs a list edit or a re-evaluation
             const unsigned short *lst = lst0 + slot * vcap;
             bool ok = false;
+            bool handed = false;
             if (sp.flags & SQV_DISP) {
                 i = sp.i;
-                if (!clean_known) clean = sqv_fresh(v.touch[i], now, window);
-                if (false) {
-                } else if (clean && (sp.flags & SQV_LIST) && sqv_cells_clean<D>(v, sp.c2, now, window) &&
-                           (!(sp.flags & SQV_REB2) || sqv_cells_clean<D>(v, sp.c3, now, window))) {
-                    // ... and nobody has touched the cells its scan read: the rebuild is applied from the evaluator's list.
-                    // Net effect of update_neighbour_list! at the trial position (and again at the reverted one, REB2): i has
-                    // left its old neighbours' lists and is appended to those of the final list; the cell vectors took
-                    // every move in turn
-                    ok = (sp.flags & SQV_OK) != 0;
-                    if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }
-                    sp.xw[2] = rec->xw[2]; sp.xl[0] = rec->xl[0]; sp.xl[1] = rec->xl[1]; sp.xl[2] = rec->xl[2];      // (the rest of the record: the evaluator leaves it alone until this step is over)
-                    int err = sqv_leave_lists(s, v, i);
-                    const int c = v.cs[i];
-                    if (c != sp.c2) err |= sqv_cell_move(s, v, i, c, sp.c2);
-                    if (sp.c3 != sp.c2) err |= sqv_cell_move(s, v, i, sp.c2, sp.c3);
-                    unsigned short *row_i = v.vrows + i * vcap;
-                    const int nl = sp.nl;
-                    for (int q = lane; q < nl; q += PMC_WAVE) {
-                        const int j = lst[q];
-                        const int nj = v.vcnt[j];
-                        if (nj < vcap) {
-                            v.vrows[j * vcap + nj] = (unsigned short)i;
-                            v.vcnt[j] = (unsigned short)(nj + 1);
-                            v.touch[j] = v.stamp;
-                        } else {
-                            err |= SQV_ERR_ROW;
+                for (int pass = 0; ; pass++) {
+                    // Everything the hand-over of a rebuild reads, in TWO round trips (every address is in the record): the mark of
+                    // i, its cell, its row and the new list (for the marks), the cells the scans read; then those cells' marks.
+                    bool take = false;
+                    int c_old = 0, ni = 0, rj = 0, lj = 0, applied_seen = 0;
+                    if (sp.flags & SQV_LIST) {
+                        const int ti = v.touch[i];
+                        const int cnt2 = v.nbrcnt[sp.c2], cnt3 = v.nbrcnt[sp.c3];
+                        const int nb2 = v.nbr[sp.c2 * NN + min(lane, NN - 1)], nb3 = v.nbr[sp.c3 * NN + min(lane, NN - 1)];
+                        c_old = v.cs[i];
+                        ni = v.vcnt[i];
+                        rj = v.vrows[i * vcap + min(lane, vcap - 1)];
+                        lj = lst[min(lane, vcap - 1)];
+                        applied_seen = sqv_ld_relaxed(p_applied);
+                        sp.xw[2] = rec->xw[2]; sp.xl[0] = rec->xl[0]; sp.xl[1] = rec->xl[1]; sp.xl[2] = rec->xl[2];      // (the rest of the record: the evaluator leaves it alone until this step is over)
+                        asm volatile("" : : "v"(ti), "v"(cnt2), "v"(cnt3), "v"(nb2), "v"(nb3), "v"(c_old), "v"(ni), "v"(rj), "v"(lj), "v"(applied_seen));
+                        const int t2 = v.ctouch[nb2], t3 = v.ctouch[nb3];
+                        clean = sqv_fresh(ti, now, window);
+                        bool bad = !clean;
+                        bad |= lane < cnt2 && !sqv_fresh(t2, now, window);
+                        bad |= (sp.flags & SQV_REB2) && lane < cnt3 && !sqv_fresh(t3, now, window);
+                        take = __ballot(bad) == 0ull;
+                    } else if (!clean_known) {
+                        clean = sqv_fresh(v.touch[i], now, window);
+                    }
+                    if (take) {
+                        // ... and nobody has touched the cells its scan read: the rebuild is taken from the evaluation's list.
+                        // Net effect of update_neighbour_list! at the trial position (and again at the reverted one, REB2): i has
+                        // left its old neighbours' lists and is appended to those of the final list; the cell vectors took
+                        // every move in turn.  The edits are the applier's; here: the marks they need, the position, the job.
+                        // (i's own row and cell are nobody's job in the making: a job that edits them has marked i.)
+                        ok = (sp.flags & SQV_OK) != 0;
+                        if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }
+                        while (posted - applied_seen >= SQV_JQ) {
+                            if (sqv_ld(p_err)) { stop = true; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                            applied_seen = sqv_ld(p_applied);
                         }
-                        row_i[q] = (unsigned short)j;
+                        if (stop) break;
+                        const int c = c_old;
+                        const unsigned short *row_i = v.vrows + i * vcap;
+                        const int nl = sp.nl;
+                        if (lane < ni) v.touch[rj] = v.stamp;
+                        if (lane < nl) v.touch[lj] = v.stamp;
+                        for (int q = PMC_WAVE + lane; q < ni; q += PMC_WAVE) v.touch[row_i[q]] = v.stamp;
+                        for (int q = PMC_WAVE + lane; q < nl; q += PMC_WAVE) v.touch[lst[q]] = v.stamp;
+                        if (lane == 0) {
+                            v.touch[i] = v.stamp;
+                            v.ctouch[c] = v.stamp;
+                            v.ctouch[sp.c2] = v.stamp;
+                            v.ctouch[sp.c3] = v.stamp;
+                            int *job = p_job + 6 * (posted & (SQV_JQ - 1));
+                            job[0] = i; job[1] = slot; job[2] = sp.c2; job[3] = sp.c3; job[4] = nl;
+                            p_jstep[posted & (SQV_JQ - 1)] = now;
+                        }
+                        if (lane < D) {
+                            v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
+                            v.last[i * D + lane] = sqv_sel3(sp.xl, lane);
+                        }
+                        posted++;
+                        handed = true;
+                        nreb += (sp.flags & SQV_REB2) ? 2 : 1;
+                        napp++;
+                        SQVT_COUNT(10);
+                        SQVT(3);
+                        break;
                     }
-                    if (lane == 0) {
-                        v.vcnt[i] = (unsigned short)nl;
-                        v.touch[i] = v.stamp;
-                        v.ctouch[c] = v.stamp;
-                        v.ctouch[sp.c3] = v.stamp;
+                    // the evaluation does not stand (or the step is one an evaluation cannot settle): the lists as every job so
+                    // far leaves them, then ...
+                    if (pass == 0) { nser++; SQVT_COUNT(11); }
+                    while (sqv_ld(p_applied) != posted) {
+                        if (sqv_ld(p_err)) { stop = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    if (lane < D) {
-                        v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
-                        v.last[i * D + lane] = sqv_sel3(sp.xl, lane);
+                    if (stop) break;
+                    if (pass == 0) {
+                        // ... the step is evaluated AGAIN on the state as it stands, exactly as an evaluator would (by wavefront 12,
+                        // into the record and the buffers of the step's own evaluator, which is through with them and far from
+                        // its next step), and taken as above: a rebuilt list goes to the applier like any other
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the resolver's own earlier stores to positions_at_last_update)
+                        if (lane == 0) sqv_st(p_ask, 4 * now + 1);
+                        while (sqv_ld(p_told) != 4 * now + 1) __builtin_amdgcn_s_sleep(1);
+                        SqvRaw rawb;
+                        sqv_rec_request(rec, zero, rawb);
+                        sqv_rec_decode(rawb, sp);
+                        window = 0;
+                        clean_known = false;
+                        if ((sp.flags & (SQV_DISP | SQV_SERIAL | SQV_REBUILD)) == SQV_DISP) {
+                            // (the list stays: the evaluation is the step)
+                            ok = (sp.flags & SQV_OK) != 0;
+                            if (sp.flags & SQV_FINITE) { E += sp.de; if (!ok) E -= sp.de; }
+                            if (sp.flags & SQV_CHG) {
+                                if (D == 3) sp.xw[2] = rec->xw[2];
+                                if (lane < D) v.pos[i * D + lane] = sqv_sel3(sp.xw, lane);
+                                sqv_mark_row(s, v, i);
+                                if (lane == 0) v.ctouch[sp.c0] = v.stamp;
+                            }
+                            break;
+                        }
+                        if (sp.flags & SQV_LIST) continue;
                     }
-                    if (__ballot(err != 0)) {
-                        int e = err;
-#pragma unroll
-                        for (int sft = 32; sft >= 1; sft >>= 1) e |= __shfl_xor(e, sft, PMC_WAVE);
-                        if (lane == 0) atomicOr(p_err, e);
-                    }
-                    nreb += (sp.flags & SQV_REB2) ? 2 : 1;
-                    napp++;
-                    SQVT_COUNT(10);
-                    SQVT(3);
-                } else {
-                    nser++;
-                    SQVT_COUNT(11);
-                    const SqGen ge = v.gen[t & (SQV_GEN - 1)];
-                    ok = sqv_disp_serial<D, KIND>(s, v, tb, i, ge, T, E, nreb, clean && (sp.flags & SQV_REBUILD) != 0, sp.e1);
+                    // ... or (an inexact revert that re-lists the particle, a list longer than a row) run as the literal loop runs
+                    // it, by wavefront 12 as well
+                    if (lane == 0) { *reinterpret_cast<volatile double *>(v.ctl + 56) = E; sqv_st(p_ask, 4 * now + 2); }
+                    while (sqv_ld(p_told) != 4 * now + 2) __builtin_amdgcn_s_sleep(1);
+                    E = *reinterpret_cast<volatile double *>(v.ctl + 58);
+                    ok = v.ctl[60] != 0;
+                    break;
                 }
+                if (stop) break;
             } else {
                 // DiscreteSwap (src/moves.jl:137-207): four sums, species exchange, SpeciesList fix-up; the SpeciesList
                 // stays in global memory (the launch's working copy: this wavefront is its only reader and writer)
                 nser++;
+                while (sqv_ld(p_applied) != posted) {
+                    if (sqv_ld(p_err)) { stop = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (stop) break;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the resolver's own earlier stores to the SpeciesList)
                 const SqGen ge = v.gen[t & (SQV_GEN - 1)];
                 const int sa = s.pool.sp0[m], sb = s.pool.sp1[m];
@@ -963,12 +1041,17 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
             // (What it stored in global memory -- positions_at_last_update, the SpeciesList -- may still be on its way: an
             // evaluator that reads a stale positions_at_last_update[i] reads it for a particle this step has marked.)
             asm volatile("" ::: "memory");
-            if (lane == 0) sqv_st_relaxed(p_done, now);
+            if (lane == 0) {
+                if (handed) sqv_st_relaxed(p_posted, posted);       // (behind the job and its marks, before the step counter)
+                sqv_st_relaxed(p_done, now);
+            }
             t++;
             slot = (slot + 1 == NB) ? 0 : slot + 1;
             if (t >= nsteps_r) fin = true;
         }
         if (lane < 16) p_cnt[lane] = (int)cntv;
+        asm volatile("" ::: "memory");
+        if (lane == 0) sqv_st(p_fin, 1);
     } else if (wv == 4) {
         // ---- the GENERATOR: block B of the random parts takes the place of block B - 2 once the resolver is through with it
         for (int B = 2; (B << 6) < nsteps; B++) {
@@ -985,6 +1068,78 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) sqv_st(p_gen, B + 1);
         }
+    } else if (wv == 8) {
+        // ---- the APPLIER: the jobs in the order they were handed over
+        int applied = 0;
+        while (true) {
+            const int fin = sqv_ld(p_fin);                      // (read before the count: set behind the last job)
+            const int pw = sqv_ld(p_posted);
+            if (pw != applied) {
+                const int *job = p_job + 6 * (applied & (SQV_JQ - 1));
+                const int i = __builtin_amdgcn_readfirstlane(job[0]), jslot = __builtin_amdgcn_readfirstlane(job[1]);
+                const int c2 = __builtin_amdgcn_readfirstlane(job[2]), c3 = __builtin_amdgcn_readfirstlane(job[3]), nl = __builtin_amdgcn_readfirstlane(job[4]);
+                const unsigned short *lst = lst0 + jslot * vcap;
+                int err = sqv_leave_lists<false>(s, v, i);
+                const int c = v.cs[i];
+                if (c != c2) err |= sqv_cell_move<false>(s, v, i, c, c2);
+                if (c3 != c2) err |= sqv_cell_move<false>(s, v, i, c2, c3);
+                unsigned short *row_i = v.vrows + i * vcap;
+                for (int q = lane; q < nl; q += PMC_WAVE) {
+                    const int j = lst[q];
+                    const int nj = v.vcnt[j];
+                    if (nj < vcap) {
+                        v.vrows[j * vcap + nj] = (unsigned short)i;
+                        v.vcnt[j] = (unsigned short)(nj + 1);
+                    } else {
+                        err |= SQV_ERR_ROW;
+                    }
+                    row_i[q] = (unsigned short)j;
+                }
+                if (lane == 0) v.vcnt[i] = (unsigned short)nl;
+                if (__ballot(err != 0)) {
+                    int e = err;
+#pragma unroll
+                    for (int sft = 32; sft >= 1; sft >>= 1) e |= __shfl_xor(e, sft, PMC_WAVE);
+                    if (lane == 0) atomicOr(p_err, e);
+                }
+                applied++;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) sqv_st(p_applied, applied);
+                continue;
+            }
+            if (fin) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    } else if (wv == 12) {
+        // ---- the SECOND OPINION: step t on the state the resolver has stopped at
+        int told = 0;
+        while (true) {
+            const int fin = sqv_ld(p_fin);
+            const int ask = sqv_ld(p_ask);
+            if (ask != told) {
+                const int t = (ask >> 2) - 1, slot = t % NB;
+                const SqGen ge = v.gen[t & (SQV_GEN - 1)];
+                if ((ask & 3) == 1) {
+                    sqv_evaluate<D, KIND>(s, v, tbr + (size_t)slot * 2 * s.tstride, ge, T, spec0 + slot, lst0 + slot * vcap, t, t + 1);
+                } else {
+                    // the Displacement step as the literal loop runs it, on the live lists
+                    v.stamp = (unsigned short)(t + 1);
+                    double E12 = *reinterpret_cast<volatile double *>(v.ctl + 56);
+                    bool ok = false;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (this wavefront's own earlier stores to positions_at_last_update)
+                    ok = sqv_disp_serial<D, KIND>(s, v, tb, (int)mulhi32(ge.r1, (uint32_t)N), ge, T, E12, nser, false, 0.0);
+                    if (lane == 0) { *reinterpret_cast<volatile double *>(v.ctl + 58) = E12; v.ctl[60] = ok ? 1 : 0; }
+                }
+                told = ask;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) sqv_st(p_told, told);
+                continue;
+            }
+            if (fin) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane == 0) v.ctl[61] = (int)nser;                 // (here: the rebuilds of the steps this wavefront ran as the literal loop does)
+        nser = 0;
     } else if (ev >= 0) {
         // ---- an EVALUATOR: every NB-th step, begun once the resolver is within SQV_LOOK steps of it
         // (An evaluator is idle nine tenths of the time.  Twelve of them polling the control words every hundred cycles kept the
@@ -997,7 +1152,23 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                 const sqv_u4 c = *reinterpret_cast<const volatile sqv_u4 *>(v.ctl);      // err, done, random parts, -
                 if (c.x) { stop = true; break; }
                 s0 = (int)c.y;
-                if (s0 >= t - SQV_LOOK && (int)c.z > (t >> 6)) break;
+                if (s0 >= t - SQV_LOOK && (int)c.z > (t >> 6)) {
+                    // jobs the applier has not finished: the evaluation can vouch for the lists only up to the step before the
+                    // oldest of them (its step is looked up, and the count read again: had it moved on, the entry may be a later job's)
+                    asm volatile("" ::: "memory");
+                    const int pw = sqv_ld_relaxed(p_posted);
+                    if (pw == (int)c.w) break;
+                    asm volatile("" ::: "memory");
+                    const int js = sqv_ld_relaxed(p_jstep + ((int)c.w & (SQV_JQ - 1)));
+                    asm volatile("" ::: "memory");
+                    const int ap2 = sqv_ld_relaxed(p_applied);
+                    if (ap2 == (int)c.w) {
+                        s0 = min(s0, js - 1);
+                        if (s0 >= t - SQV_LOOK) break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
                 if (t - SQV_LOOK - s0 > 2) __builtin_amdgcn_s_sleep(24); else __builtin_amdgcn_s_sleep(3);
             }
             if (stop) break;
@@ -1044,6 +1215,6 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
         ch.energy = E;
         ch.step0 += (unsigned long long)nsteps;
         for (int q = 0; q < 8; q++) { ch.att[q] += (unsigned long long)p_cnt[q]; ch.acc[q] += (unsigned long long)p_cnt[8 + q]; }
-        ch.n_serial += nser; ch.n_rebuild += nreb; ch.n_batches += nwait; ch.n_applied += napp;
+        ch.n_serial += nser; ch.n_rebuild += nreb + (unsigned long long)v.ctl[61]; ch.n_batches += nwait; ch.n_applied += napp;
     }
 }

@@ -30,7 +30,7 @@ size_t pmc_sqv_layout(int n_, int d, int nspecies, int ncell, int nn_, int vcap,
     const size_t o_lst = o;       o = sqv_align(o + nb * (size_t)vcap * 2, 16);
     const size_t o_models = o;    o = sqv_align(o + (size_t)nspecies * nspecies * sizeof(DevModel), 16);
     const size_t o_terms = o;     o = sqv_align(o + nb * 2 * tstride * sizeof(double), 16);      // (the evaluators' only)
-    const size_t o_ctl = o;       o = sqv_align(o + 24 * sizeof(int), 16);
+    const size_t o_ctl = o;       o = sqv_align(o + 64 * sizeof(int), 16);
     if (s) {
         s->vcap = vcap; s->ccap = ccap; s->tstride = (int)tstride;
         s->o_vrows = (int)o_vrows; s->o_crows = (int)o_crows; s->o_cs = (int)o_cs; s->o_vcnt = (int)o_vcnt;
