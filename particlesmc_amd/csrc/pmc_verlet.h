@@ -1,5 +1,6 @@
 // pmc_verlet.h -- engine 4 of the reference-order chain: VerletList systems (src/neighbours.jl:387-543) with their whole state in
-// LDS, one wavefront RESOLVING the steps in order while six others EVALUATE the steps behind them.
+// LDS, one wavefront RESOLVING the steps in order while twelve others EVALUATE the steps behind them, one APPLIES the list edits
+// the resolver hands over, and one evaluates AGAIN the steps whose first evaluation did not stand.
 //
 // The reference's only CI system (test/runtests.jl:22-91: config_0, N = 1290, 2-D ternary JBB) runs with a VerletList, dr = 0.2.
 // On the literal loop (pmc_ref.h, engine 1) a step of that chain is ~1 us of work behind a dozen dependent global-memory round
@@ -10,21 +11,29 @@
 //     and written once per rebuild: it stays in global memory (a working copy, L2), its load issued before the sums it hides behind.
 //  2. The random part of a step is a pure function of the step counter, so the particle of step t + k is known in advance; and a
 //     Verlet row is short (27 ids), so a step reads almost nothing: x_i, last_i, neighbours[i] and the positions / species of its
-//     members.  The workgroup is a pipeline of eight wavefronts over batches of SQV_NB = 6 steps:
-//       * six EVALUATORS each take one step of batch b + 1 and work it out against the state as they find it: e1 and e2 in row
-//         order, the decision, the position to store; and if the trial position is dr / 2 from the last update, the REBUILT list
-//         (the scan of the neighbourhood in cell / vector order, src/neighbours.jl:523-538), e2 over it, and the list of the
-//         reverted position if the step is rejected far from where it was re-listed;
-//       * wavefront 0, the RESOLVER, meanwhile walks batch b in step order.  A step whose inputs nobody has touched since its
-//         evaluation began -- no mark on i in the two epochs of `dirty` (the resolver marks i and every member of neighbours[i]
-//         whenever it moves, re-lists or re-labels i: lists are symmetric at every point of the reference's algorithm), and for
-//         a rebuilt list no mark on the cells its scan read -- IS its evaluation: energy update, position store, marks; a
-//         rebuild is applied from the evaluator's list (i leaves its old neighbours' lists in registers, is appended to the new
-//         ones').  Any other step, and every swap, is run by the resolver on the current state exactly as the literal loop runs it;
-//       * wavefront 4 (the resolver's SIMD mate, otherwise idle) generates the random parts, 64 steps at a time.
-//     One workgroup barrier per batch.  An evaluation that raced with the resolver's stores may have read anything -- every id,
-//     count and cell index it can have read is a valid one (rows and cell vectors are zero-filled at the start, entries are
-//     stored before the counts that expose them), and whatever it computed is discarded by the marks.
+//     members.  The workgroup is a rolling pipeline of sixteen wavefronts, no barrier inside a launch:
+//       * twelve EVALUATORS (evaluator e: the steps t = e mod 12) each begin their step once the resolver is within SQV_LOOK
+//         steps of it and work it out against the state as they find it: e1 and e2 in row order, the decision, the position to
+//         store; and if the trial position is dr / 2 from the last update, the REBUILT list (the scan of the neighbourhood in
+//         cell / vector order, src/neighbours.jl:523-538), e2 over it, and the list of the reverted position if the step is
+//         rejected far from where it was re-listed.  They leave a record (SqvSpec) and the list.
+//       * wavefront 0, the RESOLVER, walks the steps in order.  A step whose inputs nobody has touched since its evaluation
+//         began -- no mark on i newer than the evaluation (the resolver marks i and every member of neighbours[i] with the
+//         step number whenever it moves, re-lists or re-labels i: lists are symmetric at every point of the reference's
+//         algorithm), and for a rebuilt list no such mark on the cells its scan read -- IS its evaluation: energy update,
+//         position store, marks.  A rebuilt list is HANDED OVER: the resolver marks what the edit will touch (i, its old and
+//         new neighbours, the cells) and goes on;
+//       * wavefront 8, the APPLIER, makes the edits in the order they were handed over (i leaves its old neighbours' rows in
+//         registers, is appended to the new ones', moves between cell vectors).  An evaluation can vouch for the lists only up
+//         to the step before the oldest edit in the making, and says so in its record; the resolver waits for the applier only
+//         before a step it runs on the lists itself;
+//       * a step whose evaluation does not stand is evaluated AGAIN on the state as it is by wavefront 12 (the second opinion:
+//         same code as an evaluator, into the same record) and taken like any other; swaps are run by the resolver, an inexact
+//         revert that re-lists the particle by wavefront 12, exactly as the literal loop runs them;
+//       * wavefront 4 generates the random parts, 64 steps at a time.  (0, 4, 8 and 12 share a SIMD: three of them sleep.)
+//     An evaluation that raced with the resolver's or the applier's stores may have read anything -- every id, count and cell
+//     index it can have read is a valid one (rows and cell vectors are zero-filled at the start, entries are stored before the
+//     counts that expose them), and whatever it computed is discarded by the marks.
 //
 // Same arithmetic, same iterator order (neighbours[i] in vector order: deleteat! keeps it, push! appends), same bits as
 // orc_mc_steps_sequential: positions, positions_at_last_update, cells[], neighbours[], accept counts, system.energy.
@@ -35,11 +44,14 @@
 
 #define SQV_GEN 128               // ring of random parts: two blocks of 64 steps
 #ifndef SQV_NW
-#define SQV_NW 16                 // wavefronts of a chain's workgroup: wavefront 0 resolves, 4 generates, 8 and 12 (the resolver's other SIMD mates) idle
+#define SQV_NW 16                 // wavefronts of a chain's workgroup: wavefront 0 resolves, 4 generates, 8 applies the handed-over list edits, 12 evaluates again
 #endif
 #define SQV_NB (3 * SQV_NW / 4)   // evaluators (wavefronts 1-3, 5-7, 9-11, 13-15): evaluator e takes the steps t = e (mod SQV_NB)
 #ifndef SQV_LOOK
 #define SQV_LOOK 7                // an evaluator begins step t once the resolver has finished step t - SQV_LOOK - 1 (< SQV_NB: its record is free by then)
+#endif
+#ifndef SQV_HOLD
+#define SQV_HOLD SQV_LOOK         // ... and no later than SQV_HOLD steps behind the oldest rebuild the applier has not finished (<= SQV_NB - 1: the list of the evaluator's last step is the applier's until then; 7 / 9 / 11: 1.007 / 0.984 / 0.963e6 moves/s)
 #endif
 #define SQV_HW 10                 // rows of 4 * SQV_HW ids leave a list in registers (sqv_leave_lists)
 
@@ -569,9 +581,11 @@ __device__ __forceinline__ bool sqv_disp_serial(const SqvArgs &s, const SqvView 
 }
 
 // An evaluator's work on one step: everything the resolver needs to take the step as it is, provided nobody touches its inputs.
-template <int D, int KIND>
+// HAVE_E1 (the second opinion on a step whose first evaluation stands as far as e1 goes -- nobody has touched i or its row -- and
+// whose trial position rebuilds the list): e1 is taken from it, e2 follows the scan.
+template <int D, int KIND, bool HAVE_E1 = false>
 __device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v, double *tb, const SqGen &ge, double T, SqvSpec *out, unsigned short *lst,
-                                             int s0, int seq)
+                                             int s0, int seq, double e1_in = 0.0)
 {
     const RefArgs &a = s.a;
     const int lane = wave_lane();
@@ -594,8 +608,15 @@ __device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v,
             xr[q] = xn[q] + (-ge.d[q]);
         }
         const int spi = (S > 1) ? min((int)v.species[i], S - 1) : 0;
-        double e1, e2;
-        sqv_energy2<D, KIND>(s, v, i, spi, spi, -1, 0, x, xn, e1, e2);
+        double e1 = e1_in, e2 = 0.0;
+        bool sums = true;
+        if (HAVE_E1) {
+            double dd = 0.0;
+#pragma unroll
+            for (int q = 0; q < D; q++) { const double dx = xn[q] - last[q]; dd = (q == 0) ? dx * dx : dd + dx * dx; }
+            sums = dd < a.dr2o4;                                     // (the list stays after all: both sums over the row)
+        }
+        if (sums) sqv_energy2<D, KIND>(s, v, i, spi, spi, -1, 0, x, xn, e1, e2);
         double d2 = 0.0, d2r = 0.0, d2b = 0.0;
         bool chg = false;
 #pragma unroll
@@ -656,18 +677,6 @@ __device__ __forceinline__ void sqv_evaluate(const SqvArgs &s, const SqvView &v,
 
 // a mark older than `window` steps (the step number + 1 is `now`): set before the evaluation in question began
 __device__ __forceinline__ bool sqv_fresh(int tv, int now, int window) { return ((now - tv) & 0xffff) > window; }
-
-// no mark since the evaluation began on any of the cells a scan around c2 reads
-template <int D>
-__device__ __forceinline__ bool sqv_cells_clean(const SqvView &v, int c2, int now, int window)
-{
-    constexpr int NN = (D == 3) ? 27 : 9;
-    const int lane = wave_lane();
-    const int cnt = v.nbrcnt[c2];
-    bool bad = false;
-    if (lane < cnt) bad = !sqv_fresh(v.ctouch[v.nbr[c2 * NN + lane]], now, window);
-    return __ballot(bad) == 0ull;
-}
 
 template <int D, int KIND>
 __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
@@ -943,18 +952,22 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                     // the evaluation does not stand (or the step is one an evaluation cannot settle): the lists as every job so
                     // far leaves them, then ...
                     if (pass == 0) { nser++; SQVT_COUNT(11); }
+                    SQVT(7);
                     while (sqv_ld(p_applied) != posted) {
                         if (sqv_ld(p_err)) { stop = true; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (stop) break;
+                    SQVT(4);
                     if (pass == 0) {
                         // ... the step is evaluated AGAIN on the state as it stands, exactly as an evaluator would (by wavefront 12,
                         // into the record and the buffers of the step's own evaluator, which is through with them and far from
                         // its next step), and taken as above: a rebuilt list goes to the applier like any other
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the resolver's own earlier stores to positions_at_last_update)
-                        if (lane == 0) sqv_st(p_ask, 4 * now + 1);
-                        while (sqv_ld(p_told) != 4 * now + 1) __builtin_amdgcn_s_sleep(1);
+                        const int how = (clean && (sp.flags & SQV_REBUILD)) ? 3 : 1;       // (3: e1 of the first evaluation stands)
+                        if (lane == 0) { *reinterpret_cast<volatile double *>(v.ctl + 56) = sp.e1; sqv_st(p_ask, 4 * now + how); }
+                        while (sqv_ld(p_told) != 4 * now + how) __builtin_amdgcn_s_sleep(1);
+                        SQVT(5);
                         SqvRaw rawb;
                         sqv_rec_request(rec, zero, rawb);
                         sqv_rec_decode(rawb, sp);
@@ -1108,7 +1121,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                 continue;
             }
             if (fin) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
     } else if (wv == 12) {
         // ---- the SECOND OPINION: step t on the state the resolver has stopped at
@@ -1121,6 +1134,9 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                 const SqGen ge = v.gen[t & (SQV_GEN - 1)];
                 if ((ask & 3) == 1) {
                     sqv_evaluate<D, KIND>(s, v, tbr + (size_t)slot * 2 * s.tstride, ge, T, spec0 + slot, lst0 + slot * vcap, t, t + 1);
+                } else if ((ask & 3) == 3) {
+                    const double e1 = *reinterpret_cast<volatile double *>(v.ctl + 56);
+                    sqv_evaluate<D, KIND, true>(s, v, tbr + (size_t)slot * 2 * s.tstride, ge, T, spec0 + slot, lst0 + slot * vcap, t, t + 1, e1);
                 } else {
                     // the Displacement step as the literal loop runs it, on the live lists
                     v.stamp = (unsigned short)(t + 1);
@@ -1136,7 +1152,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                 continue;
             }
             if (fin) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
         if (lane == 0) v.ctl[61] = (int)nser;                 // (here: the rebuilds of the steps this wavefront ran as the literal loop does)
         nser = 0;
@@ -1164,7 +1180,7 @@ __global__ __launch_bounds__(SQV_NW * 64) void k_sq_verlet(SqvArgs s)
                     const int ap2 = sqv_ld_relaxed(p_applied);
                     if (ap2 == (int)c.w) {
                         s0 = min(s0, js - 1);
-                        if (s0 >= t - SQV_LOOK) break;
+                        if (s0 >= t - SQV_HOLD) break;              // (and the applier is through with this evaluator's last list)
                     }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
