@@ -648,7 +648,7 @@ def other_configs(pmc, budget_cpu_s=1.2):
         pmc.mc_sweep_many(chains, vpool, nsweeps=20, mode="sequential")
         dtn = time.perf_counter() - t0
         rows.append({"config": "the reference's CI system (test/runtests.jl:22-91): config_0, N=1290 2-D ternary JBB, T=0.231, VerletList dr=0.2, Displacement sigma=0.05; "
-                               "the reference's sequential chain on engine 4 (state in LDS, one resolver and twelve evaluators per chain)",
+                               "the reference's sequential chain on engine 4 (state in LDS; per chain one resolver, twelve evaluators, one wavefront applying the list edits, one evaluating again)",
                      "reference_order_chain": {"moves_per_s_one_chain": 100 * one.N / dt1, "us_per_step_one_chain": 1e6 * dt1 / (100 * one.N),
                                                "kernel_moves_per_s_one_chain": 100 * one.N / (st1.sweep_kernel_ms * 1e-3),
                                                "moves_per_s_256_chains_one_launch": 256 * 20 * one.N / dtn,
