@@ -196,3 +196,24 @@ def test_random_empty_list_chain(gpu, case):
         assert np.array_equal(st.attempted[: len(pm)], att) and np.array_equal(st.accepted[: len(pm)], acc), (call, engine, st.accepted, acc)
         assert np.array_equal(g.position, o.positions()), (call, engine)
         assert g.energy[0] == o.energy, (call, engine, g.energy[0], o.energy)
+
+
+def test_engine5_wavefronts_per_chain_are_eight_or_sixteen(gpu):
+    """pmc_set_sequential_engine(h, 5, window): with engine 5 the window is the number of wavefronts per chain -- 0 (the library's
+    choice), 8 or 16; anything else is a bad argument and leaves the selection as it was."""
+    from oracle import oracle as O
+    from particlesmc_amd import _lib
+    pmc = gpu
+    pos, sp, rho = _benchmark_system()
+    N = len(pos)
+    g = pmc.System(pos, sp, rho, 0.2, pmc.BHHP(), list_type=pmc.EmptyList, seed=5)
+    o = O.System(pos, sp, rho, 0.2, O.bhhp(), O.EMPTYLIST)
+    g.set_sequential_engine(5, 8)
+    for bad in (4, 12, 64):
+        with pytest.raises(_lib.PMCError) as ei:
+            g.set_sequential_engine(5, bad)
+        assert ei.value.code == _lib.PMC_ERR_BADARG
+    st = pmc.mc_sweep(g, [_disp(pmc, 0.1)], nsweeps=3, mode="sequential")
+    att, acc = o.mc_steps(O.make_pool([{"kind": "Displacement", "sigma": 0.1}]), 5, 0, 0, 3 * N)
+    assert st.accepted[0] == acc[0] and np.array_equal(g.position, o.positions()) and g.energy[0] == o.energy
+    assert g.verlet_info()[3] == 3 * N                     # (engine 5 ran the call)
