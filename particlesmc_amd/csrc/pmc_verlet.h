@@ -418,62 +418,81 @@ __device__ __forceinline__ int sqv_scan(const SqvArgs &s, const SqvView &v, int 
     constexpr int NN = (D == 3) ? 27 : 9;
     const int lane = wave_lane();
     const int vcap = s.vcap, ccap = s.ccap, S = s.a.S;
+    const int cc_any = (int)v.nbr[c2 * NN + min(lane, NN - 1)];          // (with the count: one round trip for the two)
     const int cnt = min((int)v.nbrcnt[c2], NN);
-    const int cc = (lane < cnt) ? (int)v.nbr[c2 * NN + lane] : 0;
+    const int cc = (lane < cnt) ? cc_any : 0;
     const int len = (lane < cnt) ? min((int)v.ccnt[cc], ccap) : 0;
     const int incl = sq_scan32(len);                                 // (inclusive; lanes >= cnt repeat the total)
     const int total = __builtin_amdgcn_readlane(incl, 31);
     unsigned short *row_i = v.vrows + i * vcap;
     const int tmax = 2 * s.tstride - 2 * SQ_TERMS_PAD;
     int fill = 0, tcnt = 0;
-    for (int base = 0; base < total; base += PMC_WAVE) {
-        const int t = base + lane;
-        int l = 0;
+    // TWO trips of 64 candidates per turn of the loop, every load of both requested before anything of either is stored (a 2-D
+    // neighbourhood is 80 candidates: the second trip's three dependent round trips ride behind the first's)
+    for (int base = 0; base < total; base += 2 * PMC_WAVE) {
+        int tt[2], jj[2];
+        bool in[2];
+        double uu[2];
 #pragma unroll
-        for (int m = 0; m < NN - 1; m++) l += (t >= __builtin_amdgcn_readlane(incl, m)) ? 1 : 0;
-        l = min(l, cnt - 1);
-        const int cc_l = __shfl(cc, l, PMC_WAVE);
-        const int end_l = __shfl(incl, l, PMC_WAVE), len_l = __shfl(len, l, PMC_WAVE);
-        bool in = false;
-        int j = 0;
-        double u = 0.0;
-        if (t < total) {
-            j = v.crows[cc_l * ccap + (t - (end_l - len_l))];
-            if (j != i) {
-                double xj[3] = {0, 0, 0};
+        for (int h = 0; h < 2; h++) {
+            const int t = base + h * PMC_WAVE + lane;
+            tt[h] = t;
+            int l = 0;
 #pragma unroll
-                for (int q = 0; q < D; q++) xj[q] = v.pos[j * D + q];
-                const double r2 = sqv_dist2<D>(s, x, xj);
-                in = r2 < s.a.rcutoff2;
-                if (WITH_E && in) {
-                    const DevModel &m = v.models[spi * S + ((S > 1) ? (int)v.species[j] : 0)];
-                    if (!(r2 > m.rcut2)) u = (KIND == 4 ? dev_potential_dyn(r2, m) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2, m));
-                }
+            for (int m = 0; m < NN - 1; m++) l += (t >= __builtin_amdgcn_readlane(incl, m)) ? 1 : 0;
+            l = min(l, cnt - 1);
+            const int cc_l = __shfl(cc, l, PMC_WAVE);
+            const int end_l = __shfl(incl, l, PMC_WAVE), len_l = __shfl(len, l, PMC_WAVE);
+            const int at = min(max(t - (end_l - len_l), 0), ccap - 1);
+            jj[h] = (int)v.crows[cc_l * ccap + at];                 // (a candidate beyond the total reads some valid id and is dropped below)
+        }
+        double r2[2];
+        int sj[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double xj[3] = {0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < D; q++) xj[q] = v.pos[jj[h] * D + q];
+            sj[h] = (WITH_E && S > 1) ? (int)v.species[jj[h]] : 0;
+            r2[h] = sqv_dist2<D>(s, x, xj);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            in[h] = tt[h] < total && jj[h] != i && r2[h] < s.a.rcutoff2;
+            uu[h] = 0.0;
+            if (WITH_E && in[h]) {
+                const DevModel &m = v.models[spi * S + sj[h]];
+                if (!(r2[h] > m.rcut2)) uu[h] = (KIND == 4 ? dev_potential_dyn(r2[h], m) : dev_potential<(KIND == 4 ? 0 : KIND)>(r2[h], m));
             }
         }
-        const unsigned long long mk = __ballot(in);
-        if (in) {
-            const int p = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-            if (APPLY) {
-                const int nj = v.vcnt[j];
-                if (p < vcap && nj < vcap) {
-                    row_i[p] = (unsigned short)j;
-                    v.vrows[j * vcap + nj] = (unsigned short)i;
-                    v.vcnt[j] = (unsigned short)(nj + 1);
-                    v.touch[j] = v.stamp;
-                } else {
-                    err |= SQV_ERR_ROW;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = jj[h];
+            const unsigned long long mk = __ballot(in[h]);
+            if (in[h]) {
+                const int p = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (APPLY) {
+                    const int nj = v.vcnt[j];
+                    if (p < vcap && nj < vcap) {
+                        row_i[p] = (unsigned short)j;
+                        v.vrows[j * vcap + nj] = (unsigned short)i;
+                        v.vcnt[j] = (unsigned short)(nj + 1);
+                        v.touch[j] = v.stamp;
+                    } else {
+                        err |= SQV_ERR_ROW;
+                    }
+                } else if (p < vcap) {
+                    lst[p] = (unsigned short)j;
                 }
-            } else if (p < vcap) {
-                lst[p] = (unsigned short)j;
             }
-        }
-        fill += __popcll(mk);
-        if (WITH_E) {
-            const unsigned long long mt = __ballot(u != 0.0);
-            const int r = tcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mt, 0u));
-            if (u != 0.0 && r < tmax) tb[r] = u;
-            tcnt = min(tcnt + __popcll(mt), tmax);
+            fill += __popcll(mk);
+            if (WITH_E) {
+                const double u = uu[h];
+                const unsigned long long mt = __ballot(u != 0.0);
+                const int r = tcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mt, 0u));
+                if (u != 0.0 && r < tmax) tb[r] = u;
+                tcnt = min(tcnt + __popcll(mt), tmax);
+            }
         }
     }
     if (WITH_E) {
